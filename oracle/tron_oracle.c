@@ -1,0 +1,565 @@
+/*
+ * tron_oracle.c -- CPU restatement of TRON's 2-D radial grid/degrid path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load it, and only as the checker / reported CPU
+ * baseline.  The shipped library (tron_amd/csrc) never links, loads or calls it.
+ *
+ * What it restates (all citations are file:line into the reference, davidssmith/TRON):
+ *   src/tron.cu:161-178   fftshift
+ *   src/tron.cu:255-268   coilcombinesos
+ *   src/tron.cu:304-349   besseli0, kernel_shape, gridkernel
+ *   src/tron.cu:351-378   gridkernelhat, modang
+ *   src/tron.cu:390-402   deapodkernel
+ *   src/tron.cu:405-416   precompensate
+ *   src/tron.cu:418-457   crop, pad
+ *   src/tron.cu:465-536   gridradial2d
+ *   src/tron.cu:540-577   degridradial2d
+ *   src/tron.cu:623-649   tron_nufft_adj_radial2d / tron_nufft_radial2d (stage order)
+ *   src/tron.cu:726-786   recon_radial2d (slice loop, offsets)
+ *   src/tron.cu:905-961   main() dimension logic
+ *   src/float2math.h      float2 operator semantics (notably /= multiplies by 1.0f/s, :23)
+ *
+ * Arithmetic contract: every expression is evaluated with the C/C++ type-promotion rules
+ * the reference source implies when built for an IEEE-754 host: float unless a double
+ * literal (M_PI, the besseli0 coefficients) promotes the expression, sincosf/fmodf/
+ * hypotf/sinhf from libm, true division, correctly rounded sqrtf, and NO fused
+ * multiply-add (build with -ffp-contract=off).  The real CUDA build used
+ * --use_fast_math (src/Makefile:3), whose approximate intrinsics are not reproducible
+ * off an NVIDIA GPU; the IEEE evaluation is the defined parity target.
+ *
+ * PARITY PINNING: the reference holds no golden vectors, known-answer tests or fixtures
+ * for this path, and src/tron.cu cannot be built in this image (it
+ * needs the CUDA toolkit headers, cuFFT and cuBLAS).  The grid/degrid restatement is
+ * therefore "parity unpinned" against reference execution; it is pinned only by
+ * line-by-line citation, by an independent numpy restatement (tests/ref_numpy.py) and
+ * by mathematical properties (DTFT agreement, adjointness).  The .ra format and the
+ * half-float conversions ARE pinned against the reference's own src/ra.cu and
+ * src/float16.cu compiled unmodified into oracle/_ref (see oracle/Makefile).
+ *
+ * The only deliberate deviations, each needed to make the reference's undefined
+ * behaviour defined:
+ *   - per-thread channel scratch is heap-sized instead of MAXCHAN=6 (tron.h:51), so
+ *     nchan > 6 works instead of overflowing the stack array;
+ *   - the FFT (cuFFT in the reference, tron.cu:205-220,632,645) is an unnormalised DFT
+ *     evaluated in double precision and rounded once to float: any correct FFT agrees
+ *     with it to fp32 rounding.
+ */
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+typedef struct { float x, y; } cfloat;
+
+/* tron.cu:90 */
+static const float PHI = 1.9416089796736116f;
+
+/* ------------------------------------------------------------------ scalar functions */
+
+/* tron.cu:304-321.  The coefficients are double literals, so both Horner chains run in
+   double and are rounded to float on assignment; the final quotient is float/float. */
+float oracle_besseli0(const float x)
+{
+    if (x == 0.f) return 1.f;
+    float z = x * x;
+    float num = (z* (z* (z* (z* (z* (z* (z* (z* (z* (z* (z* (z* (z*
+        (z* 0.210580722890567e-22  + 0.380715242345326e-19 ) +
+        0.479440257548300e-16) + 0.435125971262668e-13 ) +
+        0.300931127112960e-10) + 0.160224679395361e-7  ) +
+        0.654858370096785e-5)  + 0.202591084143397e-2  ) +
+        0.463076284721000e0)   + 0.754337328948189e2   ) +
+        0.830792541809429e4)   + 0.571661130563785e6   ) +
+        0.216415572361227e8)   + 0.356644482244025e9   ) +
+        0.144048298227235e10);
+    float den = (z*(z*(z-0.307646912682801e4)+
+        0.347626332405882e7)-0.144048298227235e10);
+    return -num/den;
+}
+
+/* tron.cu:323-335 (BEATTY_BETA is off in the reference Makefile) */
+float oracle_kernel_shape(const float kernwidth, const float gridos)
+{
+    (void)gridos;
+    return 2.34f*2.0f*kernwidth;
+}
+
+/* tron.cu:338-349 */
+float oracle_gridkernel(const float x, const float kernwidth, const float sigma)
+{
+    float beta = oracle_kernel_shape(kernwidth, sigma);
+    if (fabsf(x) < kernwidth) {
+        float r = x/kernwidth;
+        float f = sqrtf(1.0f - r*r);
+        return 0.5f*oracle_besseli0(beta*f)/kernwidth;
+    } else
+        return 0.0f;
+}
+
+/* tron.cu:351-370.  r = M_PI*J*u is a double product rounded to float. */
+float oracle_gridkernelhat(const float u, const float kernwidth, const float sigma)
+{
+    float J = 2.0f*kernwidth;
+    float beta = oracle_kernel_shape(kernwidth, sigma);
+    float r = M_PI*J*u;
+    float q = r*r - beta*beta;
+    float y, z;
+    if (q > 0) {
+        z = sqrtf(q);
+        y = sinf(z) / z;
+    } else if (q < 0) {
+        z = sqrtf(-q);
+        y = sinhf(z) / z;
+    } else
+        y = 1;
+    return y;
+}
+
+/* tron.cu:372-378 */
+float oracle_modang(const float x)
+{
+    const float TWOPI = 2.f*M_PI;
+    float y = fmodf(x, TWOPI);
+    return y < 0.f ? y + TWOPI : y;
+}
+
+/* Spoke angle used by the gridding kernel, tron.cu:509 */
+float oracle_grid_angle(int pe, int npe, int skip_angles, int golden)
+{
+    float t = golden ? oracle_modang(PHI * (float)(pe + skip_angles))
+                     : pe*2.0f*M_PI / (float)npe + M_PI*0.5f;
+    return t;
+}
+
+/* Spoke angle used by the degridding kernel, tron.cu:555 */
+float oracle_degrid_angle(int pe, int npe, int skip_angles, int golden)
+{
+    float T = golden ? oracle_modang(PHI*(pe + skip_angles)) : pe*M_PI/(float)npe;
+    return T;
+}
+
+/* ------------------------------------------------------------------ data movement */
+
+/* tron.cu:161-178.  direction 0 = FFT_SHIFT_FORWARD, 1 = FFT_SHIFT_INVERSE (:159) */
+void oracle_fftshift(cfloat *dst, const cfloat *src, const int n, const int nchan, int direction)
+{
+    int offset = direction == 0 ? n/2 : n - n/2;
+    for (int idsrc = 0; idsrc < n*n; ++idsrc) {
+        int xsrc = idsrc / n;
+        int ysrc = idsrc % n;
+        int xdst = (xsrc + offset) % n;
+        int ydst = (ysrc + offset) % n;
+        int iddst = n*xdst + ydst;
+        for (int c = 0; c < nchan; ++c)
+            dst[(size_t)iddst*nchan + c] = src[(size_t)idsrc*nchan + c];
+    }
+}
+
+/* tron.cu:418-431 */
+void oracle_crop(cfloat *dst, const int ndst, const cfloat *src, const int nsrc, const int nchan)
+{
+    const int w = (nsrc - ndst) / 2;
+    for (int id = 0; id < ndst*ndst; ++id) {
+        int xdst = id / ndst;
+        int ydst = id % ndst;
+        int srcid = (xdst + w)*nsrc + ydst + w;
+        for (int c = 0; c < nchan; ++c)
+            dst[(size_t)nchan*id + c] = src[(size_t)nchan*srcid + c];
+    }
+}
+
+/* tron.cu:435-457.  The strict "> 0" tests drop source row 0 and column 0. */
+void oracle_pad(cfloat *dst, const int ndst, const cfloat *src, const int nsrc, const int nchan)
+{
+    const int w = ndst > nsrc ? (ndst - nsrc) / 2 : 0;
+    for (int id = 0; id < ndst*ndst; ++id) {
+        for (int c = 0; c < nchan; ++c) {
+            dst[(size_t)nchan*id + c].x = 0.f;
+            dst[(size_t)nchan*id + c].y = 0.f;
+        }
+        int xdst = id / ndst;
+        int ydst = id % ndst;
+        if ((xdst - w > 0) && (xdst - w < nsrc) &&
+            (ydst - w > 0) && (ydst - w < nsrc)) {
+            size_t srcid = (size_t)(xdst - w)*nsrc + (ydst - w);
+            for (int c = 0; c < nchan; ++c)
+                dst[(size_t)nchan*id + c] = src[(size_t)nchan*srcid + c];
+        }
+    }
+}
+
+/* tron.cu:255-268.  norm(a) = a.x*a.x + a.y*a.y (float2math.h:59) */
+void oracle_coilcombinesos(cfloat *img, const cfloat *coilimg, const int nimg, const int nchan)
+{
+    for (int id = 0; id < nimg*nimg; ++id) {
+        if (nchan > 1) {
+            float val = 0.f;
+            for (int c = 0; c < nchan; ++c) {
+                cfloat a = coilimg[(size_t)nchan*id + c];
+                val += a.x * a.x + a.y * a.y;
+            }
+            img[id].x = sqrtf(val);
+            img[id].y = 0.f;
+        } else
+            img[id] = coilimg[id];
+    }
+}
+
+/* ------------------------------------------------------------------ weights */
+
+/* tron.cu:390-402.  Returns the weight the kernel divides by at linear index id
+   (note the fractional x coordinate). */
+float oracle_deapod_weight(size_t id, const int n, const float m, const float sigma)
+{
+    float x = id / (float)n - (n + 1) / 2;
+    float y = (float)(id % n) - (n + 1) / 2;
+    float scale = 1.f / n / sigma;
+    float wgt = oracle_gridkernelhat(x*scale, m, sigma) * oracle_gridkernelhat(y*scale, m, sigma);
+    return wgt;
+}
+
+void oracle_deapod(cfloat *d_a, const int n, const int nrep, const float m, const float sigma)
+{
+    for (size_t id = 0; id < (size_t)n*n; ++id) {
+        float wgt = oracle_deapod_weight(id, n, m, sigma);
+        /* float2 /= float is "multiply by 1.0f/s", float2math.h:23 */
+        float inv = 1.0f / (wgt > 0.f ? wgt : 1.f);
+        for (int c = 0; c < nrep; ++c) {
+            d_a[(size_t)nrep*id + c].x *= inv;
+            d_a[(size_t)nrep*id + c].y *= inv;
+        }
+    }
+}
+
+/* tron.cu:405-416 (in place, like the reference) */
+void oracle_precompensate(cfloat *nudata, const int nchan, const int nro, const int npe1work)
+{
+    float a = (2.f  - 2.f / (float)npe1work) / (float)nro;
+    float b = 1.f / (float)npe1work;
+    for (int id = 0; id < npe1work; ++id)
+        for (int r = 0; r < nro; ++r) {
+            float sdc = a*fabsf(r - (float)(nro/2)) + b;
+            for (int c = 0; c < nchan; ++c) {
+                size_t k = (size_t)nro*nchan*id + (size_t)nchan*r + c;
+                nudata[k].x *= sdc;
+                nudata[k].y *= sdc;
+            }
+        }
+}
+
+/* ------------------------------------------------------------------ interpolators */
+
+/* tron.cu:465-536.  One "thread" per Cartesian point; the 4x4-blocked tid->(X,Y) map of
+   :488-494 only permutes which thread owns which point, so points are visited in plain
+   raster order here.  The running sum order per point (pe ascending; aligned r loop
+   then anti-aligned r loop) is the reference's. */
+void oracle_gridradial2d(cfloat *udata, const cfloat *nudata, const int nxos,
+    const int nchan, const int nro, const int npe, const float kernwidth, const float gridos,
+    const int skip_angles, const int flag_golden_angle)
+{
+    /* the spoke direction depends only on pe: hoist sincosf out of the point loop
+       (same values the reference recomputes per thread, :509-511) */
+    float *st_tab = (float*)malloc(sizeof(float)*(size_t)npe);
+    float *ct_tab = (float*)malloc(sizeof(float)*(size_t)npe);
+    for (int pe = 0; pe < npe; ++pe) {
+        float t = oracle_grid_angle(pe, npe, skip_angles, flag_golden_angle);
+        sincosf(t, &st_tab[pe], &ct_tab[pe]);
+    }
+#ifdef _OPENMP
+#pragma omp parallel
+#endif
+    {
+        cfloat *utmp = (cfloat*)malloc(sizeof(cfloat)*(size_t)nchan);
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 64)
+#endif
+        for (int id = 0; id < nxos*nxos; ++id) {
+            for (int ch = 0; ch < nchan; ch++) { utmp[ch].x = 0.f; utmp[ch].y = 0.f; }
+            int Y = id / nxos;
+            int X = id % nxos;
+            X -= nxos/2;
+            Y -= nxos/2;
+            float R = hypotf((float)X, (float)Y);
+            int Rhi = fminf(floorf(R + kernwidth), nxos/2-1);
+            int Rlo = fmaxf(ceilf(R - kernwidth), 0);
+            for (int pe = 0; pe < npe; ++pe) {
+                float st = st_tab[pe], ct = ct_tab[pe];
+                for (int r = Rlo; r <= Rhi; ++r) {          /* aligned profiles */
+                    float kx = r*ct;
+                    float ky = r*st;
+                    float wgt = oracle_gridkernel(kx-X, kernwidth, gridos) * oracle_gridkernel(ky-Y, kernwidth, gridos);
+                    int ridx = (r * nro) / nxos;
+                    for (int ch = 0; ch < nchan && wgt > 0.f; ch++) {
+                        cfloat d = nudata[(size_t)nchan*((size_t)nro*pe + ridx + nro/2) + ch];
+                        utmp[ch].x += d.x * wgt;
+                        utmp[ch].y += d.y * wgt;
+                    }
+                }
+                for (int r = -Rhi; r <= -Rlo; ++r) {        /* anti-aligned profiles */
+                    float kx = r*ct;
+                    float ky = r*st;
+                    float wgt = oracle_gridkernel(kx-X, kernwidth, gridos) * oracle_gridkernel(ky-Y, kernwidth, gridos);
+                    int ridx = (r * nro) / nxos;
+                    for (int ch = 0; ch < nchan && wgt > 0.f; ch++) {
+                        cfloat d = nudata[(size_t)nchan*((size_t)nro*pe + ridx + nro/2) + ch];
+                        utmp[ch].x += d.x * wgt;
+                        utmp[ch].y += d.y * wgt;
+                    }
+                }
+            }
+            float scale_factor =  1.f / nxos / npe;
+            for (int ch = 0; ch < nchan; ++ch) {
+                udata[(size_t)nchan*id + ch].x = utmp[ch].x * scale_factor;
+                udata[(size_t)nchan*id + ch].y = utmp[ch].y * scale_factor;
+            }
+        }
+        free(utmp);
+    }
+    free(st_tab);
+    free(ct_tab);
+}
+
+/* tron.cu:540-577.  X is the sine (row) coordinate, Y the cosine (column) one. */
+void oracle_degridradial2d(cfloat *nudata, const cfloat *udata, const int n, const int nrep,
+    const int nro, const int npe, const float W, const float gridos, const int skip_angles,
+    const int flag_golden_angle)
+{
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+    for (int id = 0; id < nro*npe; ++id) {
+        for (int c = 0; c < nrep; ++c) { nudata[(size_t)nrep*id + c].x = 0.f; nudata[(size_t)nrep*id + c].y = 0.f; }
+        int pe = id / nro;
+        int ro = id % nro;
+        float R = (float)ro/(float)nro - 0.5f;
+        float T = oracle_degrid_angle(pe, npe, skip_angles, flag_golden_angle);
+        float X, Y;
+        sincosf(T, &X, &Y);
+        X = n*R*X + (n + 1)/2;
+        Y = n*R*Y + (n + 1)/2;
+        for (int xu = ceilf(X-W); xu <= (X+W); ++xu) {
+            float wgtx = oracle_gridkernel(xu-X, W, gridos);
+            for (int yu = ceilf(Y-W); yu <= (Y+W); ++yu) {
+                float wgt = wgtx * oracle_gridkernel(yu-Y, W, gridos);
+                int i = (xu + n) % n;
+                int j = (yu + n) % n;
+                size_t offset = (size_t)nrep*((size_t)i*n + j);
+                for (int c = 0; c < nrep; ++c) {
+                    nudata[(size_t)nrep*id + c].x += udata[offset + c].x * wgt;
+                    nudata[(size_t)nrep*id + c].y += udata[offset + c].y * wgt;
+                }
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ DFT (stands for cuFFT) */
+
+static void dft_line(double *re, double *im, int n, int sign, double *wr, double *wi, double *tr, double *ti)
+{
+    if ((n & (n - 1)) == 0) {
+        /* iterative radix-2, decimation in time */
+        for (int i = 1, j = 0; i < n; ++i) {
+            int bit = n >> 1;
+            for (; j & bit; bit >>= 1) j ^= bit;
+            j ^= bit;
+            if (i < j) { double t = re[i]; re[i] = re[j]; re[j] = t; t = im[i]; im[i] = im[j]; im[j] = t; }
+        }
+        for (int len = 2; len <= n; len <<= 1) {
+            int step = n / len;
+            for (int i = 0; i < n; i += len)
+                for (int k = 0; k < len/2; ++k) {
+                    double cr = wr[k*step], ci = sign * wi[k*step];
+                    double ur = re[i+k], ui = im[i+k];
+                    double vr = re[i+k+len/2]*cr - im[i+k+len/2]*ci;
+                    double vi = re[i+k+len/2]*ci + im[i+k+len/2]*cr;
+                    re[i+k] = ur + vr; im[i+k] = ui + vi;
+                    re[i+k+len/2] = ur - vr; im[i+k+len/2] = ui - vi;
+                }
+        }
+    } else {
+        for (int k = 0; k < n; ++k) {
+            double sr = 0, si = 0;
+            for (int j = 0; j < n; ++j) {
+                int idx = (int)(((long long)k * j) % n);
+                double cr = wr[idx], ci = sign * wi[idx];
+                sr += re[j]*cr - im[j]*ci;
+                si += re[j]*ci + im[j]*cr;
+            }
+            tr[k] = sr; ti[k] = si;
+        }
+        memcpy(re, tr, sizeof(double)*n);
+        memcpy(im, ti, sizeof(double)*n);
+    }
+}
+
+/* Unnormalised 2-D DFT of nchan channel-interleaved n x n images: the transform cuFFT
+   performs for the plan of tron.cu:205-220 (istride = nchan, idist = 1, batch = nchan).
+   sign = -1: CUFFT_FORWARD (tron.cu:645); sign = +1: CUFFT_INVERSE (tron.cu:632). */
+void oracle_fft2(cfloat *dst, const cfloat *src, const int n, const int nchan, const int sign)
+{
+    double *wr = (double*)malloc(sizeof(double)*n), *wi = (double*)malloc(sizeof(double)*n);
+    for (int k = 0; k < n; ++k) { wr[k] = cos(2*M_PI*k/n); wi[k] = sin(2*M_PI*k/n); }
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+    for (int c = 0; c < nchan; ++c) {
+        double *are = (double*)malloc(sizeof(double)*(size_t)n*n), *aim = (double*)malloc(sizeof(double)*(size_t)n*n);
+        double *lr = (double*)malloc(sizeof(double)*n), *li = (double*)malloc(sizeof(double)*n);
+        double *tr = (double*)malloc(sizeof(double)*n), *ti = (double*)malloc(sizeof(double)*n);
+        for (size_t i = 0; i < (size_t)n*n; ++i) { are[i] = src[i*nchan + c].x; aim[i] = src[i*nchan + c].y; }
+        for (int row = 0; row < n; ++row)
+            dft_line(are + (size_t)row*n, aim + (size_t)row*n, n, sign, wr, wi, tr, ti);
+        for (int col = 0; col < n; ++col) {
+            for (int row = 0; row < n; ++row) { lr[row] = are[(size_t)row*n + col]; li[row] = aim[(size_t)row*n + col]; }
+            dft_line(lr, li, n, sign, wr, wi, tr, ti);
+            for (int row = 0; row < n; ++row) { are[(size_t)row*n + col] = lr[row]; aim[(size_t)row*n + col] = li[row]; }
+        }
+        for (size_t i = 0; i < (size_t)n*n; ++i) { dst[i*nchan + c].x = (float)are[i]; dst[i*nchan + c].y = (float)aim[i]; }
+        free(are); free(aim); free(lr); free(li); free(tr); free(ti);
+    }
+    free(wr); free(wi);
+}
+
+/* ------------------------------------------------------------------ pipelines */
+
+typedef struct {
+    /* inputs, as main() and the getopt loop leave them (tron.cu:66-87, 822-874) */
+    int adjoint, golden_angle, koosh;
+    float gridos, kernwidth, data_undersamp;
+    int prof_slide, skip_angles;
+    /* derived (tron.cu:905-961) */
+    int nc, nt, nro, npe1, npe2, npe1work;
+    int nx, ny, nz, nxos, nyos, nzos;
+    uint64_t out_dims[5];
+    uint64_t out_bytes;
+} oracle_params;
+
+/* tron.cu:905-961.  Fills the derived fields from the input .ra dims. Returns 0, or -1
+   when the reference's assert(nc % 2 == 0 || nc == 1) (:963) would fire. */
+int oracle_derive_dims(oracle_params *p, const uint64_t in_dims[5])
+{
+    p->out_dims[0] = 1;
+    if (p->adjoint) {
+        p->nc = in_dims[0];
+        p->nt = in_dims[1];
+        p->nro = in_dims[2];
+        p->npe1 = in_dims[3];
+        p->npe2 = in_dims[4];
+        p->nx = p->nro / 2;
+        p->ny = p->nro / 2;
+        p->nxos = p->nx * p->gridos;
+        p->nyos = p->ny * p->gridos;
+        if (p->npe1 <= p->nro * p->data_undersamp)
+            p->npe1work = p->npe1;
+        else
+            p->npe1work = p->nro * p->data_undersamp;
+        if (p->prof_slide == 0)
+            p->prof_slide = p->npe1work;
+        if (p->koosh) {
+            p->nz = p->nro / 2;
+            p->nzos = p->nz * p->gridos;
+        } else {
+            p->nz = 1 + (p->npe1 - p->npe1work) / p->prof_slide;
+            p->nzos = 1;
+        }
+        p->out_dims[1] = p->nt;
+        p->out_dims[2] = p->nx;
+        p->out_dims[3] = p->ny;
+        p->out_dims[4] = p->nz;
+        p->out_bytes = (uint64_t)1*p->nt*p->nx*p->ny*p->nz*sizeof(cfloat);
+    } else {
+        p->nc = in_dims[0];
+        p->nt = in_dims[1];
+        p->nx = in_dims[2];
+        p->ny = in_dims[3];
+        p->nz = in_dims[4];
+        p->nxos = p->nx*p->gridos;
+        p->nyos = p->ny*p->gridos;
+        p->nro = p->gridos*p->nx;
+        p->npe1work = p->data_undersamp * p->nro;
+        p->npe1 = p->npe1work;
+        if (p->koosh) {
+            p->npe2 = p->nz;
+            p->nzos = p->nz;
+        } else {
+            p->npe2 = 1;
+            p->nzos = 1;
+        }
+        p->out_dims[1] = p->nt;
+        p->out_dims[2] = p->nro;
+        p->out_dims[3] = p->npe1;
+        p->out_dims[4] = p->npe2;
+        p->out_bytes = (uint64_t)p->nc*p->nt*p->nro*p->npe1*p->npe2*sizeof(cfloat);
+    }
+    return (p->nc % 2 == 0 || p->nc == 1) ? 0 : -1;
+}
+
+static int imax(int a, int b) { return a > b ? a : b; }
+
+/* tron.cu:623-637.  d_in is modified in place (precompensate), d_out receives the
+   nx*ny*nchan deapodised coil images; both buffers hold nchan*max(nro*npe1work, nxos*nyos). */
+void oracle_nufft_adj_radial2d(const oracle_params *p, cfloat *d_out, cfloat *d_in, int peoffset)
+{
+    const int nchan = p->nc * p->nt;
+    oracle_precompensate(d_in, nchan, p->nro, p->npe1work);
+    oracle_gridradial2d(d_out, d_in, p->nxos, nchan, p->nro, p->npe1work, p->kernwidth,
+        p->gridos, p->skip_angles + peoffset, p->golden_angle);
+    oracle_fftshift(d_in, d_out, p->nxos, nchan, 1 /* FFT_SHIFT_INVERSE */);
+    oracle_fft2(d_out, d_in, p->nxos, nchan, +1 /* CUFFT_INVERSE */);
+    oracle_fftshift(d_in, d_out, p->nxos, nchan, 0 /* FFT_SHIFT_FORWARD */);
+    oracle_crop(d_out, p->nx, d_in, p->nxos, nchan);
+    oracle_deapod(d_out, p->nx, nchan, p->kernwidth, p->gridos);
+}
+
+/* tron.cu:639-649 */
+void oracle_nufft_radial2d(const oracle_params *p, cfloat *d_out, cfloat *d_in)
+{
+    const int nchan = p->nc * p->nt;
+    oracle_pad(d_out, p->nxos, d_in, p->nx, nchan);
+    oracle_deapod(d_out, p->nxos, nchan, p->kernwidth, 1.f);
+    oracle_fftshift(d_in, d_out, p->nxos, nchan, 0 /* FORWARD */);
+    oracle_fft2(d_out, d_in, p->nxos, nchan, -1 /* CUFFT_FORWARD */);
+    oracle_fftshift(d_in, d_out, p->nxos, nchan, 1 /* INVERSE */);
+    oracle_degridradial2d(d_out, d_in, p->nxos, nchan, p->nro, p->npe1work, p->kernwidth,
+        p->gridos, p->skip_angles, p->golden_angle);
+}
+
+/* tron.cu:726-786.  zfirst/zcount select a sub-range of the slice loop (the reference
+   always runs 0..nz-1); outputs land at the same offsets the full loop would use.
+   Returns 0, or -2 if a slice window would read past npe1 (the reference would read
+   out of bounds, e.g. with -3). */
+int oracle_recon_radial2d(const oracle_params *p, cfloat *h_out, const cfloat *h_in, int zfirst, int zcount)
+{
+    const int nc = p->nc, nt = p->nt, nro = p->nro, npe1work = p->npe1work;
+    const size_t nbuf = (size_t)nc*nt*imax(nro*npe1work, p->nxos*p->nyos);  /* tron.cu:591 */
+    cfloat *d_u = (cfloat*)malloc(nbuf*sizeof(cfloat));
+    cfloat *d_v = (cfloat*)malloc(nbuf*sizeof(cfloat));
+    int rc = 0;
+    for (int z = zfirst; z < zfirst + zcount && z < p->nz; ++z) {
+        int peoffset = z*p->prof_slide;
+        size_t data_offset = (size_t)nc*nt*nro*peoffset;
+        size_t img_offset = (size_t)nt*p->nx*p->ny*z;
+        if (p->adjoint) {
+            if ((long long)peoffset + npe1work > (long long)p->npe1 * (p->npe2 > 0 ? p->npe2 : 1)) { rc = -2; break; }
+            memcpy(d_u, h_in + data_offset, (size_t)nc*nt*nro*npe1work*sizeof(cfloat));
+            oracle_nufft_adj_radial2d(p, d_v, d_u, peoffset);
+            oracle_coilcombinesos(d_u, d_v, p->nx, nc);
+            memcpy(h_out + img_offset, d_u, (size_t)p->nx*p->ny*nt*sizeof(cfloat));
+        } else {
+            memcpy(d_u, h_in + data_offset, (size_t)nc*nt*p->nx*p->ny*sizeof(cfloat));
+            oracle_nufft_radial2d(p, d_v, d_u);
+            memcpy(h_out + (size_t)nc*nt*nro*npe1work*z, d_v, (size_t)nc*nt*nro*npe1work*sizeof(cfloat));
+        }
+    }
+    free(d_u);
+    free(d_v);
+    return rc;
+}
+
+size_t oracle_params_size(void) { return sizeof(oracle_params); }

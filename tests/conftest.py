@@ -1,0 +1,28 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def rel_l2(a, b):
+    import numpy as np
+    a = np.asarray(a).astype(np.complex128).ravel()
+    b = np.asarray(b).astype(np.complex128).ravel()
+    nb = np.linalg.norm(b)
+    return float(np.linalg.norm(a - b) / (nb if nb > 0 else 1.0))
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import pyoracle
+    pyoracle.lib()
+    return pyoracle

@@ -1,0 +1,178 @@
+"""CPU tests of the oracle itself (no GPU): scalar known-answers, the C restatement
+against an independent numpy scatter restatement, and mathematical properties.
+
+The reference ships no golden vectors for this path; what is checked
+here is (a) values recorded while surveying the reference's arithmetic,
+(b) agreement of two structurally different restatements, (c) the DFT / NUFFT maths.
+"""
+import numpy as np
+import pytest
+from scipy import special
+
+from conftest import rel_l2
+import ref_numpy
+import synth
+
+
+def test_besseli0_matches_scipy(oracle):
+    # tron.cu:304-321: rational approximation, ~1e-7 in float
+    xs = np.linspace(0, 9.36, 400, dtype=np.float32)
+    got = np.array([oracle.besseli0(x) for x in xs])
+    assert np.max(np.abs(got / special.i0(xs.astype(np.float64)) - 1)) < 5e-7
+    assert oracle.besseli0(0.0) == 1.0
+
+
+def test_kernel_constants(oracle):
+    # SURVEY Appendix A (values read off the reference's arithmetic)
+    assert abs(oracle.gridkernel(0.0) - 384.03) < 0.01
+    assert abs(oracle.gridkernel(1.999) - 0.2555) < 1e-3
+    assert oracle.gridkernel(2.0) == 0.0 and oracle.gridkernel(-2.0) == 0.0
+    assert oracle.gridkernel(np.nextafter(np.float32(2), np.float32(0))) > 0.24
+    # per-dimension deapodisation factors: 382.7..620.4 over u in [-1/4,1/4), 74.3..620.4 over [-1/2,1/2)
+    h = np.array([oracle.gridkernelhat(u) for u in np.linspace(-0.25, 0.25, 257)[:-1]])
+    assert abs(h.min() - 382.7) < 0.1 and abs(h.max() - 620.4) < 0.1
+    h = np.array([oracle.gridkernelhat(u, 2.0, 1.0) for u in np.linspace(-0.5, 0.5, 513)[:-1]])
+    assert abs(h.min() - 74.3) < 0.1 and abs(h.max() - 620.4) < 0.1
+    # the weight deapodkernel divides by is the product of two of them, with the
+    # fractional x coordinate of tron.cu:395
+    n = 256
+    for idx in (0, 255, 256 * 128 + 128, 256 * 255 + 7):
+        x = np.float32(np.float32(idx) / np.float32(n)) - np.float32((n + 1) // 2)
+        y = np.float32(idx % n) - np.float32((n + 1) // 2)
+        s = np.float32(np.float32(1.0) / np.float32(n)) / np.float32(2.0)
+        want = np.float32(oracle.gridkernelhat(x * s)) * np.float32(oracle.gridkernelhat(y * s))
+        assert oracle.deapod_weight(idx, n, 2.0, 2.0) == want
+
+
+def test_numpy_kernel_bitexact(oracle):
+    xs = np.concatenate([np.linspace(-2.5, 2.5, 2001), [0.0, 2.0, -2.0]]).astype(np.float32)
+    got = ref_numpy.gridkernel(xs)
+    want = np.array([oracle.gridkernel(x) for x in xs], np.float32)
+    assert np.array_equal(got, want)
+
+
+def test_angles(oracle):
+    for golden in (0, 1):
+        for pe in (0, 1, 7, 401, 20270):
+            assert oracle.grid_angle(pe, 402, 3, golden) == ref_numpy.grid_angle(pe, 402, 3, golden)
+            assert oracle.degrid_angle(pe, 402, 3, golden) == ref_numpy.degrid_angle(pe, 402, 3, golden)
+    # golden angle is 111.246 degrees
+    assert abs(np.degrees(float(ref_numpy.PHI)) - 111.246) < 1e-3
+    assert 0 <= oracle.modang(-1.0) < 2 * np.pi
+
+
+@pytest.mark.parametrize("golden", [1, 0])
+@pytest.mark.parametrize("nchan", [1, 2])
+def test_grid_c_vs_numpy_scatter(oracle, golden, nchan):
+    nxos, nro, npe = 32, 32, 24
+    nu = synth.uniform_c64(npe * nro * nchan, 7).reshape(npe, nro, nchan)
+    nu = ref_numpy.precompensate(nu)
+    assert np.array_equal(nu, oracle.precompensate(synth.uniform_c64(npe * nro * nchan, 7).reshape(npe, nro, nchan)))
+    want = oracle.gridradial2d(nu, nxos, golden=golden, skip_angles=5)
+    got = ref_numpy.grid_scatter(nu, nxos, skip=5, golden=golden)
+    assert rel_l2(got, want) < 5e-7          # identical terms, different summation order
+
+
+def test_grid_readout_resample(oracle):
+    # nro != nxos exercises ridx = (r*nro)/nxos
+    nxos, nro, npe = 24, 32, 10
+    nu = synth.uniform_c64(npe * nro, 9).reshape(npe, nro, 1)
+    want = oracle.gridradial2d(nu, nxos, golden=1)
+    got = ref_numpy.grid_scatter(nu, nxos, golden=1)
+    assert rel_l2(got, want) < 5e-7
+
+
+@pytest.mark.parametrize("golden", [1, 0])
+def test_degrid_c_vs_numpy(oracle, golden):
+    n, nro, npe, nrep = 32, 32, 20, 2
+    u = synth.uniform_c64(n * n * nrep, 11).reshape(n, n, nrep)
+    want = oracle.degridradial2d(u, nro, npe, golden=golden, skip_angles=2)
+    got = ref_numpy.degrid_gather(u, nro, npe, skip=2, golden=golden)
+    assert rel_l2(got, want) < 1e-7
+
+
+def test_fft2_is_unnormalised_dft(oracle):
+    for n in (16, 12):
+        a = synth.uniform_c64(n * n * 2, 13).reshape(n, n, 2)
+        for sign, ref in ((-1, np.fft.fft2), (+1, lambda x: np.fft.ifft2(x) * n * n)):
+            got = oracle.fft2(a, sign)
+            for c in range(2):
+                assert rel_l2(got[:, :, c], ref(a[:, :, c].astype(np.complex128))) < 2e-7
+
+
+def test_shift_crop_pad(oracle):
+    n = 8
+    a = synth.uniform_c64(n * n, 17).reshape(n, n, 1)
+    assert np.array_equal(oracle.fftshift(a, 0)[:, :, 0], np.fft.fftshift(a[:, :, 0]))
+    assert np.array_equal(oracle.fftshift(a, 1)[:, :, 0], np.fft.ifftshift(a[:, :, 0]))
+    m = 7  # odd sizes: forward shifts by n//2, inverse by n - n//2
+    b = synth.uniform_c64(m * m, 18).reshape(m, m, 1)
+    assert np.array_equal(oracle.fftshift(b, 0)[:, :, 0], np.roll(b[:, :, 0], (m // 2, m // 2), (0, 1)))
+    assert np.array_equal(oracle.fftshift(b, 1)[:, :, 0], np.roll(b[:, :, 0], (m - m // 2, m - m // 2), (0, 1)))
+    assert np.array_equal(oracle.crop(a, 4)[:, :, 0], a[2:6, 2:6, 0])
+    p = oracle.pad(oracle.crop(a, 4), 8)[:, :, 0]
+    want = np.zeros((8, 8), np.complex64)
+    want[3:6, 3:6] = a[3:6, 3:6, 0]      # row 0 / col 0 of the source are dropped
+    assert np.array_equal(p, want)
+
+
+def test_sos(oracle):
+    a = synth.uniform_c64(4 * 4 * 6, 19).reshape(4, 4, 6)
+    got = oracle.coilcombinesos(a)
+    assert np.allclose(got.real, np.sqrt((np.abs(a) ** 2).sum(-1)), rtol=1e-6)
+    assert np.all(got.imag == 0)
+    one = a[:, :, :1]
+    assert np.array_equal(oracle.coilcombinesos(one), one[:, :, 0])
+
+
+def test_dims_logic(oracle):
+    # whole-body invocation: tron -u 0.4 -d 21 -a -G on [6,1,512,20271,1] (RUNME3:10)
+    p = oracle.make_params((6, 1, 512, 20271, 1), adjoint=1, golden=1, data_undersamp=0.4, prof_slide=21)
+    assert (p.npe1work, p.nz, p.nx, p.nxos) == (204, 956, 256, 512)
+    assert tuple(p.out_dims) == (1, 1, 256, 256, 956)
+    # metric shape: -u 0.7852 -d 402
+    p = oracle.make_params((1, 1, 512, 402 * 3, 1), adjoint=1, golden=1, data_undersamp=0.7852, prof_slide=402)
+    assert (p.npe1work, p.nz) == (402, 3)
+    # forward: Shepp-Logan 256^2 -> 512 ro x 512 spokes (RUNME1:5)
+    p = oracle.make_params((1, 1, 256, 256, 1), adjoint=0)
+    assert (p.nro, p.npe1work, p.nxos) == (512, 512, 512)
+    assert tuple(p.out_dims) == (1, 1, 512, 512, 1)
+    with pytest.raises(ValueError):
+        oracle.make_params((3, 1, 64, 10, 1), adjoint=1)
+
+
+def _dtft_adjoint(samples, kx, ky, nx):
+    """sum_k s_k exp(+2 pi i (kx m1 + ky m2)/nxos-free form): exact adjoint on an nx^2 image."""
+    m = np.arange(nx) - nx // 2
+    ex = np.exp(2j * np.pi * np.outer(m, kx))   # (nx, K) rows <-> sin axis uses ky; see below
+    ey = np.exp(2j * np.pi * np.outer(m, ky))
+    return ey @ (samples[:, None] * ex.T)
+
+
+def test_adjoint_is_a_nufft(oracle):
+    """The whole adjoint pipeline approximates the exact (DCF-weighted) adjoint DTFT:
+    pins orientation (rows<->sin, cols<->cos), FFT sign, shift and crop conventions."""
+    nro, npe = 32, 40
+    data = synth.kspace(1, nro, npe, seed=23)
+    img, p = oracle.recon(data, adjoint=1, golden=1, data_undersamp=2.0)
+    img = img[0, 0, :, :, 0]        # (nx [cols, fastest], ny [rows]) in file order
+    img = img.T                      # -> [row, col]
+    nx, nxos = p.nx, p.nxos
+    # trajectory in cycles per OVERSAMPLED-grid sample
+    rr = np.arange(nro) - nro // 2
+    kxs, kys, vals = [], [], []
+    a = (2.0 - 2.0 / npe) / nro
+    b = 1.0 / npe
+    for pe in range(npe):
+        t = float(oracle.grid_angle(pe, npe, 0, 1))
+        for ro in range(1, nro):     # readout sample 0 is never used
+            r = rr[ro]
+            kxs.append(r * np.cos(t) / nxos)
+            kys.append(r * np.sin(t) / nxos)
+            vals.append(data[0, 0, ro, pe, 0] * (a * abs(r) + b))
+    vals = np.array(vals)
+    kxs, kys = np.array(kxs), np.array(kys)
+    exact = _dtft_adjoint(vals, kxs, kys, nx) / nxos / npe
+    # r = 0 is visited twice by the reference near the centre (Q2): allow for it loosely
+    err = rel_l2(img * nxos * nxos / (nxos * nxos), exact)
+    assert err < 0.05, err
