@@ -1,0 +1,182 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle on identical seeded inputs.
+
+Tolerances: north_star asks for fp32 relative L2 <= 1e-5 on the reconstruction.  The
+gridding kernel keeps the reference's summation order, so with TRON_KB_EXACT the interpolation
+stages are required to match the oracle to rounding of a single fused operation at most
+(asserted at 1e-7, typically bit-exact); full pipelines add rocFFT-vs-double-DFT rounding.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+from conftest import rel_l2
+import synth
+from tron_amd import lib
+
+pytestmark = pytest.mark.gpu
+
+TOL_PIPELINE = 1e-5      # north_star tolerance, relative L2
+TOL_STAGE_EXACT = 1e-7   # interpolation stages in exact mode
+TOL_STAGE_FAST = 2e-6    # polynomial Kaiser-Bessel
+
+
+def _plan(in_dims, adjoint, **flags):
+    cfg = lib.default_config(adjoint=int(adjoint), **flags)
+    dims = lib.derive_dims(cfg, in_dims)
+    return lib.Plan(cfg, dims)
+
+
+@pytest.mark.parametrize("golden,nchan,nxos,nro,npe,W,kb", [
+    (1, 1, 64, 64, 48, 2.0, lib.KB_EXACT),
+    (0, 1, 64, 64, 48, 2.0, lib.KB_EXACT),
+    (1, 2, 64, 64, 33, 2.0, lib.KB_EXACT),
+    (1, 6, 32, 32, 20, 2.0, lib.KB_EXACT),
+    (1, 8, 48, 48, 20, 2.0, lib.KB_EXACT),
+    (1, 1, 48, 64, 30, 2.0, lib.KB_EXACT),     # nro != nxos: readout resampling
+    (1, 1, 40, 40, 25, 1.5, lib.KB_EXACT),
+    (1, 2, 40, 40, 25, 2.5, lib.KB_EXACT),
+    (1, 1, 72, 72, 300, 2.0, lib.KB_EXACT),    # more than one 256-spoke clip chunk
+    (1, 1, 64, 64, 48, 2.0, lib.KB_FAST),
+    (0, 2, 64, 64, 48, 2.0, lib.KB_FAST),
+])
+def test_grid_stage_vs_oracle(oracle, golden, nchan, nxos, nro, npe, W, kb):
+    """tron_gridradial2d == gridradial2d kernel (src/tron.cu:465-536), reference layouts."""
+    nu = synth.uniform_c64(npe * nro * nchan, 101).reshape(npe, nro, nchan)
+    nu = oracle.precompensate(nu)
+    skip = 7
+    want = oracle.gridradial2d(nu, nxos, W=W, gridos=nxos / (nro / 2), skip_angles=skip, golden=golden)
+    # a plan whose derived dims are (nxos, nro, npe): adjoint, -o nxos/(nro/2), -u big
+    with _plan((nchan, 1, nro, npe, 1), 1, golden_angle=golden, gridos=nxos / (nro / 2), kernwidth=W,
+               data_undersamp=1e6, kb_mode=kb) as plan:
+        assert plan.dims.nxos == nxos and plan.dims.npe1work == npe
+        d_in = lib.DeviceBuffer.from_numpy(nu)
+        d_out = lib.DeviceBuffer(nxos * nxos * nchan * 8)
+        plan.grid_device(d_out.ptr, d_in.ptr, skip)
+        plan.sync()
+        got = d_out.to_numpy(np.complex64, nxos * nxos * nchan).reshape(nxos, nxos, nchan)
+    err = rel_l2(got, want)
+    if kb == lib.KB_EXACT:
+        assert err <= TOL_STAGE_EXACT, err
+        # same terms, same order, unfused arithmetic: expect identical bits
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"not bit-exact (rel {err:.3e})"
+    else:
+        assert err <= TOL_STAGE_FAST, err
+
+
+@pytest.mark.parametrize("golden,nrep,n,nro,npe,kb", [
+    (1, 1, 64, 64, 40, lib.KB_EXACT),
+    (0, 1, 64, 64, 40, lib.KB_EXACT),
+    (1, 2, 32, 32, 17, lib.KB_EXACT),
+    (1, 6, 32, 32, 17, lib.KB_EXACT),
+    (1, 1, 64, 64, 40, lib.KB_FAST),
+])
+def test_degrid_stage_vs_oracle(oracle, golden, nrep, n, nro, npe, kb):
+    """tron_degridradial2d == degridradial2d kernel (src/tron.cu:540-577)."""
+    u = synth.uniform_c64(n * n * nrep, 202).reshape(n, n, nrep)
+    nx = n // 2
+    want = oracle.degridradial2d(u, nro, npe, skip_angles=3, golden=golden)
+    with _plan((nrep, 1, nx, nx, 1), 0, golden_angle=golden, data_undersamp=npe / nro + 1e-6, skip_angles=3, kb_mode=kb) as plan:
+        assert (plan.dims.nxos, plan.dims.nro, plan.dims.npe1work) == (n, nro, npe)
+        d_in = lib.DeviceBuffer.from_numpy(u)
+        d_out = lib.DeviceBuffer(npe * nro * nrep * 8)
+        plan.degrid_device(d_out.ptr, d_in.ptr)
+        plan.sync()
+        got = d_out.to_numpy(np.complex64, npe * nro * nrep).reshape(npe, nro, nrep)
+    err = rel_l2(got, want)
+    if kb == lib.KB_EXACT:
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"not bit-exact (rel {err:.3e})"
+    else:
+        assert err <= TOL_STAGE_FAST, err
+
+
+ADJ_CASES = [
+    # nc, nro, npe1, flags
+    (1, 64, 50, dict(golden_angle=1, data_undersamp=2.0)),
+    (1, 64, 50, dict(golden_angle=0, data_undersamp=2.0)),
+    (2, 64, 120, dict(golden_angle=1, data_undersamp=0.5, prof_slide=11)),          # sliding window, 9 slices
+    (6, 32, 90, dict(golden_angle=1, data_undersamp=0.5, prof_slide=7, skip_angles=5)),
+    (8, 32, 40, dict(golden_angle=1, data_undersamp=1.0)),                           # > MAXCHAN of the reference
+    (1, 64, 40, dict(golden_angle=1, data_undersamp=2.0, gridos=1.5)),
+    (1, 48, 30, dict(golden_angle=1, data_undersamp=2.0, kernwidth=2.5)),
+    (2, 64, 64, dict(golden_angle=0, data_undersamp=0.25, prof_slide=16)),           # linear angle windows
+]
+
+
+@pytest.mark.parametrize("kb", [lib.KB_EXACT, lib.KB_FAST])
+@pytest.mark.parametrize("nc,nro,npe1,flags", ADJ_CASES)
+def test_adjoint_recon_vs_oracle(oracle, nc, nro, npe1, flags, kb):
+    """tron -a ... == recon_radial2d adjoint branch (src/tron.cu:726-786)."""
+    data = synth.kspace(nc, nro, npe1, seed=303)
+    want, p = oracle.recon(data, adjoint=1, **{("golden" if k == "golden_angle" else k): v for k, v in flags.items()})
+    got, dims = lib.recon(data, adjoint=True, kb_mode=kb, **flags)
+    assert got.shape == want.shape == tuple(p.out_dims)
+    assert (dims.nz, dims.npe1work) == (p.nz, p.npe1work)
+    err = rel_l2(got, want)
+    assert err <= TOL_PIPELINE, err
+
+
+@pytest.mark.parametrize("kb", [lib.KB_EXACT, lib.KB_FAST])
+@pytest.mark.parametrize("nc,nx,flags", [
+    (1, 32, dict()),                                     # linear angle, like RUNME1
+    (1, 32, dict(golden_angle=1)),
+    (2, 32, dict(golden_angle=1, data_undersamp=0.5)),
+    (6, 16, dict(golden_angle=1, skip_angles=4)),
+])
+def test_forward_recon_vs_oracle(oracle, nc, nx, flags, kb):
+    """tron (no -a) == recon_radial2d forward branch."""
+    img = synth.image(nc, nx, seed=404)
+    want, p = oracle.recon(img, adjoint=0, **{("golden" if k == "golden_angle" else k): v for k, v in flags.items()})
+    got, dims = lib.recon(img, adjoint=False, kb_mode=kb, **flags)
+    assert got.shape == want.shape
+    err = rel_l2(got, want)
+    assert err <= TOL_PIPELINE, err
+
+
+def test_sharded_ranges_assemble(oracle):
+    """Disjoint slice ranges computed by separate plans fill the same output."""
+    data = synth.kspace(2, 32, 100, seed=505)
+    flags = dict(golden_angle=1, data_undersamp=0.5, prof_slide=6)
+    full, dims = lib.recon(data, adjoint=True, **flags)
+    cfg = lib.default_config(adjoint=1, **flags)
+    d = lib.derive_dims(cfg, data.shape)
+    flat = np.asfortranarray(data).reshape(-1, order="F")
+    out = np.zeros(d.out_bytes // 8, np.complex64)
+    cuts = [0, d.nz // 3, d.nz // 3 + 1, d.nz]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        with lib.Plan(cfg, d) as plan:
+            plan.recon(flat, zfirst=a, zcount=b - a, out=out)
+    assert np.array_equal(out.reshape(full.shape, order="F"), full)   # deterministic kernels: identical bits
+
+
+def test_device_resident_adjoint_uncombined(oracle):
+    """combine=0 returns the deapodised coil images of tron_nufft_adj_radial2d (src/tron.cu:623-637)."""
+    nc, nro, npe = 2, 32, 24
+    data = synth.kspace(nc, nro, npe, seed=606)
+    p = oracle.make_params(data.shape, adjoint=1, golden=1, data_undersamp=2.0)
+    d_u = np.ascontiguousarray(np.asfortranarray(data).reshape(-1, order="F"))
+    nbuf = nc * max(nro * npe, p.nxos * p.nxos)
+    u = np.zeros(nbuf, np.complex64); u[:d_u.size] = d_u
+    v = np.zeros(nbuf, np.complex64)
+    oracle.lib().oracle_nufft_adj_radial2d(ctypes.byref(p), v.ctypes.data_as(ctypes.c_void_p), u.ctypes.data_as(ctypes.c_void_p), 0)
+    want = v[:p.nx * p.nx * nc]
+    with _plan(data.shape, 1, golden_angle=1, data_undersamp=2.0) as plan:
+        d_in = lib.DeviceBuffer.from_numpy(d_u)
+        d_out = lib.DeviceBuffer(p.nx * p.nx * nc * 8)
+        plan.adjoint_device(d_out.ptr, d_in.ptr, 0, 1, combine=0)
+        plan.sync()
+        got = d_out.to_numpy(np.complex64, p.nx * p.nx * nc)
+    assert rel_l2(got, want) <= TOL_PIPELINE
+
+
+def test_errors_are_reported_not_fatal():
+    cfg = lib.default_config(adjoint=1, niter=3)
+    d = lib.derive_dims(cfg, (1, 1, 32, 10, 1))
+    with pytest.raises(lib.TronError) as e:
+        lib.Plan(cfg, d)
+    assert e.value.code == lib.TRON_ERR_UNSUPPORTED
+    with pytest.raises(lib.TronError):
+        lib.derive_dims(lib.default_config(adjoint=1), (3, 1, 32, 10, 1))      # odd coil count (tron.cu:963)
+    cfg = lib.default_config(adjoint=1, device=99)
+    with pytest.raises(lib.TronError):
+        lib.Plan(cfg, lib.derive_dims(cfg, (1, 1, 32, 10, 1)))

@@ -1,0 +1,29 @@
+// Host-internal declarations of libtronhip (tables, error reporting).
+#pragma once
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include <vector>
+
+#include "../../include/tron_hip.h"
+
+namespace tron {
+
+// records a printf-style message as the calling thread's last error and returns `code`
+int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+
+float grid_spoke_angle(int pe, int npe, int skip, int golden);
+float degrid_spoke_angle(int pe, int npe, int skip, int golden);
+size_t trig_table_size(const tron_config &cfg, const tron_dims &d);
+void build_trig_table(const tron_config &cfg, const tron_dims &d, float *cos_sin, size_t n);
+void build_trig_table_window(int npe, int skip, int golden, float *cos_sin);
+void build_band_table(int nxos, float kernwidth, uint32_t *band);
+void build_deapod_table(int n, float kernwidth, float sigma, float *inv_weight);
+void build_tile_order(int nxos, int tile, std::vector<int> &order);
+float kb_beta(float kernwidth);
+int kb_taylor(float kernwidth, float *poly, int max_terms);
+void dcf_constants(int nro, int npe1work, float *a, float *b);
+float grid_scale(int nxos, int npe);
+
+}  // namespace tron

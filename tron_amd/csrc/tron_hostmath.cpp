@@ -1,0 +1,299 @@
+// Host-side arithmetic of libtronhip that has to agree with the reference BIT FOR BIT:
+// the dimension logic of main(), the spoke angles, the per-point radial band and the
+// deapodisation weights.  These are evaluated once per plan on the host -- with the same libm
+// (sincosf, fmodf, hypotf, sinhf) an IEEE host build of the reference would use -- and uploaded
+// as tables, so device transcendental rounding never enters the comparison.
+//
+// Build with -ffp-contract=off and without fast-math.
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/tron_hip.h"
+#include "tron_host.h"
+
+namespace tron {
+
+static const float kGoldenAngle = 1.9416089796736116f;   // PHI, src/tron.cu:90
+
+// src/tron.cu:372-378
+static float wrap_angle(float x)
+{
+    const float two_pi = 2.f * M_PI;
+    float y = fmodf(x, two_pi);
+    return y < 0.f ? y + two_pi : y;
+}
+
+// Angle of spoke `pe` for the gridding kernel: src/tron.cu:509.  `skip` is the kernel argument,
+// i.e. skip_angles + peoffset (src/tron.cu:629-630).
+float grid_spoke_angle(int pe, int npe, int skip, int golden)
+{
+    float t;
+    if (golden)
+        t = wrap_angle(kGoldenAngle * (float)(pe + skip));
+    else
+        t = pe * 2.0f * M_PI / (float)npe + M_PI * 0.5f;      // double expression, rounded once
+    return t;
+}
+
+// Angle of spoke `pe` for the degridding kernel: src/tron.cu:555.
+float degrid_spoke_angle(int pe, int npe, int skip, int golden)
+{
+    float t;
+    if (golden)
+        t = wrap_angle(kGoldenAngle * (pe + skip));
+    else
+        t = pe * M_PI / (float)npe;
+    return t;
+}
+
+// (cos, sin) table for the plan's direction.  Adjoint + golden angle: one entry per spoke of
+// the whole stream, because slice z uses angle indices pe + skip_angles + z*prof_slide
+// (src/tron.cu:629-630, 738); otherwise one entry per spoke of a window.
+size_t trig_table_size(const tron_config &cfg, const tron_dims &d)
+{
+    if (cfg.adjoint && cfg.golden_angle)
+        return (size_t)(d.nz - 1) * d.prof_slide + d.npe1work;
+    return (size_t)d.npe1work;
+}
+
+void build_trig_table(const tron_config &cfg, const tron_dims &d, float *cos_sin, size_t n)
+{
+    for (size_t i = 0; i < n; ++i) {
+        float t = cfg.adjoint ? grid_spoke_angle((int)i, d.npe1work, cfg.skip_angles, cfg.golden_angle)
+                              : degrid_spoke_angle((int)i, d.npe1work, cfg.skip_angles, cfg.golden_angle);
+        float s, c;
+        sincosf(t, &s, &c);                                   // src/tron.cu:511, 559
+        cos_sin[2 * i] = c;
+        cos_sin[2 * i + 1] = s;
+    }
+}
+
+void build_trig_table_window(int npe, int skip, int golden, float *cos_sin)
+{
+    for (int i = 0; i < npe; ++i) {
+        float s, c;
+        sincosf(grid_spoke_angle(i, npe, skip, golden), &s, &c);
+        cos_sin[2 * i] = c;
+        cos_sin[2 * i + 1] = s;
+    }
+}
+
+// Radial band of every Cartesian point, src/tron.cu:498-502: a sample of signed radius r on any
+// spoke can contribute to the point only if Rlo <= |r| <= Rhi.
+void build_band_table(int nxos, float kernwidth, uint32_t *band)
+{
+    const int h = nxos / 2;
+    for (int yy = 0; yy < nxos; ++yy)
+        for (int xx = 0; xx < nxos; ++xx) {
+            int X = xx - h, Y = yy - h;
+            float R = hypotf((float)X, (float)Y);
+            int Rhi = fminf(floorf(R + kernwidth), nxos / 2 - 1);
+            int Rlo = fmaxf(ceilf(R - kernwidth), 0);
+            if (Rhi < 0) { Rhi = 0; Rlo = 1; }                // nxos < 2: empty band
+            band[(size_t)yy * nxos + xx] = (uint32_t)Rlo | ((uint32_t)Rhi << 16);
+        }
+}
+
+// src/tron.cu:323-335 (BEATTY_BETA is not defined by the reference Makefile)
+float kb_beta(float kernwidth)
+{
+    return 2.34f * 2.0f * kernwidth;
+}
+
+// Fourier transform of the Kaiser-Bessel window, src/tron.cu:351-370
+static float kb_hat(float u, float kernwidth)
+{
+    float J = 2.0f * kernwidth;
+    float beta = kb_beta(kernwidth);
+    float r = M_PI * J * u;
+    float q = r * r - beta * beta;
+    float y, z;
+    if (q > 0) {
+        z = sqrtf(q);
+        y = sinf(z) / z;
+    } else if (q < 0) {
+        z = sqrtf(-q);
+        y = sinhf(z) / z;
+    } else
+        y = 1;
+    return y;
+}
+
+// 1/w for every pixel, w as deapodkernel computes it (src/tron.cu:393-400, with the fractional
+// x coordinate of :395); the kernel's "/= w" is a multiplication by 1.0f/w (float2math.h:23).
+void build_deapod_table(int n, float kernwidth, float sigma, float *inv_weight)
+{
+    for (size_t id = 0; id < (size_t)n * n; ++id) {
+        float x = id / float(n) - (n + 1) / 2;
+        float y = float(id % n) - (n + 1) / 2;
+        float scale = 1.f / n / sigma;
+        float wgt = kb_hat(x * scale, kernwidth) * kb_hat(y * scale, kernwidth);
+        inv_weight[id] = 1.0f / (wgt > 0.f ? wgt : 1.f);
+    }
+}
+
+// Density compensation constants, src/tron.cu:408-409
+void dcf_constants(int nro, int npe1work, float *a, float *b)
+{
+    *a = (2.f - 2.f / float(npe1work)) / float(nro);
+    *b = 1.f / float(npe1work);
+}
+
+// Output scale of the gridding kernel, src/tron.cu:532
+float grid_scale(int nxos, int npe)
+{
+    return 1.f / nxos / npe;
+}
+
+// Taylor coefficients of (0.5/W) * I0(beta*sqrt(s)) in s, highest power first.  Returns the
+// number of terms, or 0 if more than `max_terms` would be needed for ~1e-9 accuracy.
+int kb_taylor(float kernwidth, float *poly, int max_terms)
+{
+    const double beta = kb_beta(kernwidth);
+    const double q = beta * beta / 4.0;
+    std::vector<double> a;
+    double term = 1.0;
+    for (int k = 0; k < 200; ++k) {
+        a.push_back(term);
+        term *= q / ((double)(k + 1) * (double)(k + 1));
+        if (k + 1 > q && term < 1e-9) break;                  // past the largest term and negligible vs I0(0) = 1
+    }
+    if ((int)a.size() > max_terms) return 0;
+    const int nt = (int)a.size();
+    for (int k = 0; k < nt; ++k) poly[k] = (float)(a[nt - 1 - k] * 0.5 / (double)kernwidth);
+    return nt;
+}
+
+// Tiles sorted by distance from the k-space centre: radial sampling density falls as 1/r, so
+// the central tiles are the expensive ones and are dispatched first.
+void build_tile_order(int nxos, int tile, std::vector<int> &order)
+{
+    const int tpr = (nxos + tile - 1) / tile;
+    struct T { float d; int id; };
+    std::vector<T> t;
+    for (int ty = 0; ty < tpr; ++ty)
+        for (int tx = 0; tx < tpr; ++tx) {
+            float cx = tx * tile + tile * 0.5f - nxos / 2, cy = ty * tile + tile * 0.5f - nxos / 2;
+            t.push_back({cx * cx + cy * cy, ty * tpr + tx});
+        }
+    for (size_t i = 1; i < t.size(); ++i) {                  // insertion sort keeps ties in raster order
+        T v = t[i];
+        size_t j = i;
+        while (j > 0 && t[j - 1].d > v.d) { t[j] = t[j - 1]; --j; }
+        t[j] = v;
+    }
+    order.resize(t.size());
+    for (size_t i = 0; i < t.size(); ++i) order[i] = t[i].id;
+}
+
+}  // namespace tron
+
+using namespace tron;
+
+extern "C" void tron_config_default(tron_config *cfg)
+{
+    memset(cfg, 0, sizeof(*cfg));
+    cfg->gridos = 2.f;            // src/tron.cu:67
+    cfg->kernwidth = 2.f;         // src/tron.cu:68
+    cfg->data_undersamp = 1.f;    // src/tron.cu:69
+    cfg->blocks = 4096;           // src/tron.cu:59
+    cfg->threads = 128;           // src/tron.cu:58
+    cfg->kb_mode = TRON_KB_EXACT;
+}
+
+// main()'s dimension logic.  Adjoint: src/tron.cu:905-935; forward: :936-961; the int <- float
+// conversions truncate exactly where the reference's implicit conversions do.
+extern "C" int tron_derive_dims(const tron_config *cfg, const uint64_t in_dims[5], tron_dims *d)
+{
+    if (!cfg || !in_dims || !d) return tron::fail(TRON_ERR_INVALID, "tron_derive_dims: null argument");
+    memset(d, 0, sizeof(*d));
+    for (int i = 0; i < 5; ++i)
+        if (in_dims[i] == 0 || in_dims[i] > 0x7fffffffull)
+            return tron::fail(TRON_ERR_INVALID, "tron_derive_dims: input dimension %d = %llu out of range", i, (unsigned long long)in_dims[i]);
+    int prof_slide = cfg->prof_slide;
+    d->nc = (int)in_dims[0];
+    d->nt = (int)in_dims[1];
+    d->out_dims[0] = 1;                                               // src/tron.cu:899
+    if (cfg->adjoint) {
+        d->nro = (int)in_dims[2];
+        d->npe1 = (int)in_dims[3];
+        d->npe2 = (int)in_dims[4];
+        d->nx = d->nro / 2;
+        d->ny = d->nro / 2;
+        d->nxos = d->nx * cfg->gridos;
+        d->nyos = d->ny * cfg->gridos;
+        if (d->npe1 <= d->nro * cfg->data_undersamp)                 // src/tron.cu:916
+            d->npe1work = d->npe1;
+        else
+            d->npe1work = d->nro * cfg->data_undersamp;
+        if (prof_slide == 0) prof_slide = d->npe1work;                // src/tron.cu:920
+        if (d->npe1work <= 0 || prof_slide <= 0)
+            return tron::fail(TRON_ERR_INVALID, "tron_derive_dims: no spokes per image (npe1work=%d, prof_slide=%d)", d->npe1work, prof_slide);
+        if (cfg->koosh) {
+            d->nz = d->nro / 2;
+            d->nzos = d->nz * cfg->gridos;
+        } else {
+            d->nz = 1 + (d->npe1 - d->npe1work) / prof_slide;         // src/tron.cu:926
+            d->nzos = 1;
+        }
+        d->out_dims[1] = d->nt;
+        d->out_dims[2] = d->nx;
+        d->out_dims[3] = d->ny;
+        d->out_dims[4] = d->nz;
+        d->out_bytes = (uint64_t)1 * d->nt * d->nx * d->ny * d->nz * sizeof(tron_float2);
+    } else {
+        d->nx = (int)in_dims[2];
+        d->ny = (int)in_dims[3];
+        d->nz = (int)in_dims[4];
+        d->nxos = d->nx * cfg->gridos;
+        d->nyos = d->ny * cfg->gridos;
+        d->nro = cfg->gridos * d->nx;                                 // src/tron.cu:945
+        d->npe1work = cfg->data_undersamp * d->nro;
+        d->npe1 = d->npe1work;
+        if (cfg->koosh) {
+            d->npe2 = d->nz;
+            d->nzos = d->nz;
+        } else {
+            d->npe2 = 1;
+            d->nzos = 1;
+        }
+        d->out_dims[1] = d->nt;
+        d->out_dims[2] = d->nro;
+        d->out_dims[3] = d->npe1;
+        d->out_dims[4] = d->npe2;
+        d->out_bytes = (uint64_t)d->nc * d->nt * d->nro * d->npe1 * d->npe2 * sizeof(tron_float2);
+    }
+    d->prof_slide = prof_slide;
+    d->in_elems = in_dims[0] * in_dims[1] * in_dims[2] * in_dims[3] * in_dims[4];
+    if (!(d->nc % 2 == 0 || d->nc == 1))                              // assert at src/tron.cu:963
+        return tron::fail(TRON_ERR_INVALID, "only one or an even number of coils is supported (nc=%d), as in the reference", d->nc);
+    if (d->nx <= 0 || d->nxos <= 0 || d->nro <= 0 || d->npe1work <= 0 || d->nz <= 0)
+        return tron::fail(TRON_ERR_INVALID, "degenerate dimensions (nx=%d nxos=%d nro=%d npe=%d nz=%d)", d->nx, d->nxos, d->nro, d->npe1work, d->nz);
+    return TRON_OK;
+}
+
+extern "C" int tron_host_trig_table(const tron_config *cfg, const tron_dims *dims, float *cos_sin, size_t n)
+{
+    if (!cfg || !dims || !cos_sin) return tron::fail(TRON_ERR_INVALID, "tron_host_trig_table: null argument");
+    if (n > trig_table_size(*cfg, *dims)) return tron::fail(TRON_ERR_INVALID, "tron_host_trig_table: table has only %zu entries", trig_table_size(*cfg, *dims));
+    build_trig_table(*cfg, *dims, cos_sin, n);
+    return TRON_OK;
+}
+
+extern "C" int tron_host_band_table(int nxos, float kernwidth, uint32_t *band)
+{
+    if (nxos < 2 || nxos > 16384 || !band) return tron::fail(TRON_ERR_INVALID, "tron_host_band_table: bad argument");
+    build_band_table(nxos, kernwidth, band);
+    return TRON_OK;
+}
+
+extern "C" int tron_host_deapod_table(int n, float kernwidth, float sigma, float *inv_weight)
+{
+    if (n < 1 || !inv_weight) return tron::fail(TRON_ERR_INVALID, "tron_host_deapod_table: bad argument");
+    build_deapod_table(n, kernwidth, sigma, inv_weight);
+    return TRON_OK;
+}

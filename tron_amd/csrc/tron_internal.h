@@ -1,0 +1,70 @@
+// Internal declarations shared by the HIP kernels and the host side of libtronhip.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace tron {
+
+constexpr int kTile = 16;          // Cartesian tile edge owned by one workgroup (gridding)
+constexpr int kGridThreads = 256;  // one thread per tile point, 4 waves of 16x4 points
+constexpr int kBatchSpokes = 16;   // spokes staged in LDS per batch
+constexpr int kKbPolyMax = 26;     // Taylor terms the fast Kaiser-Bessel may use
+
+// Parameters of one gridding launch (adjoint interpolation), see tron_kernels.hip.
+struct GridParams {
+    const void *nudata;      // k-space, float2 (or half2) [c + nchan*(ro + nro*spoke)]
+    float2 *udata;           // Cartesian output
+    const float2 *trig;      // (cos, sin) per spoke of the stream / window
+    const uint32_t *band;    // Rlo | Rhi<<16 per grid point, centred raster order
+    const int *tile_order;   // tile ids, most expensive first
+    unsigned int *errflag;   // device word, set non-zero on internal overflow
+    long long in_slice_stride;  // complex elements between the windows of consecutive slices
+    int trig_slice_stride;      // table entries between consecutive slices (0: same angles every slice)
+    int nxos, nro, npe, nchan;
+    int tiles_per_row, ntiles, nslices;
+    int coil0;               // first coil handled by blockIdx.y == 0 is coil0 (chunks of CPB follow)
+    float W, beta, scale, dcf_a, dcf_b;
+    int apply_dcf;
+    long long out_z, out_c;  // output strides (complex elements) per slice and per coil
+    int out_p;               // output stride per pixel
+    int out_shift;           // 1: rows/cols stored in FFT-native order ((Y+n)%n), 0: centred (Y+n/2)
+    int kb_terms;            // fast mode: number of Taylor coefficients in kb_poly
+    float kb_poly[kKbPolyMax];  // highest power first, includes the 0.5/W factor
+};
+
+struct PostParams {           // crop + deapodise + (optional) root-sum-of-squares, adjoint tail
+    const float2 *fft;        // [slice][coil][nxos][nxos], FFT-native order
+    float2 *out;              // combine: [slice][nx*nx]; else [slice][nchan*id + c]
+    const float *inv_deapod;  // nx*nx
+    int nx, nxos, nchan, nslices, combine;
+};
+
+struct PreParams {            // pad + deapodise + shift, forward head
+    const float2 *img;        // [image][nchan*(row*nx+col) + c]
+    float2 *fft;              // [image][coil][nxos][nxos] FFT-native order
+    const float *inv_deapod;  // nxos*nxos
+    int nx, nxos, nchan, nimg;
+};
+
+struct DegridParams {
+    const float2 *udata;      // Cartesian input
+    float2 *nudata;           // [image][nrep*(ro + nro*pe) + c]
+    const float2 *trig;       // (cos, sin) per spoke
+    long long in_z, in_c;     // input strides per image and per coil
+    int in_p, in_shift;       // pixel stride; 1: input is the raw FFT output (second fftshift folded into indexing)
+    int n, nrep, nro, npe, nimg;
+    float W, beta;
+    int kb_terms;
+    float kb_poly[kKbPolyMax];
+};
+
+// launchers (tron_kernels.hip); kb_mode: TRON_KB_EXACT / TRON_KB_FAST; half_in: nudata is half2
+hipError_t launch_grid(const GridParams &p, int kb_mode, int half_in, hipStream_t s);
+hipError_t launch_post(const PostParams &p, hipStream_t s);
+hipError_t launch_pre(const PreParams &p, hipStream_t s);
+hipError_t launch_degrid(const DegridParams &p, int kb_mode, hipStream_t s);
+size_t grid_lds_bytes(int cpb, int cw);
+
+}  // namespace tron

@@ -1,0 +1,155 @@
+// `tron` -- command-line driver with the reference's interface (davidssmith/TRON,
+// src/tron.cu:790-995): same getopt string, same defaults, same dimension logic, same input /
+// output .ra conventions and exit codes, on top of the C ABI of include/tron_hip.h.
+//
+//   tron [-3aGhv] [-B blocks] [-d prof_slide] [-g gpu] [-i niter] [-k width] [-o gridos]
+//        [-r nro] [-s skip_angles] [-T threads] [-u data_undersamp] <infile.ra> [outfile.ra]
+//
+// Extensions, via the environment so the flag set stays the reference's:
+//   TRON_KB_MODE=exact|fast    Kaiser-Bessel evaluation (default exact)
+//   TRON_CHUNK_SLICES=n        slices per device batch
+// A complex-half input (eltype 4, elbyte 4) is accepted for -a and gridded from half storage.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include <unistd.h>
+
+#include "../../include/rawarray.h"
+#include "../../include/tron_hip.h"
+
+static void usage()
+{
+    fputs("Trajectory-optimized Non-uniform Fast Fourier Transform (MI355X / HIP build)\n"
+          "Usage: tron [-3aGhv] [-B blocks] [-d prof_slide] [-g gpu] [-i niter] [-k width] [-o gridos]\n"
+          "            [-r nro] [-s skip_angles] [-T threads] [-u data_undersamp] <infile.ra> [outfile.ra]\n"
+          "  -3                 3D koosh ball trajectory (dimension bookkeeping only)\n"
+          "  -a                 adjoint operation (gridding); default is forward (degridding)\n"
+          "  -B blocks          accepted for compatibility, ignored\n"
+          "  -d prof_slide      phase encodes to slide between slices (helical / sliding window)\n"
+          "  -g n               GPU device to use (default: 0)\n"
+          "  -G                 golden angle radial\n"
+          "  -h                 show this help\n"
+          "  -i niter           CGNR iterations (not supported; must be 0)\n"
+          "  -k width           half-width of the gridding kernel (default 2)\n"
+          "  -o gridos          grid oversampling factor (default 2)\n"
+          "  -r nro             number of readout points (taken from the input file)\n"
+          "  -s skip_angles     angle index of the first phase encode\n"
+          "  -T threads         accepted for compatibility, ignored\n"
+          "  -u data_undersamp  input data undersampling factor (default 1)\n"
+          "  -v                 verbose output\n",
+          stderr);
+}
+
+int main(int argc, char *argv[])
+{
+    tron_config cfg;
+    tron_config_default(&cfg);
+    int c;
+    opterr = 0;
+    while ((c = getopt(argc, argv, "3aB:d:g:Ghi:k:o:r:s:T:u:v")) != -1) {   // src/tron.cu:822
+        switch (c) {
+            case '3': cfg.koosh = 1; break;
+            case 'a': cfg.adjoint = 1; break;
+            case 'B': cfg.blocks = atoi(optarg); break;
+            case 'd': cfg.prof_slide = atoi(optarg); break;
+            case 'g': cfg.device = atoi(optarg); break;
+            case 'G': cfg.golden_angle = 1; break;
+            case 'h': usage(); return 1;                                       // src/tron.cu:843-845
+            case 'i': cfg.niter = atoi(optarg); break;
+            case 'k': cfg.kernwidth = atof(optarg); break;
+            case 'o': cfg.gridos = atof(optarg); break;
+            case 'u': cfg.data_undersamp = atof(optarg); break;
+            case 'r': break;                                                   // parsed, then overwritten (src/tron.cu:859,909)
+            case 's': cfg.skip_angles = atoi(optarg); break;
+            case 'T': cfg.threads = atoi(optarg); break;
+            case 'v': cfg.verbose = 1; break;
+            default: usage(); return 1;
+        }
+    }
+    if (argc == optind) {                                                      // src/tron.cu:878-881
+        usage();
+        return 1;
+    }
+    const char *infile = argv[optind];
+    const char *outfile = optind + 1 < argc ? argv[optind + 1] : "img_tron.ra";   // src/tron.cu:877
+    if (const char *kb = getenv("TRON_KB_MODE")) cfg.kb_mode = strcmp(kb, "fast") == 0 ? TRON_KB_FAST : TRON_KB_EXACT;
+
+#define VPRINT(...) do { if (cfg.verbose) printf(__VA_ARGS__); } while (0)
+
+    VPRINT("Reading %s\n", infile);
+    ra_t in;
+    if (ra_read(&in, infile) != 0) return 1;
+    if (in.ndims != 5) {                                                       // assert at src/tron.cu:892
+        fprintf(stderr, "tron: %s has %llu dimensions, expected 5 ([nc,nt,nro,npe1,npe2] or [nc,nt,nx,ny,nz])\n", infile, (unsigned long long)in.ndims);
+        ra_free(&in);
+        return 1;
+    }
+    if (in.eltype == RA_TYPE_COMPLEX && in.elbyte == 4 && cfg.adjoint)
+        cfg.input_half = 1;
+    else if (!(in.eltype == RA_TYPE_COMPLEX && in.elbyte == 8)) {
+        fprintf(stderr, "tron: %s must hold complex64 data (eltype 4, elbyte 8), found eltype %llu elbyte %llu\n", infile,
+                (unsigned long long)in.eltype, (unsigned long long)in.elbyte);
+        ra_free(&in);
+        return 1;
+    }
+    if (!cfg.input_half) {
+        const float *f = reinterpret_cast<const float *>(in.data);
+        VPRINT("Sanity check: indata[0] = %f + %f i\n", f[0], f[1]);
+    }
+    VPRINT("indims = {%llu, %llu, %llu, %llu, %llu}\n", (unsigned long long)in.dims[0], (unsigned long long)in.dims[1],
+           (unsigned long long)in.dims[2], (unsigned long long)in.dims[3], (unsigned long long)in.dims[4]);
+    VPRINT("WARNING: Assuming square Cartesian dimensions for now.\n");
+
+    tron_dims dims;
+    if (tron_derive_dims(&cfg, in.dims, &dims) != TRON_OK) {
+        fprintf(stderr, "tron: %s\n", tron_last_error());
+        ra_free(&in);
+        return 1;
+    }
+    if (in.size < dims.in_elems * (cfg.input_half ? 4 : 8)) {
+        fprintf(stderr, "tron: %s holds %llu bytes, its dimensions need %llu\n", infile, (unsigned long long)in.size,
+                (unsigned long long)(dims.in_elems * (cfg.input_half ? 4 : 8)));
+        ra_free(&in);
+        return 1;
+    }
+
+    ra_t out;
+    memset(&out, 0, sizeof(out));
+    out.flags = 0;                                                             // src/tron.cu:897-902
+    out.eltype = RA_TYPE_COMPLEX;
+    out.elbyte = 8;
+    out.ndims = 5;
+    out.size = dims.out_bytes;
+    out.dims = static_cast<uint64_t *>(malloc(5 * sizeof(uint64_t)));
+    out.data = static_cast<uint8_t *>(calloc(dims.out_bytes ? dims.out_bytes : 1, 1));
+    if (!out.dims || !out.data) {
+        fprintf(stderr, "tron: cannot allocate %llu bytes for the output\n", (unsigned long long)dims.out_bytes);
+        return 1;
+    }
+    memcpy(out.dims, dims.out_dims, 5 * sizeof(uint64_t));
+
+    VPRINT("Running reconstruction ...\n ");
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    tron_plan *plan = nullptr;
+    int rc = tron_plan_create(&plan, &cfg, &dims);
+    if (rc == TRON_OK) rc = tron_recon_radial2d(plan, reinterpret_cast<tron_float2 *>(out.data), reinterpret_cast<const tron_float2 *>(in.data));
+    if (rc != TRON_OK) {
+        fprintf(stderr, "tron: %s\n", tron_last_error());
+        tron_plan_destroy(plan);
+        ra_free(&in);
+        ra_free(&out);
+        return rc == TRON_ERR_UNSUPPORTED ? 2 : 1;
+    }
+    tron_plan_destroy(plan);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    VPRINT("Elapsed time: %.2f s\n", (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec));
+
+    VPRINT("Saving result to %s\n", outfile);
+    rc = ra_write(&out, outfile);
+    VPRINT("Cleaning up.\n");
+    ra_free(&in);
+    ra_free(&out);
+    return rc == 0 ? 0 : 1;
+}

@@ -1,0 +1,651 @@
+// Host orchestration of libtronhip: plan life cycle, the batched adjoint / forward pipelines and
+// the C ABI of include/tron_hip.h.  Replaces src/tron.cu:579-649 and :726-786 of the reference
+// (tron_init / tron_shutdown / tron_nufft_adj_radial2d / tron_nufft_radial2d / recon_radial2d).
+//
+// Differences of structure (not of results) from the reference:
+//   * all slices of a run are batched: one gridding launch, one batched rocFFT and one fused tail
+//     kernel per chunk of slices, instead of 8 kernels + 2 copies per slice on alternating streams;
+//   * the spoke stream is uploaded ONCE and sliding windows (src/tron.cu:738-739) are views into
+//     it; the reference re-uploads every window (each spoke ~10x for the whole-body run);
+//   * the Cartesian data is coil-planar and stored in FFT-native order, so both fftshift passes,
+//     crop and the density pre-compensation pass disappear into index arithmetic.
+#include <hip/hip_runtime.h>
+#include <rocfft/rocfft.h>
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/tron_hip.h"
+#include "tron_host.h"
+#include "tron_internal.h"
+
+namespace tron {
+
+static thread_local std::string g_last_error;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                           \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail(TRON_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+#define FFT_TRY(expr)                                                                           \
+    do {                                                                                        \
+        rocfft_status s_ = (expr);                                                              \
+        if (s_ != rocfft_status_success)                                                        \
+            return fail(TRON_ERR_FFT, "%s failed: rocfft_status %d (%s:%d)", #expr, (int)s_, __FILE__, __LINE__); \
+    } while (0)
+
+enum { STAGE_GRID = 0, STAGE_FFT = 1, STAGE_POST = 2, STAGE_PRE = 3, STAGE_DEGRID = 4, STAGE_COUNT = 5 };
+
+struct FftPlan {
+    rocfft_plan plan = nullptr;
+    rocfft_execution_info info = nullptr;
+    void *work = nullptr;
+    size_t work_bytes = 0;
+};
+
+}  // namespace tron
+
+using namespace tron;
+
+struct tron_plan {
+    tron_config cfg;
+    tron_dims d;
+    int nchan = 0;
+    int kb_mode = TRON_KB_EXACT;
+    int chunk = 1;                 // slices (adjoint) or images (forward) per batch
+    hipStream_t stream = nullptr;
+    // device tables
+    float2 *d_trig = nullptr;
+    size_t ntrig = 0;
+    uint32_t *d_band = nullptr;
+    int *d_tile_order = nullptr;
+    float *d_deapod = nullptr;
+    unsigned int *d_errflag = nullptr;
+    int ntiles = 0, tiles_per_row = 0;
+    // kernel constants
+    float beta = 0, dcf_a = 0, dcf_b = 0, scale = 0;
+    int kb_terms = 0;
+    float kb_poly[kKbPolyMax];
+    // work buffers
+    float2 *d_grid = nullptr;      // chunk * nchan * nxos^2
+    void *d_stage_in = nullptr;    // host-API staging
+    size_t stage_in_bytes = 0;
+    void *d_stage_out = nullptr;
+    size_t stage_out_bytes = 0;
+    float2 *d_trig_tmp = nullptr;  // stage-level gridding calls
+    std::map<std::pair<int, int>, FftPlan> fft;   // (batch, direction) -> plan
+    // timing
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[STAGE_COUNT];
+    double ms_acc[STAGE_COUNT] = {0, 0, 0, 0, 0};
+    uint64_t launches[STAGE_COUNT] = {0, 0, 0, 0, 0};
+};
+
+namespace {
+
+std::once_flag g_fft_once;
+
+struct StageTimer {
+    tron_plan *p;
+    int stage;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    StageTimer(tron_plan *plan, int st) : p(plan), stage(st)
+    {
+        if (p->timing) {
+            hipEventCreate(&e0);
+            hipEventCreate(&e1);
+            hipEventRecord(e0, p->stream);
+        }
+    }
+    ~StageTimer()
+    {
+        if (p->timing) {
+            hipEventRecord(e1, p->stream);
+            p->ev[stage].push_back({e0, e1});
+        }
+    }
+};
+
+int drain_timers(tron_plan *p)
+{
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    for (int s = 0; s < STAGE_COUNT; ++s) {
+        for (auto &pr : p->ev[s]) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
+            p->ms_acc[s] += ms;
+            p->launches[s] += 1;
+            hipEventDestroy(pr.first);
+            hipEventDestroy(pr.second);
+        }
+        p->ev[s].clear();
+    }
+    return TRON_OK;
+}
+
+int get_fft(tron_plan *p, int batch, int inverse, FftPlan **out)
+{
+    auto key = std::make_pair(batch, inverse);
+    auto it = p->fft.find(key);
+    if (it == p->fft.end()) {
+        FftPlan f;
+        const size_t lengths[2] = {(size_t)p->d.nxos, (size_t)p->d.nxos};
+        // cufftPlan2d / cufftPlanMany of src/tron.cu:205-220: unnormalised C2C; CUFFT_INVERSE (+i)
+        // for the adjoint (:632), CUFFT_FORWARD (-i) for the forward transform (:645)
+        FFT_TRY(rocfft_plan_create(&f.plan, rocfft_placement_inplace,
+                                   inverse ? rocfft_transform_type_complex_inverse : rocfft_transform_type_complex_forward,
+                                   rocfft_precision_single, 2, lengths, (size_t)batch, nullptr));
+        FFT_TRY(rocfft_execution_info_create(&f.info));
+        FFT_TRY(rocfft_execution_info_set_stream(f.info, p->stream));
+        FFT_TRY(rocfft_plan_get_work_buffer_size(f.plan, &f.work_bytes));
+        if (f.work_bytes) {
+            HIP_TRY(hipMalloc(&f.work, f.work_bytes));
+            FFT_TRY(rocfft_execution_info_set_work_buffer(f.info, f.work, f.work_bytes));
+        }
+        it = p->fft.emplace(key, f).first;
+    }
+    *out = &it->second;
+    return TRON_OK;
+}
+
+int run_fft(tron_plan *p, float2 *buf, int batch, int inverse)
+{
+    FftPlan *f = nullptr;
+    int rc = get_fft(p, batch, inverse, &f);
+    if (rc) return rc;
+    StageTimer t(p, STAGE_FFT);
+    void *bufs[1] = {buf};
+    FFT_TRY(rocfft_execute(f->plan, bufs, nullptr, f->info));
+    return TRON_OK;
+}
+
+template <typename T>
+int upload(T **dptr, const void *host, size_t bytes)
+{
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(dptr), bytes ? bytes : 1));
+    if (bytes) HIP_TRY(hipMemcpy(*dptr, host, bytes, hipMemcpyHostToDevice));
+    return TRON_OK;
+}
+
+void fill_grid_consts(const tron_plan *p, GridParams &g)
+{
+    g.band = p->d_band;
+    g.tile_order = p->d_tile_order;
+    g.errflag = p->d_errflag;
+    g.nxos = p->d.nxos;
+    g.nro = p->d.nro;
+    g.npe = p->d.npe1work;
+    g.nchan = p->nchan;
+    g.tiles_per_row = p->tiles_per_row;
+    g.ntiles = p->ntiles;
+    g.coil0 = 0;
+    g.W = p->cfg.kernwidth;
+    g.beta = p->beta;
+    g.scale = p->scale;
+    g.dcf_a = p->dcf_a;
+    g.dcf_b = p->dcf_b;
+    g.kb_terms = p->kb_terms;
+    memcpy(g.kb_poly, p->kb_poly, sizeof(g.kb_poly));
+}
+
+// Adjoint for slices [zfirst, zfirst+zcount).  d_in_z0 points at the first spoke of slice
+// zfirst's window; d_out at that slice's output.
+int adjoint_run(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, int zcount, int combine)
+{
+    const tron_dims &d = p->d;
+    const size_t n2 = (size_t)d.nxos * d.nxos;
+    const size_t elem = p->cfg.input_half ? 4 : 8;
+    const int golden = p->cfg.golden_angle;
+    for (int z0 = 0; z0 < zcount; z0 += p->chunk) {
+        const int cz = std::min(p->chunk, zcount - z0);
+        GridParams g;
+        memset(&g, 0, sizeof(g));
+        fill_grid_consts(p, g);
+        g.nudata = static_cast<const unsigned char *>(d_in_z0) + (size_t)z0 * d.prof_slide * d.nro * p->nchan * elem;
+        g.udata = p->d_grid;
+        g.trig = p->d_trig + (golden ? (size_t)(zfirst + z0) * d.prof_slide : 0);
+        g.in_slice_stride = (long long)d.prof_slide * d.nro * p->nchan;
+        g.trig_slice_stride = golden ? d.prof_slide : 0;
+        g.nslices = cz;
+        g.apply_dcf = 1;
+        g.out_z = (long long)p->nchan * n2;
+        g.out_c = (long long)n2;
+        g.out_p = 1;
+        g.out_shift = 1;
+        {
+            StageTimer t(p, STAGE_GRID);
+            HIP_TRY(launch_grid(g, p->kb_mode, p->cfg.input_half, p->stream));
+        }
+        int rc = run_fft(p, p->d_grid, cz * p->nchan, 1);
+        if (rc) return rc;
+        PostParams q;
+        q.fft = p->d_grid;
+        q.out = static_cast<float2 *>(d_out) + (size_t)z0 * d.nx * d.nx * (combine ? 1 : p->nchan);
+        q.inv_deapod = p->d_deapod;
+        q.nx = d.nx;
+        q.nxos = d.nxos;
+        q.nchan = p->nchan;
+        q.nslices = cz;
+        q.combine = combine;
+        {
+            StageTimer t(p, STAGE_POST);
+            HIP_TRY(launch_post(q, p->stream));
+        }
+    }
+    return TRON_OK;
+}
+
+int forward_run(tron_plan *p, void *d_out, const void *d_in, int nimg)
+{
+    const tron_dims &d = p->d;
+    const size_t n2 = (size_t)d.nxos * d.nxos;
+    for (int k0 = 0; k0 < nimg; k0 += p->chunk) {
+        const int ck = std::min(p->chunk, nimg - k0);
+        PreParams a;
+        a.img = static_cast<const float2 *>(d_in) + (size_t)k0 * p->nchan * d.nx * d.nx;
+        a.fft = p->d_grid;
+        a.inv_deapod = p->d_deapod;
+        a.nx = d.nx;
+        a.nxos = d.nxos;
+        a.nchan = p->nchan;
+        a.nimg = ck;
+        {
+            StageTimer t(p, STAGE_PRE);
+            HIP_TRY(launch_pre(a, p->stream));
+        }
+        int rc = run_fft(p, p->d_grid, ck * p->nchan, 0);
+        if (rc) return rc;
+        DegridParams g;
+        memset(&g, 0, sizeof(g));
+        g.udata = p->d_grid;
+        g.nudata = static_cast<float2 *>(d_out) + (size_t)k0 * p->nchan * d.nro * d.npe1work;
+        g.trig = p->d_trig;
+        g.in_z = (long long)p->nchan * n2;
+        g.in_c = (long long)n2;
+        g.in_p = 1;
+        g.in_shift = 1;
+        g.n = d.nxos;
+        g.nrep = p->nchan;
+        g.nro = d.nro;
+        g.npe = d.npe1work;
+        g.nimg = ck;
+        g.W = p->cfg.kernwidth;
+        g.beta = p->beta;
+        g.kb_terms = p->kb_terms;
+        memcpy(g.kb_poly, p->kb_poly, sizeof(g.kb_poly));
+        {
+            StageTimer t(p, STAGE_DEGRID);
+            HIP_TRY(launch_degrid(g, p->kb_mode, p->stream));
+        }
+    }
+    return TRON_OK;
+}
+
+int ensure_buffer(void **buf, size_t *have, size_t want)
+{
+    if (*have >= want && *buf) return TRON_OK;
+    if (*buf) HIP_TRY(hipFree(*buf));
+    *buf = nullptr;
+    *have = 0;
+    HIP_TRY(hipMalloc(buf, want));
+    *have = want;
+    return TRON_OK;
+}
+
+int check_errflag(tron_plan *p)
+{
+    unsigned int flag = 0;
+    HIP_TRY(hipMemcpy(&flag, p->d_errflag, sizeof(flag), hipMemcpyDeviceToHost));
+    if (flag) {
+        HIP_TRY(hipMemset(p->d_errflag, 0, sizeof(flag)));
+        return fail(TRON_ERR_HIP, "gridding kernel reported an internal overflow (flag %u)", flag);
+    }
+    return TRON_OK;
+}
+
+}  // namespace
+
+extern "C" const char *tron_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" const char *tron_version(void) { return "tronhip 0.1 (gfx950)"; }
+
+extern "C" int tron_plan_create(tron_plan **out, const tron_config *cfg, const tron_dims *dims)
+{
+    if (!out || !cfg || !dims) return fail(TRON_ERR_INVALID, "tron_plan_create: null argument");
+    *out = nullptr;
+    const tron_dims &d = *dims;
+    if (cfg->niter > 0)
+        return fail(TRON_ERR_UNSUPPORTED, "-i %d: the CGNR path is not implemented (the reference marks its own as not working, src/tron.cu:670)", cfg->niter);
+    if (d.nt != 1)
+        return fail(TRON_ERR_UNSUPPORTED, "nt=%d: only nt=1 is supported (the reference's FFT plans ignore nt, src/tron.cu:599-601)", d.nt);
+    if (!(cfg->kernwidth > 0.f) || cfg->kernwidth > 4.f)
+        return fail(TRON_ERR_UNSUPPORTED, "kernel width %g outside (0, 4]", cfg->kernwidth);
+    if (d.nxos < 2 || d.nxos > 16384 || d.nxos != d.nyos || d.nx != d.ny)
+        return fail(TRON_ERR_INVALID, "grid %dx%d (image %dx%d) is not a supported square size", d.nxos, d.nyos, d.nx, d.ny);
+    if (cfg->adjoint && d.nx > d.nxos)
+        return fail(TRON_ERR_INVALID, "adjoint needs gridos >= 1 (nx=%d > nxos=%d)", d.nx, d.nxos);
+    if (cfg->adjoint && (long long)d.nro / 2 + ((long long)(d.nxos / 2 - 1) * d.nro) / d.nxos >= d.nro)
+        return fail(TRON_ERR_INVALID, "readout index would leave the spoke (nro=%d nxos=%d)", d.nro, d.nxos);
+    if (cfg->input_half && !cfg->adjoint)
+        return fail(TRON_ERR_UNSUPPORTED, "half-precision input is only defined for the adjoint (k-space) direction");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (cfg->device < 0 || cfg->device >= ndev)
+        return fail(TRON_ERR_HIP, "device %d requested but %d HIP device(s) present", cfg->device, ndev);
+    HIP_TRY(hipSetDevice(cfg->device));
+    std::call_once(g_fft_once, [] { rocfft_setup(); });
+
+    tron_plan *p = new tron_plan();
+    p->cfg = *cfg;
+    p->d = d;
+    p->nchan = d.nc * d.nt;
+    p->beta = kb_beta(cfg->kernwidth);
+    p->kb_mode = cfg->kb_mode == TRON_KB_FAST ? TRON_KB_FAST : TRON_KB_EXACT;
+    p->kb_terms = kb_taylor(cfg->kernwidth, p->kb_poly, kKbPolyMax);
+    if (p->kb_mode == TRON_KB_FAST && p->kb_terms == 0) p->kb_mode = TRON_KB_EXACT;   // series too long: stay exact
+    dcf_constants(d.nro, d.npe1work, &p->dcf_a, &p->dcf_b);
+    p->scale = grid_scale(d.nxos, d.npe1work);
+
+    const size_t n2 = (size_t)d.nxos * d.nxos;
+    const size_t per_unit = (size_t)p->nchan * n2 * sizeof(float2);
+    int units = cfg->adjoint ? d.nz : 1;
+    int chunk = cfg->chunk_slices > 0 ? cfg->chunk_slices : (int)std::max<size_t>(1, ((size_t)128 << 20) / per_unit);
+    if (const char *env = getenv("TRON_CHUNK_SLICES")) chunk = std::max(1, atoi(env));
+    p->chunk = std::max(1, std::min(chunk, std::max(units, 1)));
+    if (!cfg->adjoint) p->chunk = std::max(1, chunk);
+
+    int rc = TRON_OK;
+    auto bail = [&](int code) { tron_plan_destroy(p); return code; };
+    if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess)
+        return bail(fail(TRON_ERR_HIP, "hipStreamCreate failed"));
+
+    p->ntrig = trig_table_size(*cfg, d);
+    {
+        std::vector<float> trig(2 * p->ntrig);
+        build_trig_table(*cfg, d, trig.data(), p->ntrig);
+        if ((rc = upload(&p->d_trig, trig.data(), trig.size() * sizeof(float)))) return bail(rc);
+    }
+    if (cfg->adjoint) {
+        std::vector<uint32_t> band(n2);
+        build_band_table(d.nxos, cfg->kernwidth, band.data());
+        if ((rc = upload(&p->d_band, band.data(), band.size() * sizeof(uint32_t)))) return bail(rc);
+        std::vector<int> order;
+        build_tile_order(d.nxos, kTile, order);
+        p->tiles_per_row = (d.nxos + kTile - 1) / kTile;
+        p->ntiles = (int)order.size();
+        if ((rc = upload(&p->d_tile_order, order.data(), order.size() * sizeof(int)))) return bail(rc);
+        std::vector<float> dea((size_t)d.nx * d.nx);
+        build_deapod_table(d.nx, cfg->kernwidth, cfg->gridos, dea.data());        // src/tron.cu:635
+        if ((rc = upload(&p->d_deapod, dea.data(), dea.size() * sizeof(float)))) return bail(rc);
+    } else {
+        std::vector<float> dea(n2);
+        build_deapod_table(d.nxos, cfg->kernwidth, 1.f, dea.data());             // src/tron.cu:643
+        if ((rc = upload(&p->d_deapod, dea.data(), dea.size() * sizeof(float)))) return bail(rc);
+    }
+    unsigned int zero = 0;
+    if ((rc = upload(&p->d_errflag, &zero, sizeof(zero)))) return bail(rc);
+    if (hipMalloc(reinterpret_cast<void **>(&p->d_grid), (size_t)p->chunk * per_unit) != hipSuccess)
+        return bail(fail(TRON_ERR_NOMEM, "cannot allocate %zu bytes of Cartesian work space", (size_t)p->chunk * per_unit));
+    if (cfg->verbose) {
+        printf("tronhip: device %d, %s, nchan %d, grid %d^2 -> image %d^2, %d spokes/image, chunk %d, KB %s\n",
+               cfg->device, cfg->adjoint ? "adjoint" : "forward", p->nchan, d.nxos, d.nx, d.npe1work, p->chunk,
+               p->kb_mode == TRON_KB_FAST ? "fast" : "exact");
+    }
+    *out = p;
+    return TRON_OK;
+}
+
+extern "C" int tron_plan_destroy(tron_plan *p)
+{
+    if (!p) return TRON_OK;
+    hipSetDevice(p->cfg.device);
+    if (p->stream) hipStreamSynchronize(p->stream);
+    for (int s = 0; s < STAGE_COUNT; ++s)
+        for (auto &pr : p->ev[s]) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+    for (auto &kv : p->fft) {
+        if (kv.second.info) rocfft_execution_info_destroy(kv.second.info);
+        if (kv.second.plan) rocfft_plan_destroy(kv.second.plan);
+        if (kv.second.work) hipFree(kv.second.work);
+    }
+    hipFree(p->d_trig);
+    hipFree(p->d_band);
+    hipFree(p->d_tile_order);
+    hipFree(p->d_deapod);
+    hipFree(p->d_errflag);
+    hipFree(p->d_grid);
+    hipFree(p->d_stage_in);
+    hipFree(p->d_stage_out);
+    hipFree(p->d_trig_tmp);
+    if (p->stream) hipStreamDestroy(p->stream);
+    delete p;
+    return TRON_OK;
+}
+
+extern "C" int tron_plan_sync(tron_plan *p)
+{
+    if (!p) return fail(TRON_ERR_INVALID, "tron_plan_sync: null plan");
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return check_errflag(p);
+}
+
+extern "C" int tron_nufft_adj_radial2d(tron_plan *p, void *d_out, const void *d_in, int zfirst, int zcount, int combine)
+{
+    if (!p || !d_out || !d_in) return fail(TRON_ERR_INVALID, "tron_nufft_adj_radial2d: null argument");
+    if (!p->cfg.adjoint) return fail(TRON_ERR_INVALID, "plan was created for the forward direction");
+    const tron_dims &d = p->d;
+    if (zfirst < 0 || zcount < 0 || zfirst + zcount > d.nz)
+        return fail(TRON_ERR_INVALID, "slice range [%d,%d) outside [0,%d)", zfirst, zfirst + zcount, d.nz);
+    const long long last = (long long)(zfirst + zcount - 1) * d.prof_slide + d.npe1work;
+    if (zcount > 0 && last > (long long)d.npe1 * d.npe2)
+        return fail(TRON_ERR_INVALID, "slice %d would read spokes up to %lld but the input holds %lld (the reference reads out of bounds here)",
+                    zfirst + zcount - 1, last, (long long)d.npe1 * d.npe2);
+    HIP_TRY(hipSetDevice(p->cfg.device));
+    const size_t elem = p->cfg.input_half ? 4 : 8;
+    const unsigned char *in = static_cast<const unsigned char *>(d_in) + (size_t)zfirst * d.prof_slide * d.nro * p->nchan * elem;
+    return adjoint_run(p, d_out, in, zfirst, zcount, combine);
+}
+
+extern "C" int tron_nufft_radial2d(tron_plan *p, void *d_out, const void *d_in, int nimg)
+{
+    if (!p || !d_out || !d_in) return fail(TRON_ERR_INVALID, "tron_nufft_radial2d: null argument");
+    if (p->cfg.adjoint) return fail(TRON_ERR_INVALID, "plan was created for the adjoint direction");
+    if (nimg < 0) return fail(TRON_ERR_INVALID, "nimg < 0");
+    HIP_TRY(hipSetDevice(p->cfg.device));
+    return forward_run(p, d_out, d_in, nimg);
+}
+
+extern "C" int tron_recon_radial2d_range(tron_plan *p, tron_float2 *h_out, const tron_float2 *h_in, int zfirst, int zcount)
+{
+    if (!p || !h_out || !h_in) return fail(TRON_ERR_INVALID, "tron_recon_radial2d: null argument");
+    const tron_dims &d = p->d;
+    if (zfirst < 0 || zcount < 0 || zfirst + zcount > d.nz)
+        return fail(TRON_ERR_INVALID, "slice range [%d,%d) outside [0,%d)", zfirst, zfirst + zcount, d.nz);
+    if (zcount == 0) return TRON_OK;
+    HIP_TRY(hipSetDevice(p->cfg.device));
+    int rc;
+    if (p->cfg.adjoint) {
+        const size_t elem = p->cfg.input_half ? 4 : 8;
+        const long long last = (long long)(zfirst + zcount - 1) * d.prof_slide + d.npe1work;
+        if (last > (long long)d.npe1 * d.npe2)
+            return fail(TRON_ERR_INVALID, "slice %d would read spokes up to %lld but the input holds %lld (the reference reads out of bounds here)",
+                        zfirst + zcount - 1, last, (long long)d.npe1 * d.npe2);
+        // one upload of every spoke the range touches; windows are views (src/tron.cu:738-748)
+        const size_t spoke_bytes = (size_t)d.nro * p->nchan * elem;
+        const size_t first_spoke = (size_t)zfirst * d.prof_slide;
+        const size_t nspokes = (size_t)(zcount - 1) * d.prof_slide + d.npe1work;
+        if ((rc = ensure_buffer(&p->d_stage_in, &p->stage_in_bytes, nspokes * spoke_bytes))) return rc;
+        const size_t out_elems = (size_t)zcount * d.nt * d.nx * d.ny;
+        if ((rc = ensure_buffer(&p->d_stage_out, &p->stage_out_bytes, out_elems * sizeof(float2)))) return rc;
+        HIP_TRY(hipMemcpyAsync(p->d_stage_in, reinterpret_cast<const unsigned char *>(h_in) + first_spoke * spoke_bytes,
+                               nspokes * spoke_bytes, hipMemcpyHostToDevice, p->stream));
+        if ((rc = adjoint_run(p, p->d_stage_out, p->d_stage_in, zfirst, zcount, 1))) return rc;   // + coilcombinesos, src/tron.cu:764
+        HIP_TRY(hipMemcpyAsync(h_out + (size_t)d.nt * d.nx * d.ny * zfirst, p->d_stage_out, out_elems * sizeof(float2),
+                               hipMemcpyDeviceToHost, p->stream));                               // img_offset, src/tron.cu:740,768
+        return tron_plan_sync(p);
+    }
+    // forward: every z reads h_in + nc*nt*nro*(z*prof_slide) (src/tron.cu:738-739,750) -- with the
+    // default prof_slide that is slice 0 for every z -- and writes block z (src/tron.cu:776)
+    const size_t in_elems = (size_t)p->nchan * d.nx * d.ny;
+    const size_t out_elems = (size_t)p->nchan * d.nro * d.npe1work;
+    if ((rc = ensure_buffer(&p->d_stage_in, &p->stage_in_bytes, in_elems * sizeof(float2)))) return rc;
+    if ((rc = ensure_buffer(&p->d_stage_out, &p->stage_out_bytes, out_elems * sizeof(float2)))) return rc;
+    for (int z = zfirst; z < zfirst + zcount; ++z) {
+        if ((uint64_t)(z + 1) * out_elems * sizeof(float2) > d.out_bytes) break;   // h_out is sized for npe2 blocks (src/tron.cu:960)
+        const size_t data_offset = (size_t)p->nchan * d.nro * ((size_t)z * p->cfg.prof_slide);
+        if (data_offset + in_elems > d.in_elems)
+            return fail(TRON_ERR_INVALID, "forward slice %d would read past the input (offset %zu)", z, data_offset);
+        HIP_TRY(hipMemcpyAsync(p->d_stage_in, h_in + data_offset, in_elems * sizeof(float2), hipMemcpyHostToDevice, p->stream));
+        if ((rc = forward_run(p, p->d_stage_out, p->d_stage_in, 1))) return rc;
+        HIP_TRY(hipMemcpyAsync(h_out + out_elems * z, p->d_stage_out, out_elems * sizeof(float2), hipMemcpyDeviceToHost, p->stream));
+        HIP_TRY(hipStreamSynchronize(p->stream));
+    }
+    return tron_plan_sync(p);
+}
+
+extern "C" int tron_recon_radial2d(tron_plan *p, tron_float2 *h_out, const tron_float2 *h_in)
+{
+    if (!p) return fail(TRON_ERR_INVALID, "tron_recon_radial2d: null plan");
+    return tron_recon_radial2d_range(p, h_out, h_in, 0, p->d.nz);
+}
+
+extern "C" int tron_gridradial2d(tron_plan *p, void *d_udata, const void *d_nudata, int skip)
+{
+    if (!p || !d_udata || !d_nudata) return fail(TRON_ERR_INVALID, "tron_gridradial2d: null argument");
+    if (!p->cfg.adjoint) return fail(TRON_ERR_INVALID, "plan was created for the forward direction");
+    HIP_TRY(hipSetDevice(p->cfg.device));
+    const tron_dims &d = p->d;
+    std::vector<float> trig(2 * (size_t)d.npe1work);
+    build_trig_table_window(d.npe1work, skip, p->cfg.golden_angle, trig.data());
+    if (!p->d_trig_tmp) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_trig_tmp), trig.size() * sizeof(float)));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    HIP_TRY(hipMemcpy(p->d_trig_tmp, trig.data(), trig.size() * sizeof(float), hipMemcpyHostToDevice));
+    GridParams g;
+    memset(&g, 0, sizeof(g));
+    fill_grid_consts(p, g);
+    g.nudata = d_nudata;
+    g.udata = static_cast<float2 *>(d_udata);
+    g.trig = p->d_trig_tmp;
+    g.in_slice_stride = 0;
+    g.trig_slice_stride = 0;
+    g.nslices = 1;
+    g.apply_dcf = 0;                      // the caller ran precompensate, as at src/tron.cu:628-629
+    g.out_z = 0;
+    g.out_c = 1;                          // udata[nchan*id + ch], src/tron.cu:534
+    g.out_p = p->nchan;
+    g.out_shift = 0;
+    StageTimer t(p, STAGE_GRID);
+    HIP_TRY(launch_grid(g, p->kb_mode, 0, p->stream));
+    return TRON_OK;
+}
+
+extern "C" int tron_degridradial2d(tron_plan *p, void *d_nudata, const void *d_udata)
+{
+    if (!p || !d_udata || !d_nudata) return fail(TRON_ERR_INVALID, "tron_degridradial2d: null argument");
+    if (p->cfg.adjoint) return fail(TRON_ERR_INVALID, "plan was created for the adjoint direction");
+    HIP_TRY(hipSetDevice(p->cfg.device));
+    const tron_dims &d = p->d;
+    DegridParams g;
+    memset(&g, 0, sizeof(g));
+    g.udata = static_cast<const float2 *>(d_udata);
+    g.nudata = static_cast<float2 *>(d_nudata);
+    g.trig = p->d_trig;
+    g.in_z = 0;
+    g.in_c = 1;                           // udata[nrep*(i*n+j) + c], src/tron.cu:571-573
+    g.in_p = p->nchan;
+    g.in_shift = 0;
+    g.n = d.nxos;
+    g.nrep = p->nchan;
+    g.nro = d.nro;
+    g.npe = d.npe1work;
+    g.nimg = 1;
+    g.W = p->cfg.kernwidth;
+    g.beta = p->beta;
+    g.kb_terms = p->kb_terms;
+    memcpy(g.kb_poly, p->kb_poly, sizeof(g.kb_poly));
+    StageTimer t(p, STAGE_DEGRID);
+    HIP_TRY(launch_degrid(g, p->kb_mode, p->stream));
+    return TRON_OK;
+}
+
+extern "C" int tron_plan_timing(tron_plan *p, int enable)
+{
+    if (!p) return fail(TRON_ERR_INVALID, "null plan");
+    int rc = drain_timers(p);
+    p->timing = enable != 0;
+    return rc;
+}
+
+extern "C" int tron_plan_timing_get(tron_plan *p, int stage, double *ms, uint64_t *launches)
+{
+    if (!p || stage < 0 || stage >= STAGE_COUNT) return fail(TRON_ERR_INVALID, "bad stage");
+    int rc = drain_timers(p);
+    if (rc) return rc;
+    if (ms) *ms = p->ms_acc[stage];
+    if (launches) *launches = p->launches[stage];
+    return TRON_OK;
+}
+
+extern "C" int tron_plan_timing_reset(tron_plan *p)
+{
+    if (!p) return fail(TRON_ERR_INVALID, "null plan");
+    int rc = drain_timers(p);
+    for (int s = 0; s < STAGE_COUNT; ++s) { p->ms_acc[s] = 0; p->launches[s] = 0; }
+    return rc;
+}
+
+extern "C" int tron_device_count(int *count)
+{
+    if (!count) return fail(TRON_ERR_INVALID, "null argument");
+    *count = 0;
+    hipError_t e = hipGetDeviceCount(count);
+    if (e != hipSuccess) { *count = 0; return fail(TRON_ERR_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    return TRON_OK;
+}
+
+extern "C" int tron_device_malloc(void **d_ptr, size_t bytes)
+{
+    if (!d_ptr) return fail(TRON_ERR_INVALID, "null argument");
+    HIP_TRY(hipMalloc(d_ptr, bytes ? bytes : 1));
+    return TRON_OK;
+}
+
+extern "C" int tron_device_free(void *d_ptr)
+{
+    HIP_TRY(hipFree(d_ptr));
+    return TRON_OK;
+}
+
+extern "C" int tron_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes)
+{
+    HIP_TRY(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice));
+    return TRON_OK;
+}
+
+extern "C" int tron_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes)
+{
+    HIP_TRY(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost));
+    return TRON_OK;
+}
