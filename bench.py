@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""Throughput of the radial gridding reconstruction (adjoint NUFFT) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--coils C] [--slices S] [--kb fast|exact]
+
+One "step" = one pass of the hot path (density compensation + Kaiser-Bessel gridding + 2-D FFT +
+crop/deapodise/coil-combine) over one batch of S slices of synthetic golden-angle radial k-space,
+512 readout x 402 spokes x C coils per slice onto a 512^2 grid -> 256^2 images, inputs and
+outputs resident in HBM.  For N > 1 every rank (one process per GPU, launched by
+torch.distributed.run) processes its own S slices: slices are independent, there is no
+collective on the data path, scaling is weak.
+
+Prints ONE JSON line (rank 0): whole-job slices/s plus
+  roofline      the dominant kernel's algorithmic bytes / its mean hipEvent duration, vs 8 TB/s
+  cpu_baseline  the CPU oracle (a port of the reference's algorithm) timed on this host on a
+                bounded sample of the same workload
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+NRO, NPE, NXOS, NX = 512, 402, 512, 256
+HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+
+
+def algorithmic_bytes(nc):
+    """bytes that must cross HBM per coil-slice and per slice."""
+    grid = 8 * NRO * NPE + 8 * NXOS * NXOS          # read samples once + write grid once
+    fft = 2 * 8 * NXOS * NXOS                       # one read + one write
+    post_cs = 8 * NX * NX                           # read centre crop
+    per_cs = grid + fft + post_cs                   # 8 462 336
+    per_slice = nc * per_cs + 8 * NX * NX           # + image write
+    return dict(grid=grid, fft=fft, post=post_cs + 8 * NX * NX / nc, per_cs=per_cs, per_slice=per_slice)
+
+
+def cpu_baseline(nc, sample_slices):
+    """The CPU oracle (oracle/, a port of the reference's own algorithm: point-driven gather
+    over every spoke, src/tron.cu:465-536) on `sample_slices` slices of the same shape."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import synth
+    from oracle import pyoracle
+    threads = os.cpu_count() or 1
+    data = synth.kspace(nc, NRO, NPE * sample_slices, seed=synth.SEED_BASE)
+    t0 = time.perf_counter()
+    out, p = pyoracle.recon(data, adjoint=1, golden=1, data_undersamp=0.7852, prof_slide=NPE)
+    dt = time.perf_counter() - t0
+    assert p.nz == sample_slices and p.npe1work == NPE
+    return dict(value=sample_slices / dt, unit="slices/s", cores=threads, kind="port",
+                sample=f"{sample_slices} slice(s) x {nc} coil(s) of 512x402 golden-angle through the full oracle pipeline "
+                       f"(OpenMP over grid points, {threads} threads), {dt:.1f} s wall"), out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--coils", type=int, default=8)
+    ap.add_argument("--slices", type=int, default=256, help="slices per GPU per step")
+    ap.add_argument("--kb", choices=["fast", "exact"], default="fast")
+    ap.add_argument("--chunk", type=int, default=0, help="slices per internal batch (0 = auto)")
+    ap.add_argument("--cpu-slices", type=int, default=2, help="slices of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-check", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    # torch first: it brings the HIP runtime every later library (ours included) binds to
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
+    torch.cuda.set_device(local_rank)
+    torch.zeros(1, device="cuda")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import ctypes
+    import numpy as np
+    from tron_amd import lib
+
+    nc, nz = args.coils, args.slices
+    cfg = lib.default_config(adjoint=1, golden_angle=1, data_undersamp=0.7852, prof_slide=NPE, device=local_rank,
+                             kb_mode=lib.KB_FAST if args.kb == "fast" else lib.KB_EXACT, chunk_slices=args.chunk)
+    dims = lib.derive_dims(cfg, (nc, 1, NRO, NPE * nz, 1))
+    assert (dims.nz, dims.npe1work, dims.nxos, dims.nx) == (nz, NPE, NXOS, NX)
+    plan = lib.Plan(cfg, dims)
+
+    # synthetic k-space, uniform [-1,1) re/im, laid out [c + nc*(ro + nro*spoke)], resident in HBM
+    g = torch.Generator(device="cuda")
+    g.manual_seed(0x54524F4E + rank)
+    kspace = torch.rand(2 * nc * NRO * NPE * nz, device="cuda", generator=g, dtype=torch.float32) * 2 - 1
+    images = torch.empty(2 * NX * NX * nz, device="cuda", dtype=torch.float32)
+    d_in, d_out = ctypes.c_void_p(kspace.data_ptr()), ctypes.c_void_p(images.data_ptr())
+
+    def step():
+        plan.adjoint_device(d_out, d_in, 0, nz, combine=1)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    plan.sync()   # surfaces a device-side error flag, if any
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    value = world * nz * args.steps / dt
+
+    # per-kernel durations, measured live with hipEvents on the library's own stream
+    ab = algorithmic_bytes(nc)
+    roofline = None
+    stages = {}
+    if rank == 0:
+        plan.timing(True)
+        plan.timing_reset()
+        for _ in range(max(2, min(args.steps, 5))):
+            step()
+        names = {lib.STAGE_GRID: "grid", lib.STAGE_FFT: "fft", lib.STAGE_POST: "post"}
+        for st, name in names.items():
+            ms, n = plan.timing_get(st)
+            stages[name] = (ms, n)
+        plan.timing(False)
+        tot = sum(ms for ms, _ in stages.values())
+        dom = max(stages, key=lambda k: stages[k][0])
+        ms, n = stages[dom]
+        units_per_launch = nz * nc * max(2, min(args.steps, 5)) / n       # coil-slices per launch
+        bytes_per_launch = ab[dom] * units_per_launch
+        achieved = bytes_per_launch / (ms / n * 1e-3) / 1e9
+        roofline = dict(bound="hbm", kernel={"grid": "grid_tile_kernel", "fft": "rocFFT 512x512 C2C inverse (batched)", "post": "post_kernel"}[dom],
+                        achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBPS, 4),
+                        traffic=None, bytes_per_launch=int(bytes_per_launch), launch_ms=round(ms / n, 4),
+                        stage_share={k: round(v[0] / tot, 3) for k, v in stages.items()})
+
+    result = None
+    if rank == 0:
+        cpu = None
+        if args.cpu_slices > 0:
+            cpu, _ = cpu_baseline(nc, args.cpu_slices)
+            cpu["value"] = round(cpu["value"], 4)
+        if not args.no_check:
+            # the timed path produced real images: spot-check one slice of this rank against the oracle
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from oracle import pyoracle
+            host = kspace[: 2 * nc * NRO * NPE].cpu().numpy().view(np.complex64).reshape((nc, 1, NRO, NPE, 1), order="F")
+            want, _ = pyoracle.recon(host, adjoint=1, golden=1, data_undersamp=0.7852, prof_slide=NPE)
+            got = images[: 2 * NX * NX].cpu().numpy().view(np.complex64)
+            err = float(np.linalg.norm(got - want.reshape(-1, order="F")) / np.linalg.norm(want))
+            if not err <= 1e-5:
+                raise SystemExit(f"bench output disagrees with the oracle: rel L2 {err:.3e}")
+        else:
+            err = None
+        hbm_gbps = ab["per_slice"] * value / world / 1e9      # per GPU
+        result = {
+            "metric": "2D slices/sec gridded (512^2 grid, 512x402 golden-angle) + achieved HBM GB/s",
+            "value": round(value, 1), "unit": "slices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"adjoint gridding recon: {nz} slices/GPU/step x {nc} coils, 512 readout x 402 golden-angle spokes "
+                                   f"-> 512^2 oversampled grid -> 256^2 image (tron -a -G -u 0.7852 -d 402)",
+                       "coils": nc, "slices_per_gpu": nz, "kb_mode": args.kb, "parallelism": f"slices sharded over {world} GPU(s), no collective"},
+            "hbm_gbps_per_gpu": round(hbm_gbps, 1), "hbm_frac_of_peak": round(hbm_gbps / HBM_PEAK_GBPS, 4),
+            "coil_slices_per_s": round(value * nc, 1),
+            "parity_rel_l2_vs_oracle": err,
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+    plan.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()
