@@ -1,0 +1,31 @@
+"""Stage timing of the adjoint on the metric shape (tooling for kernel work).
+usage: python tools/gridbench.py [coils] [slices] [kb fast|exact] [reps]"""
+import ctypes, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tron_amd import lib
+nc = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+nz = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+kb = lib.KB_FAST if (len(sys.argv) <= 3 or sys.argv[3] == "fast") else lib.KB_EXACT
+reps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+NRO, NPE = 512, 402
+cfg = lib.default_config(adjoint=1, golden_angle=1, data_undersamp=0.7852, prof_slide=NPE, kb_mode=kb)
+dims = lib.derive_dims(cfg, (nc, 1, NRO, NPE * nz, 1))
+rng = np.random.default_rng(1)
+data = (rng.random(2 * nc * NRO * NPE * nz, dtype=np.float32) * 2 - 1)
+with lib.Plan(cfg, dims) as plan:
+    d_in = lib.DeviceBuffer.from_numpy(data)
+    d_out = lib.DeviceBuffer(dims.out_bytes)
+    plan.adjoint_device(d_out.ptr, d_in.ptr, 0, nz, 1); plan.sync()
+    plan.timing(True); plan.timing_reset()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        plan.adjoint_device(d_out.ptr, d_in.ptr, 0, nz, 1)
+    plan.sync()
+    dt = time.perf_counter() - t0
+    cs = nc * nz * reps
+    line = f"nc={nc} nz={nz} kb={'fast' if kb else 'exact'} skip={os.environ.get('TRON_DEBUG_SKIP','0')}: total {dt/cs*1e6:.3f} us/coil-slice ({nz*reps/dt:.0f} slices/s)"
+    for st, name in ((lib.STAGE_GRID, "grid"), (lib.STAGE_FFT, "fft"), (lib.STAGE_POST, "post")):
+        ms, n = plan.timing_get(st)
+        line += f" | {name} {ms/cs*1e3:.3f}"
+    print(line)

@@ -22,7 +22,7 @@ void build_band_table(int nxos, float kernwidth, uint32_t *band);
 void build_deapod_table(int n, float kernwidth, float sigma, float *inv_weight);
 void build_tile_order(int nxos, int tile, std::vector<int> &order);
 float kb_beta(float kernwidth);
-int kb_taylor(float kernwidth, float *poly, int max_terms);
+double kb_poly_fit(float kernwidth, float *poly, int nterms);
 void dcf_constants(int nro, int npe1work, float *a, float *b);
 float grid_scale(int nxos, int npe);
 

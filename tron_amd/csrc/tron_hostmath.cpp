@@ -149,23 +149,68 @@ float grid_scale(int nxos, int npe)
     return 1.f / nxos / npe;
 }
 
-// Taylor coefficients of (0.5/W) * I0(beta*sqrt(s)) in s, highest power first.  Returns the
-// number of terms, or 0 if more than `max_terms` would be needed for ~1e-9 accuracy.
-int kb_taylor(float kernwidth, float *poly, int max_terms)
+// Modified Bessel function I0 by its power series, in double.
+static double bessel_i0_series(double t)
+{
+    const double q = t * t / 4.0;
+    double term = 1.0, sum = 1.0;
+    for (int k = 1; k < 500; ++k) {
+        term *= q / ((double)k * (double)k);
+        sum += term;
+        if (term < 1e-18 * sum) break;
+    }
+    return sum;
+}
+
+// Coefficients (highest power first) of a degree-(nterms-1) polynomial in s = 1-(x/W)^2 that
+// approximates G(s) = (0.5/W)*I0(beta*sqrt(s)), the un-normalised Kaiser-Bessel window of
+// src/tron.cu:338-349, on [0,1]: Chebyshev interpolation, converted to the monomial basis in
+// long double.  Returns the largest relative error against G on a dense grid.
+double kb_poly_fit(float kernwidth, float *poly, int nterms)
 {
     const double beta = kb_beta(kernwidth);
-    const double q = beta * beta / 4.0;
-    std::vector<double> a;
-    double term = 1.0;
-    for (int k = 0; k < 200; ++k) {
-        a.push_back(term);
-        term *= q / ((double)(k + 1) * (double)(k + 1));
-        if (k + 1 > q && term < 1e-9) break;                  // past the largest term and negligible vs I0(0) = 1
+    const double amp = 0.5 / (double)kernwidth;
+    const int N = nterms;
+    std::vector<long double> c(N, 0.0L);
+    for (int k = 0; k < N; ++k) {
+        long double acc = 0.0L;
+        for (int j = 0; j < N; ++j) {
+            const long double th = M_PIl * (j + 0.5L) / N;
+            const double sj = (double)((cosl(th) + 1.0L) / 2.0L);
+            acc += (long double)(amp * bessel_i0_series(beta * sqrt(sj))) * cosl(k * th);
+        }
+        c[k] = acc * 2.0L / N;
     }
-    if ((int)a.size() > max_terms) return 0;
-    const int nt = (int)a.size();
-    for (int k = 0; k < nt; ++k) poly[k] = (float)(a[nt - 1 - k] * 0.5 / (double)kernwidth);
-    return nt;
+    c[0] /= 2.0L;
+    // T_k(t) as polynomials in t, then t = 2s - 1
+    std::vector<std::vector<long double>> T(N, std::vector<long double>(N, 0.0L));
+    T[0][0] = 1.0L;
+    if (N > 1) T[1][1] = 1.0L;
+    for (int k = 2; k < N; ++k)
+        for (int m = 0; m < N; ++m)
+            T[k][m] = (m > 0 ? 2.0L * T[k - 1][m - 1] : 0.0L) - T[k - 2][m];
+    std::vector<long double> pt(N, 0.0L);          // polynomial in t
+    for (int k = 0; k < N; ++k)
+        for (int m = 0; m < N; ++m) pt[m] += c[k] * T[k][m];
+    std::vector<long double> ps(N, 0.0L);          // polynomial in s
+    for (int m = 0; m < N; ++m) {
+        // (2s-1)^m = sum_j C(m,j) (2s)^j (-1)^(m-j)
+        long double binom = 1.0L;
+        for (int j = 0; j <= m; ++j) {
+            ps[j] += pt[m] * binom * powl(2.0L, j) * (((m - j) & 1) ? -1.0L : 1.0L);
+            binom = binom * (m - j) / (j + 1);
+        }
+    }
+    for (int k = 0; k < N; ++k) poly[k] = (float)ps[N - 1 - k];
+    double worst = 0.0;
+    for (int i = 0; i <= 4096; ++i) {
+        const double sv = i / 4096.0;
+        double acc = poly[0];
+        for (int k = 1; k < N; ++k) acc = acc * sv + (double)poly[k];
+        const double want = amp * bessel_i0_series(beta * sqrt(sv));
+        worst = fmax(worst, fabs(acc / want - 1.0));
+    }
+    return worst;
 }
 
 // Tiles sorted by distance from the k-space centre: radial sampling density falls as 1/r, so

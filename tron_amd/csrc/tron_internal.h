@@ -8,9 +8,9 @@
 namespace tron {
 
 constexpr int kTile = 16;          // Cartesian tile edge owned by one workgroup (gridding)
-constexpr int kGridThreads = 256;  // one thread per tile point, 4 waves of 16x4 points
-constexpr int kBatchSpokes = 16;   // spokes staged in LDS per batch
-constexpr int kKbPolyMax = 26;     // Taylor terms the fast Kaiser-Bessel may use
+constexpr int kGridThreads = 64;   // one wave per tile, each lane owns 2x2 points
+constexpr int kGridRecords = 128;  // sample records staged in LDS per batch
+constexpr int kKbPolyTerms = 16;   // coefficients of the fast Kaiser-Bessel polynomial (degree 15)
 
 // Parameters of one gridding launch (adjoint interpolation), see tron_kernels.hip.
 struct GridParams {
@@ -30,8 +30,8 @@ struct GridParams {
     long long out_z, out_c;  // output strides (complex elements) per slice and per coil
     int out_p;               // output stride per pixel
     int out_shift;           // 1: rows/cols stored in FFT-native order ((Y+n)%n), 0: centred (Y+n/2)
-    int kb_terms;            // fast mode: number of Taylor coefficients in kb_poly
-    float kb_poly[kKbPolyMax];  // highest power first, includes the 0.5/W factor
+    float kb_poly[kKbPolyTerms];  // fast mode: highest power first, includes the 0.5/W factor
+    int debug;               // TRON_DEBUG_SKIP: 1 = skip the gather phase, 2 = skip staging too (timing experiments only)
 };
 
 struct PostParams {           // crop + deapodise + (optional) root-sum-of-squares, adjoint tail
@@ -56,8 +56,7 @@ struct DegridParams {
     int in_p, in_shift;       // pixel stride; 1: input is the raw FFT output (second fftshift folded into indexing)
     int n, nrep, nro, npe, nimg;
     float W, beta;
-    int kb_terms;
-    float kb_poly[kKbPolyMax];
+    float kb_poly[kKbPolyTerms];
 };
 
 // launchers (tron_kernels.hip); kb_mode: TRON_KB_EXACT / TRON_KB_FAST; half_in: nudata is half2

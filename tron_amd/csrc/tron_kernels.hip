@@ -48,14 +48,13 @@ __device__ __forceinline__ float besseli0_ref(const float x)
 }
 
 struct KbCoef {
-    float W, beta;
-    int terms;
-    const float *poly;
+    float W, invW, beta;
+    float poly[kKbPolyTerms];
 };
 
-// src/tron.cu:338-349.  EXACT: the reference's expression tree.  FAST: I0(beta*sqrt(s)) is
-// an entire function of s = 1-(x/W)^2 with positive Taylor coefficients, evaluated by Horner
-// in fp32 (no sqrt, no division); coefficients (incl. 0.5/W) come from the host.
+// src/tron.cu:338-349.  EXACT: the reference's expression tree.  FAST: (0.5/W)*I0(beta*sqrt(s)) is
+// an entire function of s = 1-(x/W)^2; a fixed-degree polynomial in s (Chebyshev-economised on
+// the host, coefficients held in scalar registers) replaces sqrt, the rational I0 and the division.
 template <int KB>
 __device__ __forceinline__ float kb_weight(const float x, const KbCoef &k)
 {
@@ -65,10 +64,11 @@ __device__ __forceinline__ float kb_weight(const float x, const KbCoef &k)
         float f = sqrtf(1.0f - r * r);
         return 0.5f * besseli0_ref(k.beta * f) / k.W;
     } else {
-        float r = x / k.W;
+        float r = x * k.invW;
         float s = fmaf(-r, r, 1.0f);
         float acc = k.poly[0];
-        for (int t = 1; t < k.terms; ++t) acc = fmaf(acc, s, k.poly[t]);
+#pragma unroll
+        for (int t = 1; t < kKbPolyTerms; ++t) acc = fmaf(acc, s, k.poly[t]);
         return acc;
     }
 }
@@ -80,38 +80,18 @@ __device__ __forceinline__ float safe_rcp(float c)
 
 // ------------------------------------------------------------------------- gridding
 
-struct SpokeEntry {   // an accepted spoke of the current clip chunk
-    float ct, st;
-    int pe;
-    int rlo, rhi;
-    int pad0, pad1, pad2;
-};
-
-struct BatchSpoke {   // a staged spoke
-    float ct, st, reach, inv;
-    int rlo, rhi, use_x, pad;
-};
-
 template <int CW>
 struct GridCfg {
-    static constexpr int LPS = (CW <= 2) ? 32 : 64;       // lanes (= LDS record slots) per spoke
-    static constexpr int SPI = kGridThreads / LPS;        // spokes staged per iteration
-    static constexpr int NREC = kBatchSpokes * LPS;
+    static constexpr int LPS = (CW <= 2) ? 32 : 64;       // lanes (= LDS record slots) per staged spoke
+    static constexpr int NSP = kGridRecords / LPS;        // spokes staged per batch
     static constexpr int NW = 2 * CW;                     // footprint points per dimension
+    static constexpr int NWP = NW + 2;                    // ... padded with a zero on both sides
 };
 
 size_t grid_lds_bytes(int cpb, int cw)
 {
-    const int lps = (cw <= 2) ? 32 : 64;
-    const size_t nrec = (size_t)kBatchSpokes * lps;
-    size_t b = 0;
-    b += sizeof(SpokeEntry) * kGridThreads;
-    b += sizeof(BatchSpoke) * kBatchSpokes;
-    b += 16;                                  // wave counters
-    b += nrec * sizeof(uint32_t);             // footprint origins
-    b += nrec * 2 * cw * sizeof(float) * 2;   // wx, wy
-    b += nrec * (size_t)cpb * sizeof(float2); // samples
-    return b;
+    const size_t nwp = 2 * (size_t)cw + 2;
+    return (size_t)kGridRecords * (2 * nwp * sizeof(float) + (size_t)cpb * sizeof(float2));
 }
 
 template <bool HALF>
@@ -126,24 +106,18 @@ __device__ __forceinline__ float2 load_sample(const void *base, size_t idx)
 }
 
 // = precompensate + gridradial2d (src/tron.cu:405-416, 465-536) for a batch of slices.
-// grid = (ntiles*nslices, coil chunks); block = 256 threads = one 16x16 tile.
+// grid = (ntiles*nslices, coil chunks); block = ONE wave64 = one 16x16 tile, lane = 2x2 points.
 template <int CPB, int CW, int KB, bool HALF>
 __global__ void __launch_bounds__(kGridThreads)
 grid_tile_kernel(const GridParams p)
 {
     using C = GridCfg<CW>;
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    SpokeEntry *s_list = reinterpret_cast<SpokeEntry *>(lds_raw);
-    BatchSpoke *s_sp = reinterpret_cast<BatchSpoke *>(s_list + kGridThreads);
-    int *s_wcnt = reinterpret_cast<int *>(s_sp + kBatchSpokes);
-    uint32_t *s_b = reinterpret_cast<uint32_t *>(s_wcnt + 4);
-    float *s_wx = reinterpret_cast<float *>(s_b + C::NREC);
-    float *s_wy = s_wx + C::NREC * C::NW;
-    float2 *s_d = reinterpret_cast<float2 *>(s_wy + C::NREC * C::NW);
+    float *s_wx = reinterpret_cast<float *>(lds_raw);                 // [record][NWP], zero padded
+    float *s_wy = s_wx + kGridRecords * C::NWP;
+    float2 *s_d = reinterpret_cast<float2 *>(s_wy + kGridRecords * C::NWP);   // [record][CPB]
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int lane = threadIdx.x;
     const int z = blockIdx.x % p.nslices;
     const int tile = p.tile_order[blockIdx.x / p.nslices];
     const int c0 = p.coil0 + blockIdx.y * CPB;
@@ -152,26 +126,38 @@ grid_tile_kernel(const GridParams p)
     const int h = n / 2;
     const int rmax = n / 2 - 1;
 
-    // tile origin and this thread's point, centred coordinates (src/tron.cu:495-496)
+    // tile origin and this lane's 2x2 points, centred coordinates (src/tron.cu:495-496)
     const int x0 = (tile % p.tiles_per_row) * kTile - h;
     const int y0 = (tile / p.tiles_per_row) * kTile - h;
-    const int X = x0 + (lane & 15);
-    const int Y = y0 + wave * 4 + (lane >> 4);
-    const bool inside = (X + h < n) && (Y + h < n);
-    int Rlo = 1 << 20, Rhi = -1;                // empty band for points outside the grid
-    if (inside) {
-        const uint32_t bnd = p.band[(size_t)(Y + h) * n + (X + h)];   // src/tron.cu:498-502
-        Rlo = (int)(bnd & 0xffffu);
-        Rhi = (int)(bnd >> 16);
+    const int X0 = x0 + 2 * (lane & 7);
+    const int Y0 = y0 + 2 * (lane >> 3);
+    // radial band of each point (src/tron.cu:498-502); empty for points outside the grid
+    int Rlo[4], Rhi[4];
+    int RloMin = 1 << 20, RhiMax = -1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int X = X0 + (q & 1), Y = Y0 + (q >> 1);
+        Rlo[q] = 1 << 20; Rhi[q] = -1;
+        if (X + h < n && Y + h < n) {
+            const uint32_t bnd = p.band[(size_t)(Y + h) * n + (X + h)];
+            Rlo[q] = (int)(bnd & 0xffffu);
+            Rhi[q] = (int)(bnd >> 16);
+        }
+        RloMin = min(RloMin, Rlo[q]);
+        RhiMax = max(RhiMax, Rhi[q]);
     }
-    const float Xf = (float)X, Yf = (float)Y;
+    const float Xc = (float)X0 + 0.5f, Yc = (float)Y0 + 0.5f;
 
     KbCoef kb;
-    kb.W = p.W; kb.beta = p.beta; kb.terms = p.kb_terms; kb.poly = p.kb_poly;
-
-    float2 acc[CPB];
+    kb.W = p.W; kb.invW = 1.0f / p.W; kb.beta = p.beta;
 #pragma unroll
-    for (int c = 0; c < CPB; ++c) acc[c] = make_float2(0.f, 0.f);
+    for (int t = 0; t < kKbPolyTerms; ++t) kb.poly[t] = p.kb_poly[t];
+
+    float2 acc[4][CPB];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int c = 0; c < CPB; ++c) acc[q][c] = make_float2(0.f, 0.f);
 
     const unsigned char *in_bytes = reinterpret_cast<const unsigned char *>(p.nudata)
         + (size_t)z * (size_t)p.in_slice_stride * (HALF ? sizeof(__half2) : sizeof(float2));
@@ -181,9 +167,9 @@ grid_tile_kernel(const GridParams p)
     const float bx_lo = (float)x0 - p.W - eps, bx_hi = (float)(x0 + kTile - 1) + p.W + eps;
     const float by_lo = (float)y0 - p.W - eps, by_hi = (float)(y0 + kTile - 1) + p.W + eps;
 
-    for (int chunk0 = 0; chunk0 < p.npe; chunk0 += kGridThreads) {
-        // ---- 1. clip: one lane per spoke -------------------------------------------------
-        const int pe = chunk0 + tid;
+    for (int chunk0 = 0; chunk0 < p.npe; chunk0 += 64) {
+        // ---- 1. clip: one lane per spoke; survivors are visited in acquisition order ---------
+        const int pe = chunk0 + lane;
         bool accept = false;
         float ct = 0.f, st = 0.f;
         int rlo = 0, rhi = -1;
@@ -205,102 +191,117 @@ grid_tile_kernel(const GridParams p)
                 }
             }
         }
-        const unsigned long long m = __ballot(accept);
-        if (lane == 0) s_wcnt[wave] = __popcll(m);
-        __syncthreads();
-        int base = 0, total = 0;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const int cnt = s_wcnt[w];
-            if (w < wave) base += cnt;
-            total += cnt;
-        }
-        if (accept) {
-            SpokeEntry e;
-            e.ct = ct; e.st = st; e.pe = pe; e.rlo = rlo; e.rhi = rhi; e.pad0 = e.pad1 = e.pad2 = 0;
-            s_list[base + __popcll(m & ((1ull << lane) - 1ull))] = e;
-        }
-        __syncthreads();
+        unsigned long long todo = __ballot(accept);
 
-        for (int b0 = 0; b0 < total; b0 += kBatchSpokes) {
-            const int nsp = min(kBatchSpokes, total - b0);
-            // ---- 2. stage: lanes run along the spoke ----------------------------------
-            for (int sidx = tid / C::LPS; sidx < nsp; sidx += C::SPI) {
-                const SpokeEntry e = s_list[b0 + sidx];
-                const int k = tid % C::LPS;
-                const int r = e.rlo + k;
-                if (k == 0) {
-                    BatchSpoke bs;
-                    bs.ct = e.ct; bs.st = e.st;
-                    bs.reach = (float)CW * (fabsf(e.ct) + fabsf(e.st)) + 1e-3f;
-                    bs.use_x = fabsf(e.ct) >= fabsf(e.st);
-                    bs.inv = 1.0f / (bs.use_x ? e.ct : e.st);
-                    bs.rlo = e.rlo; bs.rhi = e.rhi; bs.pad = 0;
-                    s_sp[sidx] = bs;
+        while (todo) {
+            // ---- 2. stage up to NSP spokes: lanes run ALONG the spoke ---------------------
+            int sp_lane[C::NSP];
+            int nsp = 0;
+#pragma unroll
+            for (int s = 0; s < C::NSP; ++s) {
+                sp_lane[s] = -1;
+                if (todo) {
+                    sp_lane[s] = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1;
+                    nsp = s + 1;
                 }
-                if (r <= e.rhi) {
-                    const int rec = sidx * C::LPS + k;
-                    const float kx = (float)r * e.ct;                 // src/tron.cu:514-515
-                    const float ky = (float)r * e.st;
-                    const int bx = (int)floorf(kx) - CW + 1;
-                    const int by = (int)floorf(ky) - CW + 1;
-                    s_b[rec] = ((uint32_t)bx & 0xffffu) | ((uint32_t)by << 16);
+            }
+            if (p.debug < 2) {
 #pragma unroll
-                    for (int i = 0; i < C::NW; ++i) {
-                        s_wx[rec * C::NW + i] = kb_weight<KB>(kx - (float)(bx + i), kb);   // src/tron.cu:516
-                        s_wy[rec * C::NW + i] = kb_weight<KB>(ky - (float)(by + i), kb);
-                    }
-                    const int ridx = (r * p.nro) / n;                 // src/tron.cu:517 (truncating)
-                    const int ro = ridx + p.nro / 2;
-                    float sdc = 1.0f;
-                    if (p.apply_dcf)                                  // src/tron.cu:412
-                        sdc = p.dcf_a * fabsf((float)ro - (float)(p.nro / 2)) + p.dcf_b;
-                    const size_t sbase = ((size_t)p.nro * e.pe + ro) * p.nchan + c0;
+                for (int it = 0; it < (C::NSP * C::LPS) / 64; ++it) {
+                    const int s = it * (64 / C::LPS) + lane / C::LPS;    // staged spoke this lane works on
+                    const int src = C::LPS == 32 ? (lane < 32 ? sp_lane[(it * 2) % C::NSP] : sp_lane[(it * 2 + 1) % C::NSP]) : sp_lane[it % C::NSP];
+                    const int srcl = src < 0 ? 0 : src;
+                    const float sct = __shfl(ct, srcl), sst = __shfl(st, srcl);
+                    const int srlo = __shfl(rlo, srcl), srhi = __shfl(rhi, srcl);
+                    const int k = lane % C::LPS;
+                    const int r = srlo + k;
+                    if (src >= 0 && r <= srhi) {
+                        const int rec = s * C::LPS + k;
+                        const float kx = (float)r * sct;              // src/tron.cu:514-515
+                        const float ky = (float)r * sst;
+                        const int bx = (int)floorf(kx) - CW + 1;
+                        const int by = (int)floorf(ky) - CW + 1;
+                        float *wxr = s_wx + rec * C::NWP, *wyr = s_wy + rec * C::NWP;
+                        wxr[0] = 0.f; wxr[C::NWP - 1] = 0.f;
+                        wyr[0] = 0.f; wyr[C::NWP - 1] = 0.f;
 #pragma unroll
-                    for (int c = 0; c < CPB; ++c) {
-                        float2 d = make_float2(0.f, 0.f);
-                        if (c < ncb) {
-                            d = load_sample<HALF>(in_bytes, sbase + c);
-                            d.x *= sdc; d.y *= sdc;                   // src/tron.cu:414
+                        for (int i = 0; i < C::NW; ++i) {
+                            wxr[1 + i] = kb_weight<KB>(kx - (float)(bx + i), kb);   // src/tron.cu:516
+                            wyr[1 + i] = kb_weight<KB>(ky - (float)(by + i), kb);
                         }
-                        s_d[rec * CPB + c] = d;
+                        const int ridx = (r * p.nro) / n;             // src/tron.cu:517 (truncating)
+                        const int ro = ridx + p.nro / 2;
+                        float sdc = 1.0f;
+                        if (p.apply_dcf)                              // src/tron.cu:412
+                            sdc = p.dcf_a * fabsf((float)ro - (float)(p.nro / 2)) + p.dcf_b;
+                        const size_t sbase = ((size_t)p.nro * (chunk0 + src) + ro) * p.nchan + c0;
+#pragma unroll
+                        for (int c = 0; c < CPB; ++c) {
+                            float2 d = make_float2(0.f, 0.f);
+                            if (c < ncb) {
+                                d = load_sample<HALF>(in_bytes, sbase + c);
+                                d.x *= sdc; d.y *= sdc;               // src/tron.cu:414
+                            }
+                            s_d[rec * CPB + c] = d;
+                        }
                     }
                 }
             }
             __syncthreads();
-            // ---- 3. gather: one thread per Cartesian point ----------------------------
-            for (int s = 0; s < nsp; ++s) {
-                const BatchSpoke bs = s_sp[s];
-                const float q = Yf * bs.ct - Xf * bs.st;
-                if (fabsf(q) < bs.reach) {
-                    const float P = bs.use_x ? Xf : Yf;
-                    const float ta = (P - (float)CW - eps) * bs.inv;
-                    const float tb = (P + (float)CW + eps) * bs.inv;
-                    const int ca = max((int)ceilf(fminf(ta, tb)), bs.rlo);
-                    const int cb = min((int)floorf(fmaxf(ta, tb)), bs.rhi);
+            // ---- 3. gather: each lane collects, for its 2x2 points, the staged samples whose
+            //         footprint covers them, in the reference's summation order ---------------
+            for (int s = 0; s < nsp && p.debug < 1; ++s) {
+                const int src = sp_lane[s];
+                const float sct = __shfl(ct, src), sst = __shfl(st, src);     // wave-uniform
+                const int srlo = __shfl(rlo, src), srhi = __shfl(rhi, src);
+                const float aco = fabsf(sct), asi = fabsf(sst);
+                const float reach = ((float)CW + 0.5f) * (aco + asi) + 1e-3f;
+                const float qd = Yc * sct - Xc * sst;                  // distance of the micro-tile centre from the spoke
+                if (fabsf(qd) < reach) {
+                    const bool use_x = aco >= asi;
+                    const float inv = 1.0f / (use_x ? sct : sst);
+                    const float P0 = use_x ? (float)X0 : (float)Y0;
+                    const float ta = (P0 - (float)CW - eps) * inv;
+                    const float tb = (P0 + 1.0f + (float)CW + eps) * inv;
+                    const int ca = max((int)ceilf(fminf(ta, tb)), srlo);
+                    const int cb = min((int)floorf(fmaxf(ta, tb)), srhi);
                     // reference order: aligned radii ascending, then anti-aligned ascending
                     // (src/tron.cu:512,521); r = 0 is met twice when Rlo == 0, as there.
 #pragma unroll
                     for (int pass = 0; pass < 2; ++pass) {
-                        const int a = pass == 0 ? max(ca, Rlo) : max(ca, -Rhi);
-                        const int b = pass == 0 ? min(cb, Rhi) : min(cb, -Rlo);
+                        const int a = pass == 0 ? max(ca, RloMin) : max(ca, -RhiMax);
+                        const int b = pass == 0 ? min(cb, RhiMax) : min(cb, -RloMin);
                         for (int r = a; r <= b; ++r) {
-                            const int rec = s * C::LPS + (r - bs.rlo);
-                            const uint32_t bb = s_b[rec];
-                            const int i = X - (int)(short)(bb & 0xffffu);
-                            const int j = Y - (int)(short)(bb >> 16);
-                            if ((unsigned)i < (unsigned)C::NW && (unsigned)j < (unsigned)C::NW) {
-                                const float wgt = s_wx[rec * C::NW + i] * s_wy[rec * C::NW + j];
-                                if (wgt > 0.f) {                      // src/tron.cu:518
+                            const float kx = (float)r * sct;
+                            const float ky = (float)r * sst;
+                            const int i0 = X0 - ((int)floorf(kx) - CW + 1);   // footprint column of point X0
+                            const int j0 = Y0 - ((int)floorf(ky) - CW + 1);
+                            if (i0 >= -1 && i0 < C::NW && j0 >= -1 && j0 < C::NW) {
+                                const int rec = s * C::LPS + (r - srlo);
+                                const float *wxr = s_wx + rec * C::NWP + (i0 + 1);
+                                const float *wyr = s_wy + rec * C::NWP + (j0 + 1);
+                                const float wxa = wxr[0], wxb = wxr[1];
+                                const float wya = wyr[0], wyb = wyr[1];
+                                const int ar = r < 0 ? -r : r;
+                                float wq[4];
+                                wq[0] = wxa * wya; wq[1] = wxb * wya; wq[2] = wxa * wyb; wq[3] = wxb * wyb;   // src/tron.cu:516
 #pragma unroll
-                                    for (int c = 0; c < CPB; ++c) {
-                                        const float2 d = s_d[rec * CPB + c];
+                                for (int q = 0; q < 4; ++q)
+                                    if (!(wq[q] > 0.f && ar >= Rlo[q] && ar <= Rhi[q])) wq[q] = 0.f;       // src/tron.cu:512,518
+#pragma unroll
+                                for (int c = 0; c < CPB; ++c) {
+                                    const float2 d = s_d[rec * CPB + c];
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q) {
                                         if (KB == TRON_KB_EXACT) {
-                                            acc[c].x += d.x * wgt;    // src/tron.cu:519, unfused
-                                            acc[c].y += d.y * wgt;
+                                            if (wq[q] > 0.f) {
+                                                acc[q][c].x += d.x * wq[q];          // src/tron.cu:519, unfused
+                                                acc[q][c].y += d.y * wq[q];
+                                            }
                                         } else {
-                                            acc[c].x = fmaf(d.x, wgt, acc[c].x);
-                                            acc[c].y = fmaf(d.y, wgt, acc[c].y);
+                                            acc[q][c].x = fmaf(d.x, wq[q], acc[q][c].x);
+                                            acc[q][c].y = fmaf(d.y, wq[q], acc[q][c].y);
                                         }
                                     }
                                 }
@@ -313,21 +314,25 @@ grid_tile_kernel(const GridParams p)
         }
     }
 
-    if (inside) {
-        int row = Y + h, col = X + h;
-        if (p.out_shift) {      // both fftshifts of src/tron.cu:631 folded into the store index
-            row = Y < 0 ? Y + n : Y;
-            col = X < 0 ? X + n : X;
-        }
-        float2 *out = p.udata + (size_t)z * p.out_z + ((size_t)row * n + col) * p.out_p;
 #pragma unroll
-        for (int c = 0; c < CPB; ++c)
-            if (c < ncb) {
-                float2 v;
-                v.x = acc[c].x * p.scale;                              // src/tron.cu:532-534
-                v.y = acc[c].y * p.scale;
-                out[(size_t)(c0 + c) * p.out_c] = v;
+    for (int q = 0; q < 4; ++q) {
+        const int X = X0 + (q & 1), Y = Y0 + (q >> 1);
+        if (X + h < n && Y + h < n) {
+            int row = Y + h, col = X + h;
+            if (p.out_shift) {      // both fftshifts of src/tron.cu:631 folded into the store index
+                row = Y < 0 ? Y + n : Y;
+                col = X < 0 ? X + n : X;
             }
+            float2 *out = p.udata + (size_t)z * p.out_z + ((size_t)row * n + col) * p.out_p;
+#pragma unroll
+            for (int c = 0; c < CPB; ++c)
+                if (c < ncb) {
+                    float2 v;
+                    v.x = acc[q][c].x * p.scale;                       // src/tron.cu:532-534
+                    v.y = acc[q][c].y * p.scale;
+                    out[(size_t)(c0 + c) * p.out_c] = v;
+                }
+        }
     }
 }
 
@@ -340,9 +345,6 @@ static hipError_t launch_grid_kb(const GridParams &p, int kb_mode, int half_in, 
 #define TRON_LAUNCH(KBM, HF)                                                                   \
     do {                                                                                       \
         auto kern = grid_tile_kernel<CPB, CW, KBM, HF>;                                        \
-        hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),              \
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        if (e_ != hipSuccess) return e_;                                                       \
         hipLaunchKernelGGL(kern, grid, dim3(kGridThreads), lds, s, p);                         \
     } while (0)
     if (kb_mode == TRON_KB_EXACT) { if (half_in) TRON_LAUNCH(TRON_KB_EXACT, true); else TRON_LAUNCH(TRON_KB_EXACT, false); }
@@ -463,7 +465,9 @@ __global__ void __launch_bounds__(256) degrid_kernel(const DegridParams p)
     const int pe = id / p.nro;
     const int ro = id % p.nro;
     KbCoef kb;
-    kb.W = p.W; kb.beta = p.beta; kb.terms = p.kb_terms; kb.poly = p.kb_poly;
+    kb.W = p.W; kb.invW = 1.0f / p.W; kb.beta = p.beta;
+#pragma unroll
+    for (int t = 0; t < kKbPolyTerms; ++t) kb.poly[t] = p.kb_poly[t];
     const float W = p.W;
     const float R = (float)ro / (float)p.nro - 0.5f;                  // src/tron.cu:554
     const float2 cs = p.trig[pe];

@@ -87,8 +87,8 @@ struct tron_plan {
     int ntiles = 0, tiles_per_row = 0;
     // kernel constants
     float beta = 0, dcf_a = 0, dcf_b = 0, scale = 0;
-    int kb_terms = 0;
-    float kb_poly[kKbPolyMax];
+    double kb_poly_err = 0;        // max relative error of the fast Kaiser-Bessel polynomial
+    float kb_poly[kKbPolyTerms];
     // work buffers
     float2 *d_grid = nullptr;      // chunk * nchan * nxos^2
     void *d_stage_in = nullptr;    // host-API staging
@@ -207,8 +207,8 @@ void fill_grid_consts(const tron_plan *p, GridParams &g)
     g.scale = p->scale;
     g.dcf_a = p->dcf_a;
     g.dcf_b = p->dcf_b;
-    g.kb_terms = p->kb_terms;
     memcpy(g.kb_poly, p->kb_poly, sizeof(g.kb_poly));
+    if (const char *dbg = getenv("TRON_DEBUG_SKIP")) g.debug = atoi(dbg);
 }
 
 // Adjoint for slices [zfirst, zfirst+zcount).  d_in_z0 points at the first spoke of slice
@@ -294,7 +294,6 @@ int forward_run(tron_plan *p, void *d_out, const void *d_in, int nimg)
         g.nimg = ck;
         g.W = p->cfg.kernwidth;
         g.beta = p->beta;
-        g.kb_terms = p->kb_terms;
         memcpy(g.kb_poly, p->kb_poly, sizeof(g.kb_poly));
         {
             StageTimer t(p, STAGE_DEGRID);
@@ -364,15 +363,17 @@ extern "C" int tron_plan_create(tron_plan **out, const tron_config *cfg, const t
     p->nchan = d.nc * d.nt;
     p->beta = kb_beta(cfg->kernwidth);
     p->kb_mode = cfg->kb_mode == TRON_KB_FAST ? TRON_KB_FAST : TRON_KB_EXACT;
-    p->kb_terms = kb_taylor(cfg->kernwidth, p->kb_poly, kKbPolyMax);
-    if (p->kb_mode == TRON_KB_FAST && p->kb_terms == 0) p->kb_mode = TRON_KB_EXACT;   // series too long: stay exact
+    p->kb_poly_err = kb_poly_fit(cfg->kernwidth, p->kb_poly, kKbPolyTerms);
+    if (p->kb_mode == TRON_KB_FAST && !(p->kb_poly_err < 1e-7)) p->kb_mode = TRON_KB_EXACT;   // polynomial too short for this beta: stay exact
     dcf_constants(d.nro, d.npe1work, &p->dcf_a, &p->dcf_b);
     p->scale = grid_scale(d.nxos, d.npe1work);
 
     const size_t n2 = (size_t)d.nxos * d.nxos;
     const size_t per_unit = (size_t)p->nchan * n2 * sizeof(float2);
     int units = cfg->adjoint ? d.nz : 1;
-    int chunk = cfg->chunk_slices > 0 ? cfg->chunk_slices : (int)std::max<size_t>(1, ((size_t)128 << 20) / per_unit);
+    // The heaviest tile (the k-space centre, crossed by every spoke) is one wave's serial work, so a
+    // launch needs enough slices in flight to cover that critical path: batch up to 1 GiB of grid.
+    int chunk = cfg->chunk_slices > 0 ? cfg->chunk_slices : (int)std::max<size_t>(1, ((size_t)1 << 30) / per_unit);
     if (const char *env = getenv("TRON_CHUNK_SLICES")) chunk = std::max(1, atoi(env));
     p->chunk = std::max(1, std::min(chunk, std::max(units, 1)));
     if (!cfg->adjoint) p->chunk = std::max(1, chunk);
@@ -413,6 +414,7 @@ extern "C" int tron_plan_create(tron_plan **out, const tron_config *cfg, const t
         printf("tronhip: device %d, %s, nchan %d, grid %d^2 -> image %d^2, %d spokes/image, chunk %d, KB %s\n",
                cfg->device, cfg->adjoint ? "adjoint" : "forward", p->nchan, d.nxos, d.nx, d.npe1work, p->chunk,
                p->kb_mode == TRON_KB_FAST ? "fast" : "exact");
+        printf("tronhip: fast Kaiser-Bessel polynomial max relative error %.2e\n", p->kb_poly_err);
     }
     *out = p;
     return TRON_OK;
@@ -583,7 +585,6 @@ extern "C" int tron_degridradial2d(tron_plan *p, void *d_nudata, const void *d_u
     g.nimg = 1;
     g.W = p->cfg.kernwidth;
     g.beta = p->beta;
-    g.kb_terms = p->kb_terms;
     memcpy(g.kb_poly, p->kb_poly, sizeof(g.kb_poly));
     StageTimer t(p, STAGE_DEGRID);
     HIP_TRY(launch_degrid(g, p->kb_mode, p->stream));
