@@ -1,0 +1,417 @@
+// Gridding kernel of the TRON_KB_FAST path: sample records are BINNED by Cartesian cell inside the
+// workgroup, so every point walks exactly the samples whose Kaiser-Bessel footprint covers it.
+//
+// Same arithmetic per (sample, point) pair as grid_tile_kernel / the reference's gridradial2d
+// (src/tron.cu:465-536: weights :516, band :498-502,:512, r = 0 twice :512/:521, scale :532) but
+// the pairs are found by a counting sort instead of a per-spoke search, and summed cell by cell
+// rather than spoke by spoke -- so results agree with the reference to fp32 summation-order noise
+// (~1e-7), not bit for bit.  That is why this kernel serves TRON_KB_FAST only; TRON_KB_EXACT keeps
+// the order-preserving gather.
+//
+// One workgroup = 4 waves = one 32x32 tile; each thread owns 2x2 points.  Per batch of <= NREC records:
+//   A  stage   lanes run along the spoke: coalesced k-space read, DCF, 2x(2CW) weights once per
+//              sample; the sample's base cell gets a packed per-wave counter bumped with ONE
+//              integer LDS atomic (ds_add_rtn_u32: 6.6 cycles per wave instruction on MI355X,
+//              vs 194 for ds_add_f32), which returns the sample's rank in its (wave, cell) bucket;
+//   B  scan    exclusive prefix sum over the (32+2CW-1)^2 cells -> CSR row starts;
+//   C  place   record ids are written to their sorted slots: cell start + earlier waves' counts + rank
+//              (deterministic: each wave issues its atomics in program order);
+//   D  apply   a thread reads, for each of the 2CW+1 cell rows its 2x2 points can see, ONE contiguous
+//              id range, and accumulates weight pair x weight pair x sample for all coils in registers.
+// No floating-point atomics anywhere; the output is written once, coil-planar, in FFT-native order.
+#include "tron_device.h"
+
+namespace tron {
+
+constexpr int kBinTile = 32;
+constexpr int kBinThreads = 256;
+constexpr int kBinMaxSpokes = 512;   // accepted spokes kept per clip round
+
+template <int CPB, int CW>
+struct BinCfg {
+    static constexpr int NW = 2 * CW;
+    static constexpr int NWP = NW + 2;                       // weights padded with a zero each side
+    static constexpr int NCELL = kBinTile + 2 * CW - 1;      // base cells per dimension that can touch the tile
+    static constexpr int CELLW = NCELL + 1;                  // + sentinel column
+    static constexpr int NCELLS = NCELL * CELLW;
+    static constexpr int CPT = (NCELLS + kBinThreads - 1) / kBinThreads;   // cells per thread in the scan
+    // records per batch, sized so a workgroup stays near 48 KiB of LDS
+    static constexpr int REC_BYTES = 2 * NWP * 4 + CPB * 8 + 4 + 2 + 1;
+    static constexpr int NREC_RAW = (36 * 1024) / REC_BYTES;
+    static constexpr int NREC = NREC_RAW >= 512 ? 512 : (NREC_RAW / 64) * 64;
+    static constexpr int SLOT = 64;                          // longest spoke segment through tile + halo
+};
+
+template <int CPB, int CW>
+struct BinLds {
+    using C = BinCfg<CPB, CW>;
+    int sp_pe[kBinMaxSpokes];
+    int sp_seg[kBinMaxSpokes];            // rlo (low 16, signed) | len << 16
+    int sp_start[kBinMaxSpokes + 1];      // exclusive scan of len
+    unsigned hist[C::NCELLS];             // 4 x 8-bit per-wave counters per cell
+    unsigned short start[C::NCELLS + 1];
+    unsigned short ids[C::NREC];
+    unsigned key[C::NREC];
+    unsigned char rank[C::NREC];
+    int wcnt[8];
+    float wx[C::NREC * C::NWP];
+    float wy[C::NREC * C::NWP];
+    float2 d[C::NREC * CPB];
+};
+
+template <int CPB, int CW, bool HALF>
+__global__ void __launch_bounds__(kBinThreads)
+grid_binned_kernel(const GridParams p)
+{
+    using C = BinCfg<CPB, CW>;
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    BinLds<CPB, CW> &L = *reinterpret_cast<BinLds<CPB, CW> *>(lds_raw);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int z = blockIdx.x % p.nslices;
+    const int tile = p.tile_order[blockIdx.x / p.nslices];
+    const int c0 = p.coil0 + blockIdx.y * CPB;
+    const int ncb = min(CPB, p.nchan - c0);
+    const int n = p.nxos;
+    const int h = n / 2;
+    const int rmax = n / 2 - 1;
+    if (tile < 0 || tile >= p.ntiles) {
+        if (threadIdx.x == 0) atomicOr(p.errflag, 128u);
+        return;
+    }
+
+    const int x0 = (tile % p.tiles_per_row) * kBinTile - h;     // tile origin, centred coordinates
+    const int y0 = (tile / p.tiles_per_row) * kBinTile - h;
+    const int mx = 2 * (lane & 15);                             // this thread's 2x2 points, tile-relative
+    const int my = 8 * wave + 2 * (lane >> 4);
+    const int X0 = x0 + mx, Y0 = y0 + my;
+    int Rlo[4], Rhi[4];                                         // radial band per point, src/tron.cu:498-502
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int X = X0 + (q & 1), Y = Y0 + (q >> 1);
+        Rlo[q] = 1 << 20; Rhi[q] = -1;
+        if (X + h < n && Y + h < n) {
+            const uint32_t bnd = p.band[(size_t)(Y + h) * n + (X + h)];
+            Rlo[q] = (int)(bnd & 0xffffu);
+            Rhi[q] = (int)(bnd >> 16);
+        }
+    }
+
+    KbCoef kb;
+    kb.W = p.W; kb.invW = 1.0f / p.W; kb.beta = p.beta;
+#pragma unroll
+    for (int t = 0; t < kKbPolyTerms; ++t) kb.poly[t] = p.kb_poly[t];
+
+    float2 acc[4][CPB];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int c = 0; c < CPB; ++c) acc[q][c] = make_float2(0.f, 0.f);
+
+    const unsigned char *in_bytes = reinterpret_cast<const unsigned char *>(p.nudata)
+        + (size_t)z * (size_t)p.in_slice_stride * (HALF ? sizeof(__half2) : sizeof(float2));
+    const float2 *trig = p.trig + (size_t)z * p.trig_slice_stride;
+
+    const float eps = 0.01f;
+    const float bx_lo = (float)x0 - p.W - eps, bx_hi = (float)(x0 + kBinTile - 1) + p.W + eps;
+    const float by_lo = (float)y0 - p.W - eps, by_hi = (float)(y0 + kBinTile - 1) + p.W + eps;
+    const int cx0 = x0 - CW, cy0 = y0 - CW;                     // base cell (0,0) of the histogram
+
+    for (int round0 = 0; round0 < p.npe && p.debug < 4; round0 += kBinMaxSpokes) {
+        // ---- clip: one thread per spoke, accepted spokes compacted in acquisition order ---------
+        if (tid == 0) L.sp_start[0] = 0;
+        int nacc = 0;                                           // accepted so far in this round (uniform)
+        for (int chunk0 = round0; chunk0 < min(p.npe, round0 + kBinMaxSpokes); chunk0 += kBinThreads) {
+            const int pe = chunk0 + tid;
+            bool accept = false;
+            int rlo = 0, len = 0;
+            if (pe < p.npe && pe < round0 + kBinMaxSpokes) {
+                const float2 cs = trig[pe];
+                const float ic = safe_rcp(cs.x), is = safe_rcp(cs.y);
+                const float xa = bx_lo * ic, xb = bx_hi * ic;
+                const float ya = by_lo * is, yb = by_hi * is;
+                const float lo = fmaxf(fmaxf(fminf(xa, xb), fminf(ya, yb)), -(float)rmax);
+                const float hi = fminf(fminf(fmaxf(xa, xb), fmaxf(ya, yb)), (float)rmax);
+                if (lo <= hi) {
+                    rlo = (int)ceilf(lo);
+                    int rhi = (int)floorf(hi);
+                    if (rhi - rlo + 1 > C::SLOT) {              // cannot happen for a 32x32 tile with W <= 4
+                        atomicOr(p.errflag, 2u);
+                        rhi = rlo + C::SLOT - 1;
+                    }
+                    len = rhi - rlo + 1;
+                    accept = len > 0;
+                }
+            }
+            const unsigned long long m = __ballot(accept);
+            if (lane == 0) L.wcnt[wave] = __popcll(m);
+            __syncthreads();
+            int base = nacc, total = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const int cnt = L.wcnt[w];
+                if (w < wave) base += cnt;
+                total += cnt;
+            }
+            if (accept) {
+                const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+                L.sp_pe[slot] = pe;
+                L.sp_seg[slot] = (rlo & 0xffff) | (len << 16);
+            }
+            nacc += total;
+            __syncthreads();
+        }
+        // exclusive scan of the segment lengths (nacc <= 512: two elements per thread)
+        {
+            const int i0 = 2 * tid, i1 = 2 * tid + 1;
+            const int l0 = i0 < nacc ? (L.sp_seg[i0] >> 16) : 0;
+            const int l1 = i1 < nacc ? (L.sp_seg[i1] >> 16) : 0;
+            int v = l0 + l1;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(v, o);
+                if (lane >= o) v += t;
+            }
+            if (lane == 63) L.wcnt[4 + wave] = v;
+            __syncthreads();
+            int wbase = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+                if (w < wave) wbase += L.wcnt[4 + w];
+            const int excl = wbase + v - (l0 + l1);
+            if (i0 < nacc) L.sp_start[i0 + 1] = excl + l0;
+            if (i1 < nacc) L.sp_start[i1 + 1] = excl + l0 + l1;
+            __syncthreads();
+        }
+
+        int sp0 = 0;
+        while (sp0 < nacc && p.debug < 3) {
+            // ---- batch = the longest run of spokes whose records fit in NREC (uniform) ----------
+            const int rec_base = L.sp_start[sp0];
+            int sp1 = sp0 + 1;
+            while (sp1 < nacc && L.sp_start[sp1 + 1] - rec_base <= C::NREC) ++sp1;
+            const int nrec = L.sp_start[sp1] - rec_base;
+
+            for (int c = tid; c < C::NCELLS; c += kBinThreads) L.hist[c] = 0u;
+            __syncthreads();
+
+            // ---- A. stage + count: wave w takes spokes sp0+w, sp0+w+4, ... ------------------------
+            for (int sp = sp0 + wave; sp < sp1 && p.debug < 2; sp += 4) {
+                const int pe = L.sp_pe[sp];
+                const int seg = L.sp_seg[sp];
+                const int rlo = (int)(short)(seg & 0xffff), len = seg >> 16;
+                if (pe < 0 || pe >= p.npe || len < 1 || len > C::SLOT || rlo < -rmax || rlo + len - 1 > rmax) {
+                    atomicOr(p.errflag, 64u);
+                    continue;
+                }
+                if (lane < len) {
+                    const float2 cs = trig[pe];
+                    const int r = rlo + lane;
+                    const int rec = L.sp_start[sp] - rec_base + lane;
+                    if (rec < 0 || rec >= C::NREC) { atomicOr(p.errflag, 32u); continue; }
+                    const float kx = (float)r * cs.x;                 // src/tron.cu:514-515
+                    const float ky = (float)r * cs.y;
+                    const int fx = (int)floorf(kx), fy = (int)floorf(ky);
+                    const int bx = fx - CW + 1, by = fy - CW + 1;
+                    float *wxr = L.wx + rec * C::NWP, *wyr = L.wy + rec * C::NWP;
+                    wxr[0] = 0.f; wxr[C::NWP - 1] = 0.f;
+                    wyr[0] = 0.f; wyr[C::NWP - 1] = 0.f;
+#pragma unroll
+                    for (int i = 0; i < C::NW; ++i) {
+                        wxr[1 + i] = kb_weight<TRON_KB_FAST>(kx - (float)(bx + i), kb);   // src/tron.cu:516
+                        wyr[1 + i] = kb_weight<TRON_KB_FAST>(ky - (float)(by + i), kb);
+                    }
+                    const int ridx = (r * p.nro) / n;                 // src/tron.cu:517
+                    const int ro = ridx + p.nro / 2;
+                    float sdc = 1.0f;
+                    if (p.apply_dcf) sdc = p.dcf_a * fabsf((float)ro - (float)(p.nro / 2)) + p.dcf_b;   // src/tron.cu:412
+                    const size_t sbase = ((size_t)p.nro * pe + ro) * p.nchan + c0;
+#pragma unroll
+                    for (int c = 0; c < CPB; ++c) {
+                        float2 d = make_float2(0.f, 0.f);
+                        if (c < ncb) {
+                            d = load_sample<HALF>(in_bytes, sbase + c);
+                            d.x *= sdc; d.y *= sdc;
+                        }
+                        L.d[rec * CPB + c] = d;
+                    }
+                    const int fxrel = fx - cx0, fyrel = fy - cy0;
+                    const bool valid = (unsigned)fxrel < (unsigned)C::NCELL && (unsigned)fyrel < (unsigned)C::NCELL;
+                    const int ar = r < 0 ? -r : r;
+                    unsigned key = (unsigned)(fxrel & 63) | ((unsigned)(fyrel & 63) << 6) | ((unsigned)ar << 12)
+                                   | ((unsigned)wave << 26) | (valid ? 1u << 28 : 0u) | (r == 0 ? 1u << 29 : 0u);
+                    L.key[rec] = key;
+                    if (valid) {
+                        const unsigned old = atomicAdd(&L.hist[fyrel * C::CELLW + fxrel], 1u << (8 * wave));
+                        const unsigned rk = (old >> (8 * wave)) & 0xffu;
+                        if (rk == 0xffu) atomicOr(p.errflag, 4u);
+                        L.rank[rec] = (unsigned char)rk;
+                    }
+                }
+            }
+            __syncthreads();
+
+            // ---- B. exclusive scan over cells ------------------------------------------------
+            {
+                int cnt[C::CPT];
+                int tsum = 0;
+#pragma unroll
+                for (int k = 0; k < C::CPT; ++k) {
+                    const int c = tid * C::CPT + k;
+                    unsigned hv = c < C::NCELLS ? L.hist[c] : 0u;
+                    cnt[k] = (int)((hv & 0xff) + ((hv >> 8) & 0xff) + ((hv >> 16) & 0xff) + (hv >> 24));
+                    tsum += cnt[k];
+                }
+                int v = tsum;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int t = __shfl_up(v, o);
+                    if (lane >= o) v += t;
+                }
+                if (lane == 63) L.wcnt[wave] = v;
+                __syncthreads();
+                int run = v - tsum;
+#pragma unroll
+                for (int w = 0; w < 4; ++w)
+                    if (w < wave) run += L.wcnt[w];
+#pragma unroll
+                for (int k = 0; k < C::CPT; ++k) {
+                    const int c = tid * C::CPT + k;
+                    if (c <= C::NCELLS) L.start[c] = (unsigned short)run;
+                    run += cnt[k];
+                }
+            }
+            __syncthreads();
+
+            // ---- C. place record ids in cell order ---------------------------------------------
+            for (int rec = tid; rec < nrec; rec += kBinThreads) {
+                const unsigned key = L.key[rec];
+                if (key & (1u << 28)) {
+                    const int cell = (int)((key >> 6) & 63) * C::CELLW + (int)(key & 63);
+                    const unsigned hv = L.hist[cell];
+                    const int w = (key >> 26) & 3;
+                    const unsigned below = hv & ((1u << (8 * w)) - 1u);
+                    const int wb = (int)((below & 0xff) + ((below >> 8) & 0xff) + ((below >> 16) & 0xff));
+                    const int pos = L.start[cell] + wb + L.rank[rec];
+                    if (pos >= C::NREC) { atomicOr(p.errflag, 8u); continue; }
+                    L.ids[pos] = (unsigned short)rec;
+                }
+            }
+            __syncthreads();
+
+            // ---- D. apply: each thread walks the cell rows its 2x2 points can see ----------------
+            if (p.debug < 1) {
+#pragma unroll 1
+                for (int dy = 0; dy <= 2 * CW; ++dy) {
+                    const int rowbase = (my + dy) * C::CELLW + mx;
+                    const int kbeg = L.start[rowbase];
+                    const int kend = L.start[rowbase + 2 * CW + 1];
+                    const int jp = 2 * CW - dy;                        // padded wy index for row Y0 (Y0+1 uses jp+1)
+                    for (int k = kbeg; k < kend; ++k) {
+                        const int id = L.ids[k];
+                        if (id >= C::NREC || k >= C::NREC) { atomicOr(p.errflag, 16u); break; }
+                        const unsigned key = L.key[id];
+                        const int ip = mx + 2 * CW - (int)(key & 63);  // padded wx index for column X0
+                        const float *wxr = L.wx + id * C::NWP + ip;
+                        const float *wyr = L.wy + id * C::NWP + jp;
+                        const float wxa = wxr[0], wxb = wxr[1];
+                        const float wya = wyr[0], wyb = wyr[1];
+                        const int ar = (int)((key >> 12) & 0x3fffu);
+                        const bool twice = (key >> 29) & 1u;
+                        float wq[4];
+                        wq[0] = wxa * wya; wq[1] = wxb * wya; wq[2] = wxa * wyb; wq[3] = wxb * wyb;   // src/tron.cu:516
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            if (!(ar >= Rlo[q] && ar <= Rhi[q])) wq[q] = 0.f;      // src/tron.cu:512,521
+                            if (twice && Rlo[q] == 0) wq[q] += wq[q];              // r = 0 sits in both loops
+                        }
+#pragma unroll
+                        for (int c = 0; c < CPB; ++c) {
+                            const float2 d = L.d[id * CPB + c];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                acc[q][c].x = fmaf(d.x, wq[q], acc[q][c].x);       // src/tron.cu:519
+                                acc[q][c].y = fmaf(d.y, wq[q], acc[q][c].y);
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            sp0 = sp1;
+        }
+    }
+
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int X = X0 + (q & 1), Y = Y0 + (q >> 1);
+        if (X + h < n && Y + h < n) {
+            int row = Y + h, col = X + h;
+            if (p.out_shift) {
+                row = Y < 0 ? Y + n : Y;
+                col = X < 0 ? X + n : X;
+            }
+            float2 *out = p.udata + (size_t)z * p.out_z + ((size_t)row * n + col) * p.out_p;
+#pragma unroll
+            for (int c = 0; c < CPB; ++c)
+                if (c < ncb) {
+                    float2 v;
+                    v.x = acc[q][c].x * p.scale;                       // src/tron.cu:532-534
+                    v.y = acc[q][c].y * p.scale;
+                    out[(size_t)(c0 + c) * p.out_c] = v;
+                }
+        }
+    }
+}
+
+template <int CPB, int CW>
+static hipError_t launch_binned_cpb(const GridParams &p, int half_in, hipStream_t s)
+{
+    const int tpr = (p.nxos + kBinTile - 1) / kBinTile;
+    GridParams q = p;
+    q.tiles_per_row = tpr;
+    q.ntiles = tpr * tpr;
+    const int chunks = (p.nchan - p.coil0 + CPB - 1) / CPB;
+    dim3 grid((unsigned)((size_t)q.ntiles * q.nslices), (unsigned)chunks);
+    const size_t lds = sizeof(BinLds<CPB, CW>);
+    static_assert(sizeof(BinLds<CPB, CW>) <= 64 * 1024, "binned gridding: LDS footprint must stay within the default 64 KiB");
+    if (half_in)
+        hipLaunchKernelGGL((grid_binned_kernel<CPB, CW, true>), grid, dim3(kBinThreads), lds, s, q);
+    else
+        hipLaunchKernelGGL((grid_binned_kernel<CPB, CW, false>), grid, dim3(kBinThreads), lds, s, q);
+    return hipGetLastError();
+}
+
+template <int CW>
+static hipError_t launch_binned_cw(const GridParams &p, int half_in, hipStream_t s)
+{
+    const int nc = p.nchan - p.coil0;
+    if (nc >= 8 && nc % 8 == 0) return launch_binned_cpb<8, CW>(p, half_in, s);
+    if (nc >= 4) return launch_binned_cpb<4, CW>(p, half_in, s);
+    if (nc >= 2) return launch_binned_cpb<2, CW>(p, half_in, s);
+    return launch_binned_cpb<1, CW>(p, half_in, s);
+}
+
+// p.tile_order must list the 32x32 tiles (see build_tile_order(nxos, 32, ...)).
+hipError_t launch_grid_binned(const GridParams &p, int half_in, hipStream_t s)
+{
+    const int cw = (int)ceilf(p.W);
+    switch (cw) {
+        case 1: return launch_binned_cw<1>(p, half_in, s);
+        case 2: return launch_binned_cw<2>(p, half_in, s);
+        case 3: return launch_binned_cw<3>(p, half_in, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+__global__ void warm_grid_binned_tu() {}
+
+hipError_t warm_grid_binned()   // see warm_kernels() in tron_kernels.hip
+{
+    hipLaunchKernelGGL(warm_grid_binned_tu, dim3(1), dim3(64), 0, nullptr);
+    return hipGetLastError();
+}
+
+}  // namespace tron

@@ -61,9 +61,14 @@ struct DegridParams {
 
 // launchers (tron_kernels.hip); kb_mode: TRON_KB_EXACT / TRON_KB_FAST; half_in: nudata is half2
 hipError_t launch_grid(const GridParams &p, int kb_mode, int half_in, hipStream_t s);
+// TRON_KB_FAST only; p.tile_order must list 32x32 tiles (tron_grid_binned.hip)
+hipError_t launch_grid_binned(const GridParams &p, int half_in, hipStream_t s);
+constexpr int kBinnedTile = 32;
 hipError_t launch_post(const PostParams &p, hipStream_t s);
 hipError_t launch_pre(const PreParams &p, hipStream_t s);
 hipError_t launch_degrid(const DegridParams &p, int kb_mode, hipStream_t s);
 size_t grid_lds_bytes(int cpb, int cw);
+hipError_t warm_kernels();       // force-load the code object of tron_kernels.hip
+hipError_t warm_grid_binned();   // ... and of tron_grid_binned.hip
 
 }  // namespace tron

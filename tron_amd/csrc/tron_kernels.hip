@@ -17,66 +17,9 @@
 //      radii ascending) is the reference's own, so TRON_KB_EXACT reproduces the reference's
 //      fp32 sums bit for bit.
 // Build with -ffp-contract=off: every fused multiply-add in this file is an explicit fmaf().
-#include "tron_internal.h"
-
-#include <hip/hip_fp16.h>
-
-#include "../../include/tron_hip.h"
+#include "tron_device.h"
 
 namespace tron {
-
-// ------------------------------------------------------------------------- Kaiser-Bessel
-
-// src/tron.cu:304-321, op for op: the coefficient literals are doubles, so both Horner chains
-// run in double (unfused) and are rounded to float; the quotient is an IEEE float division.
-__device__ __forceinline__ float besseli0_ref(const float x)
-{
-    if (x == 0.f) return 1.f;
-    float z = x * x;
-    float num = (z* (z* (z* (z* (z* (z* (z* (z* (z* (z* (z* (z* (z*
-        (z* 0.210580722890567e-22  + 0.380715242345326e-19 ) +
-        0.479440257548300e-16) + 0.435125971262668e-13 ) +
-        0.300931127112960e-10) + 0.160224679395361e-7  ) +
-        0.654858370096785e-5)  + 0.202591084143397e-2  ) +
-        0.463076284721000e0)   + 0.754337328948189e2   ) +
-        0.830792541809429e4)   + 0.571661130563785e6   ) +
-        0.216415572361227e8)   + 0.356644482244025e9   ) +
-        0.144048298227235e10);
-    float den = (z*(z*(z-0.307646912682801e4)+
-        0.347626332405882e7)-0.144048298227235e10);
-    return -num/den;
-}
-
-struct KbCoef {
-    float W, invW, beta;
-    float poly[kKbPolyTerms];
-};
-
-// src/tron.cu:338-349.  EXACT: the reference's expression tree.  FAST: (0.5/W)*I0(beta*sqrt(s)) is
-// an entire function of s = 1-(x/W)^2; a fixed-degree polynomial in s (Chebyshev-economised on
-// the host, coefficients held in scalar registers) replaces sqrt, the rational I0 and the division.
-template <int KB>
-__device__ __forceinline__ float kb_weight(const float x, const KbCoef &k)
-{
-    if (!(fabsf(x) < k.W)) return 0.0f;
-    if (KB == TRON_KB_EXACT) {
-        float r = x / k.W;
-        float f = sqrtf(1.0f - r * r);
-        return 0.5f * besseli0_ref(k.beta * f) / k.W;
-    } else {
-        float r = x * k.invW;
-        float s = fmaf(-r, r, 1.0f);
-        float acc = k.poly[0];
-#pragma unroll
-        for (int t = 1; t < kKbPolyTerms; ++t) acc = fmaf(acc, s, k.poly[t]);
-        return acc;
-    }
-}
-
-__device__ __forceinline__ float safe_rcp(float c)
-{
-    return fabsf(c) > 1e-12f ? 1.0f / c : copysignf(1e12f, c);
-}
 
 // ------------------------------------------------------------------------- gridding
 
@@ -92,17 +35,6 @@ size_t grid_lds_bytes(int cpb, int cw)
 {
     const size_t nwp = 2 * (size_t)cw + 2;
     return (size_t)kGridRecords * (2 * nwp * sizeof(float) + (size_t)cpb * sizeof(float2));
-}
-
-template <bool HALF>
-__device__ __forceinline__ float2 load_sample(const void *base, size_t idx)
-{
-    if (HALF) {
-        const __half2 h = reinterpret_cast<const __half2 *>(base)[idx];
-        return __half22float2(h);
-    } else {
-        return reinterpret_cast<const float2 *>(base)[idx];
-    }
 }
 
 // = precompensate + gridradial2d (src/tron.cu:405-416, 465-536) for a batch of slices.
@@ -513,6 +445,18 @@ hipError_t launch_degrid(const DegridParams &p, int kb_mode, hipStream_t s)
         if (kb_mode == TRON_KB_EXACT) hipLaunchKernelGGL((degrid_kernel<1, TRON_KB_EXACT>), grid, dim3(256), 0, s, p);
         else hipLaunchKernelGGL((degrid_kernel<1, TRON_KB_FAST>), grid, dim3(256), 0, s, p);
     }
+    return hipGetLastError();
+}
+
+// HIP loads a translation unit's code object lazily, at the first launch of one of its kernels, and
+// that upload is not ordered against a non-blocking stream: the first real launch can start before
+// its code is resident (seen on ROCm 7.2 as an intermittent "memory access fault ... address (nil)").
+// Each TU therefore exposes a no-op launch that tron_plan_create() runs and waits for once.
+__global__ void warm_kernels_tu() {}
+
+hipError_t warm_kernels()
+{
+    hipLaunchKernelGGL(warm_kernels_tu, dim3(1), dim3(64), 0, nullptr);
     return hipGetLastError();
 }
 

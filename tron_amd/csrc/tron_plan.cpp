@@ -82,6 +82,8 @@ struct tron_plan {
     size_t ntrig = 0;
     uint32_t *d_band = nullptr;
     int *d_tile_order = nullptr;
+    int *d_tile_order32 = nullptr;   // 32x32 tiles of the binned (fast) gridding kernel
+    bool binned = false;
     float *d_deapod = nullptr;
     unsigned int *d_errflag = nullptr;
     int ntiles = 0, tiles_per_row = 0;
@@ -99,6 +101,7 @@ struct tron_plan {
     std::map<std::pair<int, int>, FftPlan> fft;   // (batch, direction) -> plan
     // timing
     bool timing = false;
+    bool sync_each = false;        // TRON_SYNC_EACH=1: synchronise after every launch and name the failing stage
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[STAGE_COUNT];
     double ms_acc[STAGE_COUNT] = {0, 0, 0, 0, 0};
     uint64_t launches[STAGE_COUNT] = {0, 0, 0, 0, 0};
@@ -165,6 +168,9 @@ int get_fft(tron_plan *p, int batch, int inverse, FftPlan **out)
             HIP_TRY(hipMalloc(&f.work, f.work_bytes));
             FFT_TRY(rocfft_execution_info_set_work_buffer(f.info, f.work, f.work_bytes));
         }
+        // rocFFT builds its twiddle tables with a kernel on a stream of its own; make sure that has
+        // finished before the first execution on ours (a non-blocking stream does not wait for it)
+        HIP_TRY(hipDeviceSynchronize());
         it = p->fft.emplace(key, f).first;
     }
     *out = &it->second;
@@ -187,6 +193,15 @@ int upload(T **dptr, const void *host, size_t bytes)
 {
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(dptr), bytes ? bytes : 1));
     if (bytes) HIP_TRY(hipMemcpy(*dptr, host, bytes, hipMemcpyHostToDevice));
+    return TRON_OK;
+}
+
+int stage_check(tron_plan *p, const char *what)
+{
+    if (!p->sync_each) return TRON_OK;
+    hipError_t e = hipStreamSynchronize(p->stream);
+    if (e != hipSuccess) return fail(TRON_ERR_HIP, "stage '%s' failed: %s", what, hipGetErrorString(e));
+    fprintf(stderr, "[tronhip] stage %s ok\n", what);
     return TRON_OK;
 }
 
@@ -237,10 +252,18 @@ int adjoint_run(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, int 
         g.out_shift = 1;
         {
             StageTimer t(p, STAGE_GRID);
-            HIP_TRY(launch_grid(g, p->kb_mode, p->cfg.input_half, p->stream));
+            if (p->binned) {
+                g.tile_order = p->d_tile_order32;
+                HIP_TRY(launch_grid_binned(g, p->cfg.input_half, p->stream));
+            } else {
+                HIP_TRY(launch_grid(g, p->kb_mode, p->cfg.input_half, p->stream));
+            }
         }
-        int rc = run_fft(p, p->d_grid, cz * p->nchan, 1);
+        int rc = stage_check(p, "grid");
         if (rc) return rc;
+        rc = run_fft(p, p->d_grid, cz * p->nchan, 1);
+        if (rc) return rc;
+        if ((rc = stage_check(p, "fft"))) return rc;
         PostParams q;
         q.fft = p->d_grid;
         q.out = static_cast<float2 *>(d_out) + (size_t)z0 * d.nx * d.nx * (combine ? 1 : p->nchan);
@@ -250,10 +273,11 @@ int adjoint_run(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, int 
         q.nchan = p->nchan;
         q.nslices = cz;
         q.combine = combine;
-        {
+        if (g.debug != 5) {
             StageTimer t(p, STAGE_POST);
             HIP_TRY(launch_post(q, p->stream));
         }
+        if ((rc = stage_check(p, "post"))) return rc;
     }
     return TRON_OK;
 }
@@ -356,6 +380,10 @@ extern "C" int tron_plan_create(tron_plan **out, const tron_config *cfg, const t
         return fail(TRON_ERR_HIP, "device %d requested but %d HIP device(s) present", cfg->device, ndev);
     HIP_TRY(hipSetDevice(cfg->device));
     std::call_once(g_fft_once, [] { rocfft_setup(); });
+    // make every code object resident before anything is queued on a non-blocking stream
+    HIP_TRY(warm_kernels());
+    HIP_TRY(warm_grid_binned());
+    HIP_TRY(hipDeviceSynchronize());
 
     tron_plan *p = new tron_plan();
     p->cfg = *cfg;
@@ -398,6 +426,10 @@ extern "C" int tron_plan_create(tron_plan **out, const tron_config *cfg, const t
         p->tiles_per_row = (d.nxos + kTile - 1) / kTile;
         p->ntiles = (int)order.size();
         if ((rc = upload(&p->d_tile_order, order.data(), order.size() * sizeof(int)))) return bail(rc);
+        build_tile_order(d.nxos, kBinnedTile, order);
+        if ((rc = upload(&p->d_tile_order32, order.data(), order.size() * sizeof(int)))) return bail(rc);
+        p->binned = p->kb_mode == TRON_KB_FAST && cfg->kernwidth <= 3.f;
+        if (const char *gk = getenv("TRON_GRID_KERNEL")) p->binned = p->binned && strcmp(gk, "gather") != 0;
         std::vector<float> dea((size_t)d.nx * d.nx);
         build_deapod_table(d.nx, cfg->kernwidth, cfg->gridos, dea.data());        // src/tron.cu:635
         if ((rc = upload(&p->d_deapod, dea.data(), dea.size() * sizeof(float)))) return bail(rc);
@@ -416,6 +448,7 @@ extern "C" int tron_plan_create(tron_plan **out, const tron_config *cfg, const t
                p->kb_mode == TRON_KB_FAST ? "fast" : "exact");
         printf("tronhip: fast Kaiser-Bessel polynomial max relative error %.2e\n", p->kb_poly_err);
     }
+    if (const char *se = getenv("TRON_SYNC_EACH")) p->sync_each = atoi(se) != 0;
     *out = p;
     return TRON_OK;
 }
@@ -435,6 +468,7 @@ extern "C" int tron_plan_destroy(tron_plan *p)
     hipFree(p->d_trig);
     hipFree(p->d_band);
     hipFree(p->d_tile_order);
+    hipFree(p->d_tile_order32);
     hipFree(p->d_deapod);
     hipFree(p->d_errflag);
     hipFree(p->d_grid);
@@ -559,7 +593,12 @@ extern "C" int tron_gridradial2d(tron_plan *p, void *d_udata, const void *d_nuda
     g.out_p = p->nchan;
     g.out_shift = 0;
     StageTimer t(p, STAGE_GRID);
-    HIP_TRY(launch_grid(g, p->kb_mode, 0, p->stream));
+    if (p->binned) {
+        g.tile_order = p->d_tile_order32;
+        HIP_TRY(launch_grid_binned(g, 0, p->stream));
+    } else {
+        HIP_TRY(launch_grid(g, p->kb_mode, 0, p->stream));
+    }
     return TRON_OK;
 }
 
