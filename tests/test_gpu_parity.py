@@ -180,3 +180,21 @@ def test_errors_are_reported_not_fatal():
     cfg = lib.default_config(adjoint=1, device=99)
     with pytest.raises(lib.TronError):
         lib.Plan(cfg, lib.derive_dims(cfg, (1, 1, 32, 10, 1)))
+
+
+@pytest.mark.parametrize("nc,kb", [(1, lib.KB_EXACT), (2, lib.KB_FAST), (8, lib.KB_FAST)])
+def test_metric_size_pipeline_vs_oracle(oracle, monkeypatch, nc, kb):
+    """512-point readout -> 512^2 grid -> 256^2 image: the shape the fused pruned FFT (tron_fft512.hip) and the
+    32x32 binned gridding kernel are specialised for.  Checked against the oracle and against the
+    rocFFT + post_kernel path."""
+    npe = 48
+    data = synth.kspace(nc, 512, 2 * npe, seed=707)
+    flags = dict(golden_angle=1, data_undersamp=npe / 512 + 1e-6, prof_slide=npe)
+    want, p = oracle.recon(data, adjoint=1, golden=1, data_undersamp=npe / 512 + 1e-6, prof_slide=npe)
+    assert (p.nz, p.nxos, p.nx, p.npe1work) == (2, 512, 256, npe)
+    got, _ = lib.recon(data, adjoint=True, kb_mode=kb, **flags)
+    assert rel_l2(got, want) <= TOL_PIPELINE
+    monkeypatch.setenv("TRON_FFT", "rocfft")
+    ref, _ = lib.recon(data, adjoint=True, kb_mode=kb, **flags)
+    assert rel_l2(ref, want) <= TOL_PIPELINE
+    assert rel_l2(got, ref) <= 2e-6

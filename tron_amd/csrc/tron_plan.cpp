@@ -98,6 +98,9 @@ struct tron_plan {
     void *d_stage_out = nullptr;
     size_t stage_out_bytes = 0;
     float2 *d_trig_tmp = nullptr;  // stage-level gridding calls
+    bool fft512 = false;           // fused pruned FFT path (nxos 512 -> nx 256)
+    float2 *d_tw512 = nullptr;     // exp(+2 pi i k / 512)
+    float2 *d_fft_tmp = nullptr;   // chunk * nchan * 256 * 512
     std::map<std::pair<int, int>, FftPlan> fft;   // (batch, direction) -> plan
     // timing
     bool timing = false;
@@ -261,6 +264,16 @@ int adjoint_run(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, int 
         }
         int rc = stage_check(p, "grid");
         if (rc) return rc;
+        if (p->fft512 && combine) {
+            // fused: pruned inverse FFT + crop + deapodise + root-sum-of-squares (tron_fft512.hip)
+            {
+                StageTimer t(p, STAGE_FFT);
+                HIP_TRY(launch_fft512_adjoint(p->d_grid, p->d_fft_tmp, static_cast<float2 *>(d_out) + (size_t)z0 * d.nx * d.nx,
+                                              p->d_tw512, p->d_deapod, p->nchan, cz, p->stream));
+            }
+            if ((rc = stage_check(p, "fft512"))) return rc;
+            continue;
+        }
         rc = run_fft(p, p->d_grid, cz * p->nchan, 1);
         if (rc) return rc;
         if ((rc = stage_check(p, "fft"))) return rc;
@@ -383,6 +396,7 @@ extern "C" int tron_plan_create(tron_plan **out, const tron_config *cfg, const t
     // make every code object resident before anything is queued on a non-blocking stream
     HIP_TRY(warm_kernels());
     HIP_TRY(warm_grid_binned());
+    HIP_TRY(warm_fft512());
     HIP_TRY(hipDeviceSynchronize());
 
     tron_plan *p = new tron_plan();
@@ -442,6 +456,20 @@ extern "C" int tron_plan_create(tron_plan **out, const tron_config *cfg, const t
     if ((rc = upload(&p->d_errflag, &zero, sizeof(zero)))) return bail(rc);
     if (hipMalloc(reinterpret_cast<void **>(&p->d_grid), (size_t)p->chunk * per_unit) != hipSuccess)
         return bail(fail(TRON_ERR_NOMEM, "cannot allocate %zu bytes of Cartesian work space", (size_t)p->chunk * per_unit));
+    if (cfg->adjoint && d.nxos == 512 && d.nx == 256) {
+        p->fft512 = true;
+        if (const char *ff = getenv("TRON_FFT")) p->fft512 = strcmp(ff, "rocfft") != 0;
+    }
+    if (p->fft512) {
+        std::vector<float> tw(2 * 512);
+        for (int k = 0; k < 512; ++k) {
+            tw[2 * k] = (float)cos(2.0 * M_PI * k / 512.0);
+            tw[2 * k + 1] = (float)sin(2.0 * M_PI * k / 512.0);
+        }
+        if ((rc = upload(&p->d_tw512, tw.data(), tw.size() * sizeof(float)))) return bail(rc);
+        if (hipMalloc(reinterpret_cast<void **>(&p->d_fft_tmp), (size_t)p->chunk * p->nchan * 256 * 512 * sizeof(float2)) != hipSuccess)
+            return bail(fail(TRON_ERR_NOMEM, "cannot allocate the FFT intermediate buffer"));
+    }
     if (cfg->verbose) {
         printf("tronhip: device %d, %s, nchan %d, grid %d^2 -> image %d^2, %d spokes/image, chunk %d, KB %s\n",
                cfg->device, cfg->adjoint ? "adjoint" : "forward", p->nchan, d.nxos, d.nx, d.npe1work, p->chunk,
@@ -475,6 +503,8 @@ extern "C" int tron_plan_destroy(tron_plan *p)
     hipFree(p->d_stage_in);
     hipFree(p->d_stage_out);
     hipFree(p->d_trig_tmp);
+    hipFree(p->d_tw512);
+    hipFree(p->d_fft_tmp);
     if (p->stream) hipStreamDestroy(p->stream);
     delete p;
     return TRON_OK;
