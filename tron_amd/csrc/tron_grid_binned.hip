@@ -91,13 +91,15 @@ grid_binned_kernel(const GridParams p)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int X = X0 + (q & 1), Y = Y0 + (q >> 1);
-        Rlo[q] = 1 << 20; Rhi[q] = -1;
+        Rlo[q] = 1 << 20; Rhi[q] = 1 << 20;                    // empty band: (unsigned)(ar - Rlo) > 0 for every sample
         if (X + h < n && Y + h < n) {
             const uint32_t bnd = p.band[(size_t)(Y + h) * n + (X + h)];
-            Rlo[q] = (int)(bnd & 0xffffu);
-            Rhi[q] = (int)(bnd >> 16);
+            const int lo = (int)(bnd & 0xffffu), hi = (int)(bnd >> 16);
+            if (lo <= hi) { Rlo[q] = lo; Rhi[q] = hi; }         // corners beyond the last sample have lo > hi: empty
         }
     }
+    // only tiles touching the k-space centre can meet r = 0 (counted twice by the reference, :512/:521)
+    const bool has_centre = x0 <= CW && x0 + kBinTile > -CW && y0 <= CW && y0 + kBinTile > -CW;
 
     KbCoef kb;
     kb.W = p.W; kb.invW = 1.0f / p.W; kb.beta = p.beta;
@@ -197,37 +199,48 @@ grid_binned_kernel(const GridParams p)
             for (int c = tid; c < C::NCELLS; c += kBinThreads) L.hist[c] = 0u;
             __syncthreads();
 
-            // ---- A. stage + count: wave w takes spokes sp0+w, sp0+w+4, ... ------------------------
-            for (int sp = sp0 + wave; sp < sp1 && p.debug < 2; sp += 4) {
+            // ---- A. stage + count: records are dealt out flat, 64 consecutive records per wave pass ----
+            for (int rec = tid; rec < nrec && p.debug < 2; rec += kBinThreads) {
+                // which spoke of the batch holds record `rec`: sp_start[sp] <= rec_base + rec < sp_start[sp+1]
+                int lo = sp0, hi = sp1 - 1;
+                const int target = rec_base + rec;
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (L.sp_start[mid] <= target) lo = mid; else hi = mid - 1;
+                }
+                const int sp = lo;
                 const int pe = L.sp_pe[sp];
                 const int seg = L.sp_seg[sp];
-                const int rlo = (int)(short)(seg & 0xffff), len = seg >> 16;
-                if (pe < 0 || pe >= p.npe || len < 1 || len > C::SLOT || rlo < -rmax || rlo + len - 1 > rmax) {
-                    atomicOr(p.errflag, 64u);
-                    continue;
-                }
-                if (lane < len) {
-                    const float2 cs = trig[pe];
-                    const int r = rlo + lane;
-                    const int rec = L.sp_start[sp] - rec_base + lane;
-                    if (rec < 0 || rec >= C::NREC) { atomicOr(p.errflag, 32u); continue; }
-                    const float kx = (float)r * cs.x;                 // src/tron.cu:514-515
-                    const float ky = (float)r * cs.y;
-                    const int fx = (int)floorf(kx), fy = (int)floorf(ky);
-                    const int bx = fx - CW + 1, by = fy - CW + 1;
-                    float *wxr = L.wx + rec * C::NWP, *wyr = L.wy + rec * C::NWP;
-                    wxr[0] = 0.f; wxr[C::NWP - 1] = 0.f;
-                    wyr[0] = 0.f; wyr[C::NWP - 1] = 0.f;
+                const int r = (int)(short)(seg & 0xffff) + (target - L.sp_start[sp]);
+                const float2 cs = trig[pe];
+                const float kx = (float)r * cs.x;                     // src/tron.cu:514-515
+                const float ky = (float)r * cs.y;
+                const int fx = (int)floorf(kx), fy = (int)floorf(ky);
+                const int bx = fx - CW + 1, by = fy - CW + 1;
+                float *wxr = L.wx + rec * C::NWP, *wyr = L.wy + rec * C::NWP;
+                wxr[0] = 0.f; wxr[C::NWP - 1] = 0.f;
+                wyr[0] = 0.f; wyr[C::NWP - 1] = 0.f;
 #pragma unroll
-                    for (int i = 0; i < C::NW; ++i) {
-                        wxr[1 + i] = kb_weight<TRON_KB_FAST>(kx - (float)(bx + i), kb);   // src/tron.cu:516
-                        wyr[1 + i] = kb_weight<TRON_KB_FAST>(ky - (float)(by + i), kb);
+                for (int i = 0; i < C::NW; ++i) {
+                    wxr[1 + i] = kb_weight<TRON_KB_FAST>(kx - (float)(bx + i), kb);       // src/tron.cu:516
+                    wyr[1 + i] = kb_weight<TRON_KB_FAST>(ky - (float)(by + i), kb);
+                }
+                const int ridx = (r * p.nro) / n;                     // src/tron.cu:517
+                const int ro = ridx + p.nro / 2;
+                float sdc = 1.0f;
+                if (p.apply_dcf) sdc = p.dcf_a * fabsf((float)ro - (float)(p.nro / 2)) + p.dcf_b;   // src/tron.cu:412
+                const size_t sbase = ((size_t)p.nro * pe + ro) * p.nchan + c0;
+                if (!HALF && CPB % 2 == 0 && ncb == CPB && (p.nchan & 1) == 0 && (c0 & 1) == 0) {
+                    // the coils of one sample are contiguous: 16-byte loads, 16-byte LDS stores
+                    const float4 *src4 = reinterpret_cast<const float4 *>(reinterpret_cast<const float2 *>(in_bytes) + sbase);
+                    float4 *dst4 = reinterpret_cast<float4 *>(L.d + rec * CPB);
+#pragma unroll
+                    for (int c = 0; c < CPB / 2; ++c) {
+                        float4 v = src4[c];
+                        v.x *= sdc; v.y *= sdc; v.z *= sdc; v.w *= sdc;   // src/tron.cu:414
+                        dst4[c] = v;
                     }
-                    const int ridx = (r * p.nro) / n;                 // src/tron.cu:517
-                    const int ro = ridx + p.nro / 2;
-                    float sdc = 1.0f;
-                    if (p.apply_dcf) sdc = p.dcf_a * fabsf((float)ro - (float)(p.nro / 2)) + p.dcf_b;   // src/tron.cu:412
-                    const size_t sbase = ((size_t)p.nro * pe + ro) * p.nchan + c0;
+                } else {
 #pragma unroll
                     for (int c = 0; c < CPB; ++c) {
                         float2 d = make_float2(0.f, 0.f);
@@ -237,18 +250,18 @@ grid_binned_kernel(const GridParams p)
                         }
                         L.d[rec * CPB + c] = d;
                     }
-                    const int fxrel = fx - cx0, fyrel = fy - cy0;
-                    const bool valid = (unsigned)fxrel < (unsigned)C::NCELL && (unsigned)fyrel < (unsigned)C::NCELL;
-                    const int ar = r < 0 ? -r : r;
-                    unsigned key = (unsigned)(fxrel & 63) | ((unsigned)(fyrel & 63) << 6) | ((unsigned)ar << 12)
-                                   | ((unsigned)wave << 26) | (valid ? 1u << 28 : 0u) | (r == 0 ? 1u << 29 : 0u);
-                    L.key[rec] = key;
-                    if (valid) {
-                        const unsigned old = atomicAdd(&L.hist[fyrel * C::CELLW + fxrel], 1u << (8 * wave));
-                        const unsigned rk = (old >> (8 * wave)) & 0xffu;
-                        if (rk == 0xffu) atomicOr(p.errflag, 4u);
-                        L.rank[rec] = (unsigned char)rk;
-                    }
+                }
+                const int fxrel = fx - cx0, fyrel = fy - cy0;
+                const bool valid = (unsigned)fxrel < (unsigned)C::NCELL && (unsigned)fyrel < (unsigned)C::NCELL;
+                const int ar = r < 0 ? -r : r;
+                const unsigned key = (unsigned)(fxrel & 63) | ((unsigned)(fyrel & 63) << 6) | ((unsigned)ar << 12)
+                                     | ((unsigned)wave << 26) | (valid ? 1u << 28 : 0u) | (r == 0 ? 1u << 29 : 0u);
+                L.key[rec] = key;
+                if (valid) {
+                    const unsigned old = atomicAdd(&L.hist[fyrel * C::CELLW + fxrel], 1u << (8 * wave));
+                    const unsigned rk = (old >> (8 * wave)) & 0xffu;
+                    if (rk == 0xffu) atomicOr(p.errflag, 4u);
+                    L.rank[rec] = (unsigned char)rk;
                 }
             }
             __syncthreads();
@@ -301,38 +314,65 @@ grid_binned_kernel(const GridParams p)
             }
             __syncthreads();
 
-            // ---- D. apply: each thread walks the cell rows its 2x2 points can see ----------------
+            // ---- D. apply: each thread walks the 2CW+1 cell rows its 2x2 points can see as ONE loop
+            //         (row ranges concatenated), so a wave runs max-over-lanes(total), not sum of row maxima
             if (p.debug < 1) {
-#pragma unroll 1
-                for (int dy = 0; dy <= 2 * CW; ++dy) {
+                constexpr int NR = 2 * CW + 1;
+                int delta[NR], cum[NR + 1];
+                cum[0] = 0;
+#pragma unroll
+                for (int dy = 0; dy < NR; ++dy) {
                     const int rowbase = (my + dy) * C::CELLW + mx;
                     const int kbeg = L.start[rowbase];
                     const int kend = L.start[rowbase + 2 * CW + 1];
-                    const int jp = 2 * CW - dy;                        // padded wy index for row Y0 (Y0+1 uses jp+1)
-                    for (int k = kbeg; k < kend; ++k) {
-                        const int id = L.ids[k];
-                        if (id >= C::NREC || k >= C::NREC) { atomicOr(p.errflag, 16u); break; }
-                        const unsigned key = L.key[id];
-                        const int ip = mx + 2 * CW - (int)(key & 63);  // padded wx index for column X0
-                        const float *wxr = L.wx + id * C::NWP + ip;
-                        const float *wyr = L.wy + id * C::NWP + jp;
-                        const float wxa = wxr[0], wxb = wxr[1];
-                        const float wya = wyr[0], wyb = wyr[1];
-                        const int ar = (int)((key >> 12) & 0x3fffu);
-                        const bool twice = (key >> 29) & 1u;
-                        float wq[4];
-                        wq[0] = wxa * wya; wq[1] = wxb * wya; wq[2] = wxa * wyb; wq[3] = wxb * wyb;   // src/tron.cu:516
+                    delta[dy] = kbeg - cum[dy];                        // k = i + delta[row]
+                    cum[dy + 1] = cum[dy] + (kend - kbeg);
+                }
+                const int total = cum[NR];
+                for (int i = 0; i < total; ++i) {
+                    int row = 0, dl = delta[0];
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            if (!(ar >= Rlo[q] && ar <= Rhi[q])) wq[q] = 0.f;      // src/tron.cu:512,521
-                            if (twice && Rlo[q] == 0) wq[q] += wq[q];              // r = 0 sits in both loops
+                    for (int dy = 1; dy < NR; ++dy)
+                        if (i >= cum[dy]) { row = dy; dl = delta[dy]; }
+                    const int id = L.ids[i + dl];
+                    const int jp = 2 * CW - row;                       // padded wy index for row Y0 (Y0+1 uses jp+1)
+                    const unsigned key = L.key[id];
+                    const int ip = mx + 2 * CW - (int)(key & 63);      // padded wx index for column X0
+                    const float *wxr = L.wx + id * C::NWP + ip;
+                    const float *wyr = L.wy + id * C::NWP + jp;
+                    const float wxa = wxr[0], wxb = wxr[1];
+                    const float wya = wyr[0], wyb = wyr[1];
+                    const int ar = (int)((key >> 12) & 0x3fffu);
+                    float wq[4];
+                    wq[0] = wxa * wya; wq[1] = wxb * wya; wq[2] = wxa * wyb; wq[3] = wxb * wyb;   // src/tron.cu:516
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if ((unsigned)(ar - Rlo[q]) > (unsigned)(Rhi[q] - Rlo[q])) wq[q] = 0.f;    // src/tron.cu:512,521
+                    if (has_centre && ((key >> 29) & 1u)) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (Rlo[q] == 0) wq[q] += wq[q];                                      // r = 0 sits in both loops
+                    }
+                    if (CPB % 2 == 0) {
+                        const float4 *d4 = reinterpret_cast<const float4 *>(L.d + id * CPB);
+#pragma unroll
+                        for (int c = 0; c < CPB / 2; ++c) {
+                            const float4 d = d4[c];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                acc[q][2 * c].x = fmaf(d.x, wq[q], acc[q][2 * c].x);              // src/tron.cu:519
+                                acc[q][2 * c].y = fmaf(d.y, wq[q], acc[q][2 * c].y);
+                                acc[q][2 * c + 1].x = fmaf(d.z, wq[q], acc[q][2 * c + 1].x);
+                                acc[q][2 * c + 1].y = fmaf(d.w, wq[q], acc[q][2 * c + 1].y);
+                            }
                         }
+                    } else {
 #pragma unroll
                         for (int c = 0; c < CPB; ++c) {
                             const float2 d = L.d[id * CPB + c];
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
-                                acc[q][c].x = fmaf(d.x, wq[q], acc[q][c].x);       // src/tron.cu:519
+                                acc[q][c].x = fmaf(d.x, wq[q], acc[q][c].x);
                                 acc[q][c].y = fmaf(d.y, wq[q], acc[q][c].y);
                             }
                         }
@@ -345,24 +385,32 @@ grid_binned_kernel(const GridParams p)
     }
 
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int X = X0 + (q & 1), Y = Y0 + (q >> 1);
-        if (X + h < n && Y + h < n) {
-            int row = Y + h, col = X + h;
-            if (p.out_shift) {
-                row = Y < 0 ? Y + n : Y;
-                col = X < 0 ? X + n : X;
-            }
-            float2 *out = p.udata + (size_t)z * p.out_z + ((size_t)row * n + col) * p.out_p;
+    for (int qy = 0; qy < 2; ++qy) {
+        const int Y = Y0 + qy;
+        if (Y + h >= n) continue;
+        const int row = p.out_shift ? (Y < 0 ? Y + n : Y) : Y + h;     // both fftshifts of src/tron.cu:631 folded in
+        const int colA = p.out_shift ? (X0 < 0 ? X0 + n : X0) : X0 + h;
+        const bool pair = (X0 + 1 + h < n) && p.out_p == 1;            // X0 is even and n/2 is even: X0, X0+1 never straddle the wrap
+        float2 *out = p.udata + (size_t)z * p.out_z + ((size_t)row * n + colA) * p.out_p;
 #pragma unroll
-            for (int c = 0; c < CPB; ++c)
-                if (c < ncb) {
-                    float2 v;
-                    v.x = acc[q][c].x * p.scale;                       // src/tron.cu:532-534
-                    v.y = acc[q][c].y * p.scale;
-                    out[(size_t)(c0 + c) * p.out_c] = v;
+        for (int c = 0; c < CPB; ++c)
+            if (c < ncb) {
+                float4 v;
+                v.x = acc[2 * qy][c].x * p.scale;                       // src/tron.cu:532-534
+                v.y = acc[2 * qy][c].y * p.scale;
+                v.z = acc[2 * qy + 1][c].x * p.scale;
+                v.w = acc[2 * qy + 1][c].y * p.scale;
+                float2 *o = out + (size_t)(c0 + c) * p.out_c;
+                if (pair && (n & 1) == 0) {
+                    *reinterpret_cast<float4 *>(o) = v;
+                } else {
+                    if (X0 + h < n) o[0] = make_float2(v.x, v.y);
+                    if (X0 + 1 + h < n) {
+                        const int colB = p.out_shift ? (X0 + 1 < 0 ? X0 + 1 + n : X0 + 1) : X0 + 1 + h;
+                        p.udata[(size_t)z * p.out_z + ((size_t)row * n + colB) * p.out_p + (size_t)(c0 + c) * p.out_c] = make_float2(v.z, v.w);
+                    }
                 }
-        }
+            }
     }
 }
 
