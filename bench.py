@@ -132,25 +132,40 @@ def main():
     roofline = None
     stages = {}
     if rank == 0:
+        reps = max(2, min(args.steps, 5))
         plan.timing(True)
         plan.timing_reset()
-        for _ in range(max(2, min(args.steps, 5))):
+        for _ in range(reps):
             step()
-        names = {lib.STAGE_GRID: "grid", lib.STAGE_FFT: "fft", lib.STAGE_POST: "post"}
-        for st, name in names.items():
+        for st, name in {lib.STAGE_GRID: "grid", lib.STAGE_FFT: "fft", lib.STAGE_POST: "post"}.items():
             ms, n = plan.timing_get(st)
-            stages[name] = (ms, n)
+            if n:
+                stages[name] = (ms, n)
         plan.timing(False)
         tot = sum(ms for ms, _ in stages.values())
         dom = max(stages, key=lambda k: stages[k][0])
         ms, n = stages[dom]
-        units_per_launch = nz * nc * max(2, min(args.steps, 5)) / n       # coil-slices per launch
-        bytes_per_launch = ab[dom] * units_per_launch
+        units_per_launch = nz * nc * reps / n                            # coil-slices per launch
+        # "fft" = the fused pruned FFT + crop + deapodise + SoS when nxos=512 (then there is no separate post stage)
+        alg = {"grid": ab["grid"], "fft": ab["fft"] + (ab["post"] if "post" not in stages else 0), "post": ab["post"]}[dom]
+        bytes_per_launch = alg * units_per_launch
         achieved = bytes_per_launch / (ms / n * 1e-3) / 1e9
-        roofline = dict(bound="hbm", kernel={"grid": "grid_tile_kernel", "fft": "rocFFT 512x512 C2C inverse (batched)", "post": "post_kernel"}[dom],
-                        achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBPS, 4),
-                        traffic=None, bytes_per_launch=int(bytes_per_launch), launch_ms=round(ms / n, 4),
-                        stage_share={k: round(v[0] / tot, 3) for k, v in stages.items()})
+        kname = {"grid": "grid_binned_kernel" if args.kb == "fast" else "grid_tile_kernel",
+                 "fft": "fft512_rows_kernel + fft512_cols_post_kernel" if "post" not in stages else "rocFFT 512x512 C2C inverse (batched)",
+                 "post": "post_kernel"}[dom]
+        # HBM bytes the dominant kernel actually moved, from rocprofv3 PMC passes of this round
+        # (profiles/round1_v3_traffic.json: FETCH_SIZE x2 + WRITE_SIZE, separate passes), scaled to one launch
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "round1_v3_traffic.json")))["per_coil_slice_bytes_corrected"]
+            if dom == "grid" and args.kb == "fast" and nc == 8:
+                t = tj["grid_binned_kernel"]
+                traffic = int((t["read"] + t["write"]) * units_per_launch)
+        except Exception:
+            traffic = None
+        roofline = dict(bound="hbm", kernel=kname, achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
+                        frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=traffic, bytes_per_launch=int(bytes_per_launch),
+                        launch_ms=round(ms / n, 4), stage_share={k: round(v[0] / tot, 3) for k, v in stages.items()})
 
     result = None
     if rank == 0:

@@ -1,0 +1,3 @@
+cp tron_amd/lib/libtronhip.so /tmp/orig.so
+for f in tron_amd/lib/libtronhip_*.so; do cp $f tron_amd/lib/libtronhip.so; echo "variant $f"; python tools/gridbench.py 8 128 fast 2; done
+cp /tmp/orig.so tron_amd/lib/libtronhip.so

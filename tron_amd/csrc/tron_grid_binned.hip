@@ -37,7 +37,10 @@ struct BinCfg {
     static constexpr int CPT = (NCELLS + kBinThreads - 1) / kBinThreads;   // cells per thread in the scan
     // records per batch, sized so a workgroup stays near 48 KiB of LDS
     static constexpr int REC_BYTES = 2 * NWP * 4 + CPB * 8 + 4 + 2 + 1;
-    static constexpr int NREC_RAW = (36 * 1024) / REC_BYTES;
+#ifndef TRON_BIN_REC_KB
+#define TRON_BIN_REC_KB 36
+#endif
+    static constexpr int NREC_RAW = (TRON_BIN_REC_KB * 1024) / REC_BYTES;
     static constexpr int NREC = NREC_RAW >= 512 ? 512 : (NREC_RAW / 64) * 64;
     static constexpr int SLOT = 64;                          // longest spoke segment through tile + halo
 };
@@ -59,8 +62,11 @@ struct BinLds {
     float2 d[C::NREC * CPB];
 };
 
+#ifndef TRON_BIN_WAVES
+#define TRON_BIN_WAVES 1
+#endif
 template <int CPB, int CW, bool HALF>
-__global__ void __launch_bounds__(kBinThreads)
+__global__ void __launch_bounds__(kBinThreads, TRON_BIN_WAVES)
 grid_binned_kernel(const GridParams p)
 {
     using C = BinCfg<CPB, CW>;
@@ -424,7 +430,16 @@ static hipError_t launch_binned_cpb(const GridParams &p, int half_in, hipStream_
     const int chunks = (p.nchan - p.coil0 + CPB - 1) / CPB;
     dim3 grid((unsigned)((size_t)q.ntiles * q.nslices), (unsigned)chunks);
     const size_t lds = sizeof(BinLds<CPB, CW>);
-    static_assert(sizeof(BinLds<CPB, CW>) <= 64 * 1024, "binned gridding: LDS footprint must stay within the default 64 KiB");
+    if (lds > 64 * 1024) {   // above the default dynamic-LDS limit: raise it once per instantiation
+        static hipError_t once = [] {
+            hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(grid_binned_kernel<CPB, CW, false>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BinLds<CPB, CW>));
+            hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(grid_binned_kernel<CPB, CW, true>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BinLds<CPB, CW>));
+            return e1 != hipSuccess ? e1 : e2;
+        }();
+        if (once != hipSuccess) return once;
+    }
     if (half_in)
         hipLaunchKernelGGL((grid_binned_kernel<CPB, CW, true>), grid, dim3(kBinThreads), lds, s, q);
     else
