@@ -36,7 +36,7 @@ struct BinCfg {
     static constexpr int NCELLS = NCELL * CELLW;
     static constexpr int CPT = (NCELLS + kBinThreads - 1) / kBinThreads;   // cells per thread in the scan
     // records per batch, sized so a workgroup stays near 48 KiB of LDS
-    static constexpr int REC_BYTES = 2 * NWP * 4 + CPB * 8 + 4 + 2 + 1;
+    static constexpr int REC_BYTES = 2 * NWP * 4 + CPB * 8 + 4 + 4 + 1;
 #ifndef TRON_BIN_REC_KB
 #define TRON_BIN_REC_KB 36
 #endif
@@ -53,7 +53,7 @@ struct BinLds {
     int sp_start[kBinMaxSpokes + 1];      // exclusive scan of len
     unsigned hist[C::NCELLS];             // 4 x 8-bit per-wave counters per cell
     unsigned short start[C::NCELLS + 1];
-    unsigned short ids[C::NREC];
+    unsigned sorted[C::NREC];             // per sorted slot: record id | fxrel<<10 | |r|<<16 | (r==0)<<30
     unsigned key[C::NREC];
     unsigned char rank[C::NREC];
     int wcnt[8];
@@ -315,7 +315,8 @@ grid_binned_kernel(const GridParams p)
                     const int wb = (int)((below & 0xff) + ((below >> 8) & 0xff) + ((below >> 16) & 0xff));
                     const int pos = L.start[cell] + wb + L.rank[rec];
                     if (pos >= C::NREC) { atomicOr(p.errflag, 8u); continue; }
-                    L.ids[pos] = (unsigned short)rec;
+                    // everything the apply loop needs besides the weights: id, cell column, |r|, r == 0
+                    L.sorted[pos] = (unsigned)rec | ((key & 63u) << 10) | (((key >> 12) & 0x3fffu) << 16) | (((key >> 29) & 1u) << 30);
                 }
             }
             __syncthreads();
@@ -335,26 +336,37 @@ grid_binned_kernel(const GridParams p)
                     cum[dy + 1] = cum[dy] + (kend - kbeg);
                 }
                 const int total = cum[NR];
-                for (int i = 0; i < total; ++i) {
-                    int row = 0, dl = delta[0];
+                // software pipeline: the sorted entry of visit i+1 is fetched while visit i is processed
+                int row_next = 0, dl_next = delta[0];
 #pragma unroll
-                    for (int dy = 1; dy < NR; ++dy)
-                        if (i >= cum[dy]) { row = dy; dl = delta[dy]; }
-                    const int id = L.ids[i + dl];
+                for (int dy = 1; dy < NR; ++dy)
+                    if (0 >= cum[dy]) { row_next = dy; dl_next = delta[dy]; }
+                unsigned ent_next = total > 0 ? L.sorted[dl_next] : 0u;
+                for (int i = 0; i < total; ++i) {
+                    const unsigned ent = ent_next;
+                    const int row = row_next;
+                    {
+                        const int i1 = i + 1;
+                        row_next = 0; dl_next = delta[0];
+#pragma unroll
+                        for (int dy = 1; dy < NR; ++dy)
+                            if (i1 >= cum[dy]) { row_next = dy; dl_next = delta[dy]; }
+                        if (i1 < total) ent_next = L.sorted[i1 + dl_next];
+                    }
+                    const int id = (int)(ent & 1023u);
                     const int jp = 2 * CW - row;                       // padded wy index for row Y0 (Y0+1 uses jp+1)
-                    const unsigned key = L.key[id];
-                    const int ip = mx + 2 * CW - (int)(key & 63);      // padded wx index for column X0
+                    const int ip = mx + 2 * CW - (int)((ent >> 10) & 63u);   // padded wx index for column X0
                     const float *wxr = L.wx + id * C::NWP + ip;
                     const float *wyr = L.wy + id * C::NWP + jp;
                     const float wxa = wxr[0], wxb = wxr[1];
                     const float wya = wyr[0], wyb = wyr[1];
-                    const int ar = (int)((key >> 12) & 0x3fffu);
+                    const int ar = (int)((ent >> 16) & 0x3fffu);
                     float wq[4];
                     wq[0] = wxa * wya; wq[1] = wxb * wya; wq[2] = wxa * wyb; wq[3] = wxb * wyb;   // src/tron.cu:516
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
                         if ((unsigned)(ar - Rlo[q]) > (unsigned)(Rhi[q] - Rlo[q])) wq[q] = 0.f;    // src/tron.cu:512,521
-                    if (has_centre && ((key >> 29) & 1u)) {
+                    if (has_centre && ((ent >> 30) & 1u)) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
                             if (Rlo[q] == 0) wq[q] += wq[q];                                      // r = 0 sits in both loops

@@ -77,6 +77,9 @@ struct tron_plan {
     int kb_mode = TRON_KB_EXACT;
     int chunk = 1;                 // slices (adjoint) or images (forward) per batch
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;  // FFT lane of the adjoint pipeline (gridding stays on `stream`)
+    hipEvent_t ev_g[2] = {nullptr, nullptr}, ev_f[2] = {nullptr, nullptr};   // grid done / buffer free, per buffer
+    bool dual = false;
     // device tables
     float2 *d_trig = nullptr;
     size_t ntrig = 0;
@@ -93,6 +96,7 @@ struct tron_plan {
     float kb_poly[kKbPolyTerms];
     // work buffers
     float2 *d_grid = nullptr;      // chunk * nchan * nxos^2
+    float2 *d_grid2 = nullptr;     // second Cartesian buffer (dual-stream pipeline)
     void *d_stage_in = nullptr;    // host-API staging
     size_t stage_in_bytes = 0;
     void *d_stage_out = nullptr;
@@ -117,19 +121,20 @@ std::once_flag g_fft_once;
 struct StageTimer {
     tron_plan *p;
     int stage;
+    hipStream_t st_;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    StageTimer(tron_plan *plan, int st) : p(plan), stage(st)
+    StageTimer(tron_plan *plan, int st, hipStream_t stream = nullptr) : p(plan), stage(st), st_(stream ? stream : plan->stream)
     {
         if (p->timing) {
             hipEventCreate(&e0);
             hipEventCreate(&e1);
-            hipEventRecord(e0, p->stream);
+            hipEventRecord(e0, st_);
         }
     }
     ~StageTimer()
     {
         if (p->timing) {
-            hipEventRecord(e1, p->stream);
+            hipEventRecord(e1, st_);
             p->ev[stage].push_back({e0, e1});
         }
     }
@@ -138,6 +143,7 @@ struct StageTimer {
 int drain_timers(tron_plan *p)
 {
     HIP_TRY(hipStreamSynchronize(p->stream));
+    if (p->stream2) HIP_TRY(hipStreamSynchronize(p->stream2));
     for (int s = 0; s < STAGE_COUNT; ++s) {
         for (auto &pr : p->ev[s]) {
             float ms = 0.f;
@@ -203,6 +209,7 @@ int stage_check(tron_plan *p, const char *what)
 {
     if (!p->sync_each) return TRON_OK;
     hipError_t e = hipStreamSynchronize(p->stream);
+    if (e == hipSuccess && p->stream2) e = hipStreamSynchronize(p->stream2);
     if (e != hipSuccess) return fail(TRON_ERR_HIP, "stage '%s' failed: %s", what, hipGetErrorString(e));
     fprintf(stderr, "[tronhip] stage %s ok\n", what);
     return TRON_OK;
@@ -237,13 +244,25 @@ int adjoint_run(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, int 
     const size_t n2 = (size_t)d.nxos * d.nxos;
     const size_t elem = p->cfg.input_half ? 4 : 8;
     const int golden = p->cfg.golden_angle;
-    for (int z0 = 0; z0 < zcount; z0 += p->chunk) {
-        const int cz = std::min(p->chunk, zcount - z0);
+    // Two lanes: gridding is VALU/LDS bound and leaves HBM idle, the FFT passes are HBM bound and leave the
+    // VALUs idle.  All gridding launches go to `stream`, all FFT launches to `stream2`; chunk k's FFT waits
+    // for chunk k's gridding, and gridding of chunk k+2 waits until the FFT has released buffer k&1.
+    const bool dual = p->dual && p->fft512 && combine && zcount > 1;
+    const int step = dual ? std::max(1, std::min(p->chunk, (zcount + 1) / 2)) : p->chunk;
+    int lane_idx = 0;
+    for (int z0 = 0; z0 < zcount; z0 += step, ++lane_idx) {
+        const int cz = std::min(step, zcount - z0);
+        const int b = dual ? (lane_idx & 1) : 0;
+        hipStream_t st = p->stream;
+        hipStream_t st_fft = dual ? p->stream2 : p->stream;
+        float2 *grid_buf = b ? p->d_grid2 : p->d_grid;
+        float2 *tmp_buf = p->d_fft_tmp;
+        if (dual && lane_idx >= 2) HIP_TRY(hipStreamWaitEvent(st, p->ev_f[b], 0));
         GridParams g;
         memset(&g, 0, sizeof(g));
         fill_grid_consts(p, g);
         g.nudata = static_cast<const unsigned char *>(d_in_z0) + (size_t)z0 * d.prof_slide * d.nro * p->nchan * elem;
-        g.udata = p->d_grid;
+        g.udata = grid_buf;
         g.trig = p->d_trig + (golden ? (size_t)(zfirst + z0) * d.prof_slide : 0);
         g.in_slice_stride = (long long)d.prof_slide * d.nro * p->nchan;
         g.trig_slice_stride = golden ? d.prof_slide : 0;
@@ -254,23 +273,28 @@ int adjoint_run(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, int 
         g.out_p = 1;
         g.out_shift = 1;
         {
-            StageTimer t(p, STAGE_GRID);
+            StageTimer t(p, STAGE_GRID, st);
             if (p->binned) {
                 g.tile_order = p->d_tile_order32;
-                HIP_TRY(launch_grid_binned(g, p->cfg.input_half, p->stream));
+                HIP_TRY(launch_grid_binned(g, p->cfg.input_half, st));
             } else {
-                HIP_TRY(launch_grid(g, p->kb_mode, p->cfg.input_half, p->stream));
+                HIP_TRY(launch_grid(g, p->kb_mode, p->cfg.input_half, st));
             }
         }
         int rc = stage_check(p, "grid");
         if (rc) return rc;
         if (p->fft512 && combine) {
             // fused: pruned inverse FFT + crop + deapodise + root-sum-of-squares (tron_fft512.hip)
-            {
-                StageTimer t(p, STAGE_FFT);
-                HIP_TRY(launch_fft512_adjoint(p->d_grid, p->d_fft_tmp, static_cast<float2 *>(d_out) + (size_t)z0 * d.nx * d.nx,
-                                              p->d_tw512, p->d_deapod, p->nchan, cz, p->stream));
+            if (dual) {
+                HIP_TRY(hipEventRecord(p->ev_g[b], st));
+                HIP_TRY(hipStreamWaitEvent(st_fft, p->ev_g[b], 0));
             }
+            {
+                StageTimer t(p, STAGE_FFT, st_fft);
+                HIP_TRY(launch_fft512_adjoint(grid_buf, tmp_buf, static_cast<float2 *>(d_out) + (size_t)z0 * d.nx * d.nx,
+                                              p->d_tw512, p->d_deapod, p->nchan, cz, st_fft));
+            }
+            if (dual) HIP_TRY(hipEventRecord(p->ev_f[b], st_fft));
             if ((rc = stage_check(p, "fft512"))) return rc;
             continue;
         }
@@ -291,6 +315,9 @@ int adjoint_run(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, int 
             HIP_TRY(launch_post(q, p->stream));
         }
         if ((rc = stage_check(p, "post"))) return rc;
+    }
+    if (dual && lane_idx > 0) {   // later work on the main stream (e.g. the download) waits for the FFT lane
+        HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_f[(lane_idx - 1) & 1], 0));
     }
     return TRON_OK;
 }
@@ -469,6 +496,20 @@ extern "C" int tron_plan_create(tron_plan **out, const tron_config *cfg, const t
         if ((rc = upload(&p->d_tw512, tw.data(), tw.size() * sizeof(float)))) return bail(rc);
         if (hipMalloc(reinterpret_cast<void **>(&p->d_fft_tmp), (size_t)p->chunk * p->nchan * 256 * 512 * sizeof(float2)) != hipSuccess)
             return bail(fail(TRON_ERR_NOMEM, "cannot allocate the FFT intermediate buffer"));
+        // off by default: measured +2 % (the gridding kernel already fills every CU's LDS, so the FFT
+        // lane only gets the tail); TRON_DUAL_STREAM=1 turns it on
+        p->dual = false;
+        if (const char *ds = getenv("TRON_DUAL_STREAM")) p->dual = d.nz > 1 && atoi(ds) != 0;
+        if (p->dual) {
+            if (hipStreamCreateWithFlags(&p->stream2, hipStreamNonBlocking) != hipSuccess)
+                return bail(fail(TRON_ERR_HIP, "cannot create the FFT lane"));
+            for (int i = 0; i < 2; ++i)
+                if (hipEventCreateWithFlags(&p->ev_g[i], hipEventDisableTiming) != hipSuccess ||
+                    hipEventCreateWithFlags(&p->ev_f[i], hipEventDisableTiming) != hipSuccess)
+                    return bail(fail(TRON_ERR_HIP, "cannot create pipeline events"));
+            if (hipMalloc(reinterpret_cast<void **>(&p->d_grid2), (size_t)p->chunk * per_unit) != hipSuccess)
+                return bail(fail(TRON_ERR_NOMEM, "cannot allocate the second Cartesian buffer"));
+        }
     }
     if (cfg->verbose) {
         printf("tronhip: device %d, %s, nchan %d, grid %d^2 -> image %d^2, %d spokes/image, chunk %d, KB %s\n",
@@ -486,6 +527,7 @@ extern "C" int tron_plan_destroy(tron_plan *p)
     if (!p) return TRON_OK;
     hipSetDevice(p->cfg.device);
     if (p->stream) hipStreamSynchronize(p->stream);
+    if (p->stream2) hipStreamSynchronize(p->stream2);
     for (int s = 0; s < STAGE_COUNT; ++s)
         for (auto &pr : p->ev[s]) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     for (auto &kv : p->fft) {
@@ -505,6 +547,12 @@ extern "C" int tron_plan_destroy(tron_plan *p)
     hipFree(p->d_trig_tmp);
     hipFree(p->d_tw512);
     hipFree(p->d_fft_tmp);
+    hipFree(p->d_grid2);
+    for (int i = 0; i < 2; ++i) {
+        if (p->ev_g[i]) hipEventDestroy(p->ev_g[i]);
+        if (p->ev_f[i]) hipEventDestroy(p->ev_f[i]);
+    }
+    if (p->stream2) hipStreamDestroy(p->stream2);
     if (p->stream) hipStreamDestroy(p->stream);
     delete p;
     return TRON_OK;
@@ -514,6 +562,7 @@ extern "C" int tron_plan_sync(tron_plan *p)
 {
     if (!p) return fail(TRON_ERR_INVALID, "tron_plan_sync: null plan");
     HIP_TRY(hipStreamSynchronize(p->stream));
+    if (p->stream2) HIP_TRY(hipStreamSynchronize(p->stream2));
     return check_errflag(p);
 }
 
