@@ -63,7 +63,7 @@ struct BinLds {
 };
 
 #ifndef TRON_BIN_WAVES
-#define TRON_BIN_WAVES 1
+#define TRON_BIN_WAVES 3
 #endif
 template <int CPB, int CW, bool HALF>
 __global__ void __launch_bounds__(kBinThreads, TRON_BIN_WAVES)
@@ -194,30 +194,74 @@ grid_binned_kernel(const GridParams p)
             __syncthreads();
         }
 
-        int sp0 = 0;
+        // ---- batches: the longest run of spokes whose records fit in NREC; the k-space samples of batch
+        //      b+1 are fetched into registers while batch b is scanned, placed and applied ----------
+        constexpr int RPT = (C::NREC + kBinThreads - 1) / kBinThreads;      // records per thread per batch
+        int pf_pe[RPT], pf_r[RPT];
+        float2 pf_d[RPT][CPB];
+        auto batch_end = [&](int s0) {
+            const int base = L.sp_start[s0];
+            int s1 = s0 + 1;
+            while (s1 < nacc && L.sp_start[s1 + 1] - base <= C::NREC) ++s1;
+            return s1;
+        };
+        auto prefetch = [&](int s0, int s1) {
+            const int base = L.sp_start[s0];
+            const int cnt = L.sp_start[s1] - base;
+#pragma unroll
+            for (int j = 0; j < RPT; ++j) {
+                const int rec = tid + j * kBinThreads;
+                pf_pe[j] = -1;
+                if (rec < cnt) {
+                    // which spoke of the batch holds record `rec`: sp_start[sp] <= base + rec < sp_start[sp+1]
+                    int lo = s0, hi = s1 - 1;
+                    const int target = base + rec;
+                    while (lo < hi) {
+                        const int mid = (lo + hi + 1) >> 1;
+                        if (L.sp_start[mid] <= target) lo = mid; else hi = mid - 1;
+                    }
+                    const int pe = L.sp_pe[lo];
+                    const int r = (int)(short)(L.sp_seg[lo] & 0xffff) + (target - L.sp_start[lo]);
+                    pf_pe[j] = pe;
+                    pf_r[j] = r;
+                    const int ro = (r * p.nro) / n + p.nro / 2;          // src/tron.cu:517,519
+                    const size_t sbase = ((size_t)p.nro * pe + ro) * p.nchan + c0;
+                    if (!HALF && CPB % 2 == 0 && ncb == CPB && (p.nchan & 1) == 0 && (c0 & 1) == 0) {
+                        // the coils of one sample are contiguous: 16-byte loads
+                        const float4 *src4 = reinterpret_cast<const float4 *>(reinterpret_cast<const float2 *>(in_bytes) + sbase);
+#pragma unroll
+                        for (int c = 0; c < CPB / 2; ++c) {
+                            const float4 v = src4[c];
+                            pf_d[j][2 * c] = make_float2(v.x, v.y);
+                            pf_d[j][2 * c + 1] = make_float2(v.z, v.w);
+                        }
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < CPB; ++c)
+                            pf_d[j][c] = c < ncb ? load_sample<HALF>(in_bytes, sbase + c) : make_float2(0.f, 0.f);
+                    }
+                }
+            }
+        };
+
+        int sp0 = 0, sp1 = 0;
+        if (nacc > 0 && p.debug < 3) {
+            sp1 = batch_end(0);
+            if (p.debug < 2) prefetch(0, sp1);
+        }
         while (sp0 < nacc && p.debug < 3) {
-            // ---- batch = the longest run of spokes whose records fit in NREC (uniform) ----------
             const int rec_base = L.sp_start[sp0];
-            int sp1 = sp0 + 1;
-            while (sp1 < nacc && L.sp_start[sp1 + 1] - rec_base <= C::NREC) ++sp1;
             const int nrec = L.sp_start[sp1] - rec_base;
 
             for (int c = tid; c < C::NCELLS; c += kBinThreads) L.hist[c] = 0u;
             __syncthreads();
 
             // ---- A. stage + count: records are dealt out flat, 64 consecutive records per wave pass ----
-            for (int rec = tid; rec < nrec && p.debug < 2; rec += kBinThreads) {
-                // which spoke of the batch holds record `rec`: sp_start[sp] <= rec_base + rec < sp_start[sp+1]
-                int lo = sp0, hi = sp1 - 1;
-                const int target = rec_base + rec;
-                while (lo < hi) {
-                    const int mid = (lo + hi + 1) >> 1;
-                    if (L.sp_start[mid] <= target) lo = mid; else hi = mid - 1;
-                }
-                const int sp = lo;
-                const int pe = L.sp_pe[sp];
-                const int seg = L.sp_seg[sp];
-                const int r = (int)(short)(seg & 0xffff) + (target - L.sp_start[sp]);
+#pragma unroll
+            for (int j = 0; j < RPT; ++j) {
+                const int rec = tid + j * kBinThreads;
+                if (rec >= nrec || p.debug >= 2) continue;
+                const int pe = pf_pe[j], r = pf_r[j];
                 const float2 cs = trig[pe];
                 const float kx = (float)r * cs.x;                     // src/tron.cu:514-515
                 const float ky = (float)r * cs.y;
@@ -231,31 +275,23 @@ grid_binned_kernel(const GridParams p)
                     wxr[1 + i] = kb_weight<TRON_KB_FAST>(kx - (float)(bx + i), kb);       // src/tron.cu:516
                     wyr[1 + i] = kb_weight<TRON_KB_FAST>(ky - (float)(by + i), kb);
                 }
-                const int ridx = (r * p.nro) / n;                     // src/tron.cu:517
-                const int ro = ridx + p.nro / 2;
+                const int ro = (r * p.nro) / n + p.nro / 2;
                 float sdc = 1.0f;
                 if (p.apply_dcf) sdc = p.dcf_a * fabsf((float)ro - (float)(p.nro / 2)) + p.dcf_b;   // src/tron.cu:412
-                const size_t sbase = ((size_t)p.nro * pe + ro) * p.nchan + c0;
-                if (!HALF && CPB % 2 == 0 && ncb == CPB && (p.nchan & 1) == 0 && (c0 & 1) == 0) {
-                    // the coils of one sample are contiguous: 16-byte loads, 16-byte LDS stores
-                    const float4 *src4 = reinterpret_cast<const float4 *>(reinterpret_cast<const float2 *>(in_bytes) + sbase);
-                    float4 *dst4 = reinterpret_cast<float4 *>(L.d + rec * CPB);
+                // samples go to LDS coil-pair-major ([pair][record], 16 bytes each): conflict-free stores
+                if (CPB % 2 == 0) {
+                    float4 *dst4 = reinterpret_cast<float4 *>(L.d);
 #pragma unroll
                     for (int c = 0; c < CPB / 2; ++c) {
-                        float4 v = src4[c];
-                        v.x *= sdc; v.y *= sdc; v.z *= sdc; v.w *= sdc;   // src/tron.cu:414
-                        dst4[c] = v;
+                        float4 v;
+                        v.x = pf_d[j][2 * c].x * sdc; v.y = pf_d[j][2 * c].y * sdc;        // src/tron.cu:414
+                        v.z = pf_d[j][2 * c + 1].x * sdc; v.w = pf_d[j][2 * c + 1].y * sdc;
+                        dst4[c * C::NREC + rec] = v;
                     }
                 } else {
 #pragma unroll
-                    for (int c = 0; c < CPB; ++c) {
-                        float2 d = make_float2(0.f, 0.f);
-                        if (c < ncb) {
-                            d = load_sample<HALF>(in_bytes, sbase + c);
-                            d.x *= sdc; d.y *= sdc;
-                        }
-                        L.d[rec * CPB + c] = d;
-                    }
+                    for (int c = 0; c < CPB; ++c)
+                        L.d[c * C::NREC + rec] = make_float2(pf_d[j][c].x * sdc, pf_d[j][c].y * sdc);
                 }
                 const int fxrel = fx - cx0, fyrel = fy - cy0;
                 const bool valid = (unsigned)fxrel < (unsigned)C::NCELL && (unsigned)fyrel < (unsigned)C::NCELL;
@@ -269,6 +305,13 @@ grid_binned_kernel(const GridParams p)
                     if (rk == 0xffu) atomicOr(p.errflag, 4u);
                     L.rank[rec] = (unsigned char)rk;
                 }
+            }
+            // next batch: bounds now, samples in flight while this batch is scanned / placed / applied
+            const int nsp0 = sp1;
+            int nsp1 = nsp0;
+            if (nsp0 < nacc) {
+                nsp1 = batch_end(nsp0);
+                if (p.debug < 2) prefetch(nsp0, nsp1);
             }
             __syncthreads();
 
@@ -372,10 +415,10 @@ grid_binned_kernel(const GridParams p)
                             if (Rlo[q] == 0) wq[q] += wq[q];                                      // r = 0 sits in both loops
                     }
                     if (CPB % 2 == 0) {
-                        const float4 *d4 = reinterpret_cast<const float4 *>(L.d + id * CPB);
+                        const float4 *d4 = reinterpret_cast<const float4 *>(L.d) + id;
 #pragma unroll
                         for (int c = 0; c < CPB / 2; ++c) {
-                            const float4 d = d4[c];
+                            const float4 d = d4[c * C::NREC];
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
                                 acc[q][2 * c].x = fmaf(d.x, wq[q], acc[q][2 * c].x);              // src/tron.cu:519
@@ -387,7 +430,7 @@ grid_binned_kernel(const GridParams p)
                     } else {
 #pragma unroll
                         for (int c = 0; c < CPB; ++c) {
-                            const float2 d = L.d[id * CPB + c];
+                            const float2 d = L.d[c * C::NREC + id];
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
                                 acc[q][c].x = fmaf(d.x, wq[q], acc[q][c].x);
@@ -398,7 +441,8 @@ grid_binned_kernel(const GridParams p)
                 }
             }
             __syncthreads();
-            sp0 = sp1;
+            sp0 = nsp0;
+            sp1 = nsp1;
         }
     }
 
