@@ -198,3 +198,36 @@ def test_metric_size_pipeline_vs_oracle(oracle, monkeypatch, nc, kb):
     ref, _ = lib.recon(data, adjoint=True, kb_mode=kb, **flags)
     assert rel_l2(ref, want) <= TOL_PIPELINE
     assert rel_l2(got, ref) <= 2e-6
+
+
+def test_half_precision_kspace_input(oracle):
+    """Config 5: k-space stored as complex-half (.ra eltype 4 / elbyte 4), converted with the reference's
+    round-to-nearest-even (src/float16.cu); gridded from half storage with fp32 accumulation.  Parity is
+    against the fp32 oracle run on the SAME half-rounded values."""
+    nc, nro, npe = 2, 64, 90
+    data = synth.kspace(nc, nro, npe, seed=808)
+    halves = np.asfortranarray(data).reshape(-1, order="F").view(np.float32).astype(np.float16)
+    L = lib.load()
+    mine = np.array([L.ra_float_to_half_bits(int(b)) for b in np.asfortranarray(data).reshape(-1, order="F").view(np.uint32)[:512]], np.uint16)
+    assert np.array_equal(mine, halves.view(np.uint16)[:512])                 # same rounding as the C converter
+    rounded = halves.astype(np.float32).view(np.complex64).reshape(data.shape, order="F")
+    flags = dict(golden_angle=1, data_undersamp=0.5, prof_slide=13)
+    want, _ = oracle.recon(rounded, adjoint=1, golden=1, data_undersamp=0.5, prof_slide=13)
+    h = halves.reshape((2,) + data.shape, order="F")
+    for kb in (lib.KB_EXACT, lib.KB_FAST):
+        got, _ = lib.recon(h, adjoint=True, input_half=1, kb_mode=kb, **flags)
+        assert rel_l2(got, want) <= TOL_PIPELINE
+
+
+def test_whole_body_shaped_stream(oracle):
+    """Config 3 in miniature: `tron -u 0.4 -d 21 -a -G` (src/RUNME3_tron_grid_all.sh:10) on a 6-coil,
+    512-readout golden-angle stream: sliding windows of 204 spokes, hop 21.  Every slice is computed on the
+    GPU; the first, a middle and the last slice are checked against the oracle."""
+    nc, nro, npe1 = 6, 512, 204 + 21 * 7
+    data = synth.kspace(nc, nro, npe1, seed=909)
+    flags = dict(golden_angle=1, data_undersamp=0.4, prof_slide=21)
+    got, dims = lib.recon(data, adjoint=True, kb_mode=lib.KB_FAST, **flags)
+    assert (dims.nz, dims.npe1work, dims.nx) == (8, 204, 256)
+    for z in (0, 4, 7):
+        want, _ = oracle.recon(data, adjoint=1, zfirst=z, zcount=1, golden=1, data_undersamp=0.4, prof_slide=21)
+        assert rel_l2(got[..., z], want[..., z]) <= TOL_PIPELINE
