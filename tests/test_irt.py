@@ -1,0 +1,69 @@
+"""BASELINE.json config 1 / SURVEY 8d-C1: Shepp-Logan degridding on the CPU with the bundled IRT NUFFT (restated in
+oracle/irt_nufft.py), the comparison of src/RUNME2_others_degrid_phantom.m.  IRT is an INDEPENDENT algorithm (min-max
+interpolation, double precision), so agreement with TRON's forward path is a paper-level check, not bit parity:
+RUNME2:89-96 plots |tron|-|irt| on a +-4e-4 scale at N = 256 and prints norm(irt - tron)/max|irt|."""
+import os
+
+import numpy as np
+import pytest
+
+import synth  # noqa: F401
+from oracle import irt_nufft as irt
+
+
+def _dtft(om, x, N):
+    n = np.arange(N) - N / 2
+    return np.einsum("ma,ab,mb->m", np.exp(-1j * np.outer(om[:, 0], n)), x, np.exp(-1j * np.outer(om[:, 1], n)))
+
+
+def test_irt_restatement_is_a_nufft():
+    N = 32
+    om = irt.radial_trajectory(2 * N, 2 * N)
+    st = irt.Nufft(om, (N, N), (4, 4), (2 * N, 2 * N), (N / 2, N / 2))
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((N, N)) + 1j * rng.standard_normal((N, N))
+    want = _dtft(om, x, N)
+    assert np.abs(st.forward(x) - want).max() / np.abs(want).max() < 1e-3       # J = 4: ~5e-4 (nufft_best_alpha.m:33)
+    y = rng.standard_normal(om.shape[0]) + 1j * rng.standard_normal(om.shape[0])
+    n = np.arange(N) - N / 2
+    adj = np.einsum("ma,m,mb->ab", np.exp(1j * np.outer(om[:, 0], n)), y, np.exp(1j * np.outer(om[:, 1], n)))
+    assert np.abs(st.adjoint(y) - adj).max() / np.abs(adj).max() < 1e-3
+    # <A x, y> = <x, A^H y>
+    assert abs(np.vdot(st.forward(x), y) - np.vdot(x, st.adjoint(y))) < 1e-9 * abs(np.vdot(x, st.adjoint(y)))
+
+
+def test_kb_table_matches_reference_mat_file():
+    path = "/root/reference/contrib/irt/private/kaiser,m=0.mat"
+    if not os.path.exists(path):
+        pytest.skip("reference tree absent")
+    from scipy.io import loadmat
+    m = loadmat(path)
+    best = m["abest"]["zn"][0, 0].ravel()
+    for J, a in zip(m["Jlist"].ravel(), best):
+        assert irt.KB_BEST_ALPHA_OVER_J[int(J)] == pytest.approx(float(a))
+
+
+def _compare(run_forward, N=64):
+    nro = npe = 2 * N
+    st = irt.Nufft(irt.radial_trajectory(nro, npe), (N, N), (4, 4), (2 * N, 2 * N), (N / 2, N / 2))
+    x = irt.shepp_logan(N).T.copy()                          # first image index = x = TRON's column (cosine) axis
+    X = st.forward(x)
+    img = np.zeros((1, 1, N, N, 1), np.complex64)
+    img[0, 0, :, :, 0] = x
+    Xt = run_forward(img)[0, 0, :, :, 0].reshape(-1, order="F")   # tron image.ra data.ra (RUNME1:5): [1,1,nro,npe,1]
+    scale = np.vdot(X, Xt) / np.vdot(X, X)
+    resid = np.linalg.norm(Xt - scale * X) / np.linalg.norm(scale * X)
+    magdiff = np.abs(np.abs(Xt) - np.abs(X)).max() / np.abs(X).max()
+    return scale, resid, magdiff
+
+
+def test_oracle_forward_agrees_with_irt_on_shepp_logan(oracle):
+    scale, resid, magdiff = _compare(lambda img: oracle.recon(img, adjoint=0)[0])
+    assert abs(scale - 1) < 5e-3 and resid < 1e-2 and magdiff < 1e-2, (scale, resid, magdiff)
+
+
+@pytest.mark.gpu
+def test_hip_forward_agrees_with_irt_on_shepp_logan():
+    from tron_amd import lib
+    scale, resid, magdiff = _compare(lambda img: lib.recon(img, adjoint=False, kb_mode=lib.KB_FAST)[0], N=128)
+    assert abs(scale - 1) < 5e-3 and resid < 5e-3 and magdiff < 5e-3, (scale, resid, magdiff)

