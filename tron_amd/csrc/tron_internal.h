@@ -71,6 +71,9 @@ size_t grid_lds_bytes(int cpb, int cw);
 hipError_t warm_kernels();       // force-load the code object of tron_kernels.hip
 hipError_t warm_grid_binned();   // ... and of tron_grid_binned.hip
 hipError_t warm_fft512();        // ... and of tron_fft512.hip
+hipError_t warm_degrid_tile();   // ... and of tron_degrid_tile.hip
+// tiled degridding (tron_degrid_tile.hip), W <= 3
+hipError_t launch_degrid_tile(const DegridParams &p, int kb_mode, hipStream_t s);
 // fused pruned inverse FFT + crop + deapodise + SoS for nxos = 512, nx = 256 (tron_fft512.hip)
 hipError_t launch_fft512_adjoint(const float2 *grid, float2 *tmp, float2 *out, const float2 *tw, const float *inv_deapod,
                                  int nchan, int nslices, hipStream_t s);

@@ -361,7 +361,10 @@ int forward_run(tron_plan *p, void *d_out, const void *d_in, int nimg)
         memcpy(g.kb_poly, p->kb_poly, sizeof(g.kb_poly));
         {
             StageTimer t(p, STAGE_DEGRID);
-            HIP_TRY(launch_degrid(g, p->kb_mode, p->stream));
+            if (p->cfg.kernwidth <= 3.f && !getenv("TRON_DEGRID_SIMPLE"))
+                HIP_TRY(launch_degrid_tile(g, p->kb_mode, p->stream));
+            else
+                HIP_TRY(launch_degrid(g, p->kb_mode, p->stream));
         }
     }
     return TRON_OK;
@@ -424,6 +427,7 @@ extern "C" int tron_plan_create(tron_plan **out, const tron_config *cfg, const t
     HIP_TRY(warm_kernels());
     HIP_TRY(warm_grid_binned());
     HIP_TRY(warm_fft512());
+    HIP_TRY(warm_degrid_tile());
     HIP_TRY(hipDeviceSynchronize());
 
     tron_plan *p = new tron_plan();
@@ -705,7 +709,10 @@ extern "C" int tron_degridradial2d(tron_plan *p, void *d_nudata, const void *d_u
     g.beta = p->beta;
     memcpy(g.kb_poly, p->kb_poly, sizeof(g.kb_poly));
     StageTimer t(p, STAGE_DEGRID);
-    HIP_TRY(launch_degrid(g, p->kb_mode, p->stream));
+    if (p->cfg.kernwidth <= 3.f && !getenv("TRON_DEGRID_SIMPLE"))
+        HIP_TRY(launch_degrid_tile(g, p->kb_mode, p->stream));
+    else
+        HIP_TRY(launch_degrid(g, p->kb_mode, p->stream));
     return TRON_OK;
 }
 
