@@ -14,7 +14,7 @@ for f in glob.glob('$out/p*/*/*_counter_collection.csv'):
         k=r['Kernel_Name'].split('(')[0][-40:]
         agg[k][r['Counter_Name']]+=float(r['Counter_Value'])
 for k,v in agg.items():
-    if 'grid' in k or 'post' in k or 'fft' in k:
+    if any(t in k for t in ("grid","post","fft","pre")):
         w=v.get('SQ_WAVES',1)
         print(k); print('   '+'  '.join(f"{n}={val:.3g}" for n,val in sorted(v.items())))
         if 'SQ_INSTS_VALU' in v: print(f"   per wave: VALU {v['SQ_INSTS_VALU']/w:.0f} LDS {v['SQ_INSTS_LDS']/w:.0f} SALU {v['SQ_INSTS_SALU']/w:.0f} wave_cycles(quad) {v['SQ_WAVE_CYCLES']/w:.0f}  lane_util {v.get('SQ_THREAD_CYCLES_VALU',0)/max(v.get('SQ_ACTIVE_INST_VALU',1),1)/64:.2f}")

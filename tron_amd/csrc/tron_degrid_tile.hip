@@ -24,7 +24,7 @@ struct DgLds {
     int sp_seg[kDgMaxSpokes];          // ro_lo | len << 16
     int sp_start[kDgMaxSpokes + 1];   // exclusive scan of len
     int wcnt[8];
-    float2 tile[TS * TS * CPB];        // [row][col][coil]
+    float2 tile[TS * TS * CPB];        // [coil][row][col]: neighbouring samples read neighbouring banks
 };
 
 template <int CPB, int CW, int KB>
@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(kDgThreads) degrid_tile_kernel(const DegridPar
         }
         float2 v = make_float2(0.f, 0.f);
         if (c < ncb) v = src[((size_t)i * n + j) * p.in_p + (size_t)(c0 + c) * p.in_c];
-        L.tile[(r * TS + col) * CPB + c] = v;
+        L.tile[c * (TS * TS) + r * TS + col] = v;
     }
 
     const float half = (float)((n + 1) / 2);                    // src/tron.cu:560-561
@@ -163,10 +163,10 @@ __global__ void __launch_bounds__(kDgThreads) degrid_tile_kernel(const DegridPar
             if ((unsigned)(fx - tx0) >= (unsigned)kDgTile || (unsigned)(fy - ty0) >= (unsigned)kDgTile) continue;
 
             const int yu0 = (int)ceilf(Y - W);
-            float wy[2 * CW + 2];
+            float wy[2 * CW + 1];                                    // at most floor(2W)+1 integers in [Y-W, Y+W]
             int ny = 0;
 #pragma unroll
-            for (int t = 0; t < 2 * CW + 2; ++t) {
+            for (int t = 0; t < 2 * CW + 1; ++t) {
                 wy[t] = 0.f;
                 if ((float)(yu0 + t) <= (Y + W)) {                      // src/tron.cu:566
                     wy[t] = kb_weight<KB>((float)(yu0 + t) - Y, kb);
@@ -179,14 +179,14 @@ __global__ void __launch_bounds__(kDgThreads) degrid_tile_kernel(const DegridPar
             const int lrow0 = HALO - tx0, lcol0 = yu0 + HALO - ty0;
             for (int xu = (int)ceilf(X - W); (float)xu <= (X + W); ++xu) {     // src/tron.cu:563
                 const float wgtx = kb_weight<KB>((float)xu - X, kb);
-                const float2 *trow = L.tile + ((xu + lrow0) * TS + lcol0) * CPB;
+                const float2 *trow = L.tile + (xu + lrow0) * TS + lcol0;
 #pragma unroll
-                for (int t = 0; t < 2 * CW + 2; ++t) {
+                for (int t = 0; t < 2 * CW + 1; ++t) {
                     if (t < ny) {
                         const float wgt = wgtx * wy[t];                         // src/tron.cu:568
 #pragma unroll
                         for (int c = 0; c < CPB; ++c) {
-                            const float2 v = trow[t * CPB + c];
+                            const float2 v = trow[c * (TS * TS) + t];
                             if (KB == TRON_KB_EXACT) {
                                 acc[c].x += v.x * wgt;                          // src/tron.cu:573, unfused
                                 acc[c].y += v.y * wgt;
