@@ -1,21 +1,21 @@
-// HIP kernels of libtronhip for gfx950 (MI355X): radial gridding (adjoint interpolation),
-// degridding (forward interpolation) and the fused pad/crop/deapodise/coil-combine passes.
+// HIP kernels of libtronhip for gfx950 (MI355X), part 1: the reference-order gridding kernel
+// (grid_tile_kernel, used by TRON_KB_EXACT), the simple degridding kernel, and the fused
+// pad / crop / deapodise / coil-combine passes.  The fast gridding kernel lives in
+// tron_grid_binned.hip, the tiled degridding in tron_degrid_tile.hip, the fused pruned FFT in tron_fft512.hip.
 //
 // What each kernel computes follows the reference (davidssmith/TRON, src/tron.cu; cited per
 // kernel); how it computes it does not.  The reference grids with one thread per Cartesian
 // point scanning EVERY spoke (src/tron.cu:507-530, ~425 kernel evaluations per useful
-// accumulation).  Here one workgroup owns a 16x16 Cartesian tile and
-//   1. clips all spokes against the tile (one lane per spoke, wave64 ballot + popcount
-//      compaction keeps the accepted spokes in acquisition order),
+// accumulation).  grid_tile_kernel: one wave64 owns a 16x16 Cartesian tile, each lane 2x2 points, and
+//   1. clips all spokes against the tile (one lane per spoke; wave64 ballot, survivors visited in
+//      acquisition order, their parameters passed by wave shuffle),
 //   2. stages the accepted spoke segments in LDS in batches: lanes run ALONG the spoke, so
-//      k-space is read coalesced from HBM exactly once per tile-halo, and each sample's
-//      2x(2*ceil(W)) separable Kaiser-Bessel weights, density compensation and footprint
-//      origin are computed once per sample (shared by all coils and all 16 footprint points),
-//   3. lets each thread gather, for its own Cartesian point, the staged samples whose
-//      footprint covers it.  Points accumulate in registers: no atomics, deterministic, and
-//      the summation order per point (spoke ascending; positive radii ascending, then negative
-//      radii ascending) is the reference's own, so TRON_KB_EXACT reproduces the reference's
-//      fp32 sums bit for bit.
+//      k-space is read coalesced, and each sample's 2x(2*ceil(W)) separable Kaiser-Bessel weights and
+//      density compensation are computed once (shared by all coils and all footprint points),
+//   3. lets each lane gather, for its own points, the staged samples whose footprint covers them.
+//      Points accumulate in registers: no atomics, deterministic, and the summation order per point
+//      (spoke ascending; positive radii ascending, then negative radii ascending) is the
+//      reference's own, so TRON_KB_EXACT reproduces the reference's fp32 sums bit for bit.
 // Build with -ffp-contract=off: every fused multiply-add in this file is an explicit fmaf().
 #include "tron_device.h"
 
