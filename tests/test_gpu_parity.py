@@ -231,3 +231,46 @@ def test_whole_body_shaped_stream(oracle):
     for z in (0, 4, 7):
         want, _ = oracle.recon(data, adjoint=1, zfirst=z, zcount=1, golden=1, data_undersamp=0.4, prof_slide=21)
         assert rel_l2(got[..., z], want[..., z]) <= TOL_PIPELINE
+
+
+@pytest.mark.parametrize("kb", [lib.KB_EXACT, lib.KB_FAST])
+def test_odd_and_tiny_grids(oracle, kb):
+    """Odd oversampled sizes (forward shift n/2, inverse shift n - n/2 differ, src/tron.cu:164) go through
+    rocFFT + post_kernel / pre_kernel; grids smaller than one tile exercise the partial-tile paths."""
+    # adjoint: nro 40, -o 1.25 -> nx 20, nxos 25 (odd)
+    data = synth.kspace(2, 40, 30, seed=1001)
+    flags = dict(golden_angle=1, data_undersamp=2.0, gridos=1.25)
+    want, p = oracle.recon(data, adjoint=1, golden=1, data_undersamp=2.0, gridos=1.25)
+    assert p.nxos == 25
+    got, _ = lib.recon(data, adjoint=True, kb_mode=kb, **flags)
+    assert rel_l2(got, want) <= TOL_PIPELINE
+    # forward: nx 10, -o 1.5 -> nxos 15 (odd), nro 15
+    img = synth.image(1, 10, seed=1002)
+    want, p = oracle.recon(img, adjoint=0, golden=1, gridos=1.5)
+    assert p.nxos == 15
+    got, _ = lib.recon(img, adjoint=False, kb_mode=kb, golden_angle=1, gridos=1.5)
+    assert rel_l2(got, want) <= TOL_PIPELINE
+    # tiny: 8x8 image -> 16x16 grid (smaller than a 32x32 tile), one spoke per image
+    img = synth.image(2, 8, seed=1003)
+    want, _ = oracle.recon(img, adjoint=0, golden=1, data_undersamp=0.0626)
+    got, d = lib.recon(img, adjoint=False, kb_mode=kb, golden_angle=1, data_undersamp=0.0626)
+    assert d.npe1work == 1 and rel_l2(got, want) <= TOL_PIPELINE
+    data = synth.kspace(1, 16, 1, seed=1004)
+    want, _ = oracle.recon(data, adjoint=1, golden=1, data_undersamp=2.0)
+    got, d = lib.recon(data, adjoint=True, kb_mode=kb, golden_angle=1, data_undersamp=2.0)
+    assert d.npe1work == 1 and rel_l2(got, want) <= TOL_PIPELINE
+
+
+def test_sharded_cli_single_rank(tmp_path):
+    """python -m tron_amd.shard with one rank == the tron binary (the N>1 gather is covered on CPU with gloo)."""
+    import os, subprocess, sys
+    from tron_amd import ra
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    data = synth.kspace(2, 32, 60, seed=1005)
+    inp, o1, o2 = (str(tmp_path / n) for n in ("in.ra", "a.ra", "b.ra"))
+    ra.write(inp, data)
+    argv = ["-a", "-G", "-u", "0.5", "-d", "9"]
+    assert subprocess.run([os.path.join(root, "tron_amd", "bin", "tron")] + argv + [inp, o1]).returncode == 0
+    r = subprocess.run([sys.executable, "-m", "tron_amd.shard"] + argv + [inp, o2], cwd=root, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert np.array_equal(ra.read(o1), ra.read(o2))

@@ -8,13 +8,15 @@
 // the tile out flat over its 256 threads.  A sample is owned by the tile that holds floor(X), floor(Y), so
 // every sample is produced exactly once, with the reference's own coordinate arithmetic, weights and
 // accumulation order (xu outer, yu inner): TRON_KB_EXACT is bit-identical to the reference loop.
+#include <stdlib.h>
+
 #include "tron_device.h"
 
 namespace tron {
 
 constexpr int kDgTile = 32;
 constexpr int kDgThreads = 256;
-constexpr int kDgMaxSpokes = 512;
+constexpr int kDgMaxSpokes = 256;   // spokes clipped per round (one per thread)
 
 template <int CPB, int CW>
 struct DgLds {
@@ -23,9 +25,29 @@ struct DgLds {
     int sp_pe[kDgMaxSpokes];
     int sp_seg[kDgMaxSpokes];          // ro_lo | len << 16
     int sp_start[kDgMaxSpokes + 1];   // exclusive scan of len
+    float2 sp_cs[kDgMaxSpokes];        // (cos, sin) of the accepted spokes: the sample loop stays off global memory
     int wcnt[8];
-    float2 tile[TS * TS * CPB];        // [coil][row][col]: neighbouring samples read neighbouring banks
+    float2 tile[TS * TS * CPB + 8];    // [coil][row][col]: neighbouring samples read neighbouring banks; zeroed pad
 };
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// Two Kaiser-Bessel weights at once (v_pk_fma_f32): component-wise the same fmaf chain as kb_weight<TRON_KB_FAST>.
+__device__ __forceinline__ v2f kb_weight_fast2(const v2f x, const KbCoef &k)
+{
+    const v2f r = x * k.invW;
+    const v2f one = {1.0f, 1.0f};
+    const v2f s = __builtin_elementwise_fma(-r, r, one);
+    v2f acc = {k.poly[0], k.poly[0]};
+#pragma unroll
+    for (int t = 1; t < kKbPolyTerms; ++t) {
+        const v2f c = {k.poly[t], k.poly[t]};
+        acc = __builtin_elementwise_fma(acc, s, c);
+    }
+    if (!(fabsf(x.x) < k.W)) acc.x = 0.0f;
+    if (!(fabsf(x.y) < k.W)) acc.y = 0.0f;
+    return acc;
+}
 
 template <int CPB, int CW, int KB>
 __global__ void __launch_bounds__(kDgThreads) degrid_tile_kernel(const DegridParams p)
@@ -38,8 +60,9 @@ __global__ void __launch_bounds__(kDgThreads) degrid_tile_kernel(const DegridPar
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = p.n;
     const int tpr = (n + kDgTile - 1) / kDgTile;
-    const int tile = blockIdx.x % (tpr * tpr);
-    const int k = blockIdx.x / (tpr * tpr);                    // image
+    // centre tiles hold the most samples (density ~ 1/r): they are dispatched first, all images of a tile together
+    const int tile = p.tile_order ? p.tile_order[blockIdx.x / p.nimg] : (int)(blockIdx.x % (tpr * tpr));
+    const int k = p.tile_order ? (int)(blockIdx.x % p.nimg) : (int)(blockIdx.x / (tpr * tpr));   // image
     const int c0 = blockIdx.y * CPB;
     const int ncb = min(CPB, p.nrep - c0);
     const int tx0 = (tile / tpr) * kDgTile;                     // first row (sine axis, "X" of the reference)
@@ -52,23 +75,42 @@ __global__ void __launch_bounds__(kDgThreads) degrid_tile_kernel(const DegridPar
     const float W = p.W;
 
     // ---- tile + halo -> LDS (periodic wrap of src/tron.cu:569-570; fftshift(INVERSE) of :646 folded in)
-    const float2 *src = p.udata + (size_t)k * p.in_z;
-    for (int e = tid; e < TS * TS * CPB; e += kDgThreads) {
-        const int c = e / (TS * TS), rc = e % (TS * TS);
-        const int r = rc / TS, col = rc % TS;
-        int i = tx0 - HALO + r, j = ty0 - HALO + col;               // wrap without integer division
-        while (i < 0) i += n;
-        while (i >= n) i -= n;
-        while (j < 0) j += n;
-        while (j >= n) j -= n;
-        if (p.in_shift) {
-            i += n / 2; if (i >= n) i -= n;
-            j += n / 2; if (j >= n) j -= n;
+    const float2 *src = p.udata + (size_t)k * p.in_z + (size_t)c0 * p.in_c;
+    {
+        // every load of the tile is issued before the first LDS store: one HBM latency per block, not one per pass
+        constexpr int NIT = (TS * TS + kDgThreads - 1) / kDgThreads;
+        float2 stage[NIT][CPB];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int e = tid + it * kDgThreads;
+            const int r = e / TS, col = e - r * TS;
+            int i = tx0 - HALO + r, j = ty0 - HALO + col;               // periodic wrap, src/tron.cu:569-570
+            if (n >= TS) {                                              // -n <= i < 2n: one step each way
+                i += i < 0 ? n : 0; i -= i >= n ? n : 0;
+                j += j < 0 ? n : 0; j -= j >= n ? n : 0;
+            } else {
+                i %= n; i += i < 0 ? n : 0;
+                j %= n; j += j < 0 ? n : 0;
+            }
+            if (p.in_shift) {
+                i += n / 2; if (i >= n) i -= n;
+                j += n / 2; if (j >= n) j -= n;
+            }
+            const float2 *s = src + ((size_t)i * n + j) * p.in_p;
+#pragma unroll
+            for (int c = 0; c < CPB; ++c)
+                stage[it][c] = (e < TS * TS && c < ncb) ? s[(size_t)c * p.in_c] : make_float2(0.f, 0.f);
         }
-        float2 v = make_float2(0.f, 0.f);
-        if (c < ncb) v = src[((size_t)i * n + j) * p.in_p + (size_t)(c0 + c) * p.in_c];
-        L.tile[c * (TS * TS) + r * TS + col] = v;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int e = tid + it * kDgThreads;
+            if (e < TS * TS) {
+#pragma unroll
+                for (int c = 0; c < CPB; ++c) L.tile[c * (TS * TS) + e] = stage[it][c];
+            }
+        }
     }
+    if (tid < 8) L.tile[TS * TS * CPB + tid] = make_float2(0.f, 0.f);
 
     const float half = (float)((n + 1) / 2);                    // src/tron.cu:560-561
     const float eps = 0.01f;
@@ -84,8 +126,9 @@ __global__ void __launch_bounds__(kDgThreads) degrid_tile_kernel(const DegridPar
             const int pe = chunk0 + tid;
             bool accept = false;
             int rlo = 0, len = 0;
+            float2 cs = make_float2(0.f, 0.f);
             if (pe < p.npe && pe < round0 + kDgMaxSpokes) {
-                const float2 cs = p.trig[pe];
+                cs = p.trig[pe];
                 const float ax = (float)n * cs.y / (float)p.nro, ay = (float)n * cs.x / (float)p.nro;   // d/d(ro)
                 const float ox = half - 0.5f * (float)n * cs.y, oy = half - 0.5f * (float)n * cs.x;     // value at ro = 0
                 const float ix = safe_rcp(ax), iy = safe_rcp(ay);
@@ -115,6 +158,7 @@ __global__ void __launch_bounds__(kDgThreads) degrid_tile_kernel(const DegridPar
                 const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
                 L.sp_pe[slot] = pe;
                 L.sp_seg[slot] = (rlo & 0xffff) | (len << 16);
+                L.sp_cs[slot] = cs;
             }
             nacc += total;
             __syncthreads();
@@ -144,17 +188,26 @@ __global__ void __launch_bounds__(kDgThreads) degrid_tile_kernel(const DegridPar
 
         // ---- samples, dealt out flat over the 256 threads -------------------------------------------
         for (int rec = tid; rec < nrec; rec += kDgThreads) {
-          {
-            int lo = 0, hi = nacc - 1;
-            while (lo < hi) {
-                const int mid = (lo + hi + 1) >> 1;
-                if (L.sp_start[mid] <= rec) lo = mid; else hi = mid - 1;
+            // spoke holding record `rec`: largest s with sp_start[s] <= rec.  8-ary search: the seven
+            // splitters of a round are independent LDS reads, so a round costs one LDS latency.
+            int lo = 0, span = nacc;
+            while (span > 1) {
+                const int step = (span + 7) >> 3;
+                const int end = lo + span;
+                int sv[7];
+#pragma unroll
+                for (int j = 1; j < 8; ++j) sv[j - 1] = L.sp_start[min(lo + j * step, kDgMaxSpokes)];   // unconditional: one batch
+                int cnt = 0;
+#pragma unroll
+                for (int j = 1; j < 8; ++j) cnt += (lo + j * step < end && sv[j - 1] <= rec) ? 1 : 0;
+                lo += cnt * step;
+                span = min(step, end - lo);
             }
             const int pe = L.sp_pe[lo];
             const int ro = (L.sp_seg[lo] & 0xffff) + (rec - L.sp_start[lo]);
             // thread's polar and Cartesian coordinates, src/tron.cu:554-561
             const float R = (float)ro / (float)p.nro - 0.5f;
-            const float2 cs = p.trig[pe];
+            const float2 cs = L.sp_cs[lo];
             float X = cs.y, Y = cs.x;                                   // X = sin, Y = cos (src/tron.cu:559)
             X = (float)n * R * X + half;
             Y = (float)n * R * Y + half;
@@ -162,47 +215,92 @@ __global__ void __launch_bounds__(kDgThreads) degrid_tile_kernel(const DegridPar
             const int fy = min(max((int)floorf(Y), 0), n - 1);
             if ((unsigned)(fx - tx0) >= (unsigned)kDgTile || (unsigned)(fy - ty0) >= (unsigned)kDgTile) continue;
 
-            const int yu0 = (int)ceilf(Y - W);
-            float wy[2 * CW + 1];                                    // at most floor(2W)+1 integers in [Y-W, Y+W]
-            int ny = 0;
-#pragma unroll
-            for (int t = 0; t < 2 * CW + 1; ++t) {
-                wy[t] = 0.f;
-                if ((float)(yu0 + t) <= (Y + W)) {                      // src/tron.cu:566
-                    wy[t] = kb_weight<KB>((float)(yu0 + t) - Y, kb);
-                    ny = t + 1;
-                }
-            }
+            constexpr int NS = 2 * CW + 1;                              // at most floor(2W)+1 integers in [X-W, X+W]
+            const int xu0 = (int)ceilf(X - W), yu0 = (int)ceilf(Y - W);
+            const int lrow0 = HALO - tx0, lcol0 = yu0 + HALO - ty0;
             float2 acc[CPB];
 #pragma unroll
             for (int c = 0; c < CPB; ++c) acc[c] = make_float2(0.f, 0.f);
-            const int lrow0 = HALO - tx0, lcol0 = yu0 + HALO - ty0;
-            for (int xu = (int)ceilf(X - W); (float)xu <= (X + W); ++xu) {     // src/tron.cu:563
-                const float wgtx = kb_weight<KB>((float)xu - X, kb);
-                const float2 *trow = L.tile + (xu + lrow0) * TS + lcol0;
+
+            if (KB == TRON_KB_FAST) {
+                // all weights first, as interleaved packed polynomials (x and y of a slot share an instruction).
+                // 2*CW slots suffice: [X-W, X+W] holds more integers only when both end points sit at distance
+                // exactly W, where the weight is 0; a slot with |d| >= W gets weight 0, which is what skipping it
+                // (src/tron.cu:563,566) amounts to.  Then NF x NF fixed-offset LDS reads.
+                constexpr int NF = 2 * CW;
+                v2f sxy[NF], wxy[NF];
+                const v2f one = {1.0f, 1.0f};
 #pragma unroll
-                for (int t = 0; t < 2 * CW + 1; ++t) {
-                    if (t < ny) {
-                        const float wgt = wgtx * wy[t];                         // src/tron.cu:568
+                for (int t = 0; t < NF; ++t) {
+                    const v2f dxy = {(float)(xu0 + t) - X, (float)(yu0 + t) - Y};
+                    const v2f r = dxy * kb.invW;
+                    sxy[t] = __builtin_elementwise_fma(-r, r, one);
+                    // outside the window: s <- 1 - (W/W)^2 keeps the polynomial finite, the weight is zeroed below
+                    wxy[t] = (v2f){kb.poly[0], kb.poly[0]};
+                }
+#pragma unroll
+                for (int k = 1; k < kKbPolyTerms; ++k) {
+                    const v2f c = {kb.poly[k], kb.poly[k]};
+#pragma unroll
+                    for (int t = 0; t < NF; ++t) wxy[t] = __builtin_elementwise_fma(wxy[t], sxy[t], c);
+                }
+                float wx[NF], wy[NF];
+#pragma unroll
+                for (int t = 0; t < NF; ++t) {
+                    wx[t] = fabsf((float)(xu0 + t) - X) < W ? wxy[t].x : 0.0f;
+                    wy[t] = fabsf((float)(yu0 + t) - Y) < W ? wxy[t].y : 0.0f;
+                }
+                const float2 *t0 = L.tile + (xu0 + lrow0) * TS + lcol0;
+#pragma unroll
+                for (int sx = 0; sx < NF; ++sx)
+#pragma unroll
+                    for (int t = 0; t < NF; ++t) {
+                        const float wgt = wx[sx] * wy[t];                       // src/tron.cu:568
 #pragma unroll
                         for (int c = 0; c < CPB; ++c) {
-                            const float2 v = trow[c * (TS * TS) + t];
-                            if (KB == TRON_KB_EXACT) {
-                                acc[c].x += v.x * wgt;                          // src/tron.cu:573, unfused
+                            const float2 v = t0[c * (TS * TS) + sx * TS + t];
+                            acc[c].x = fmaf(v.x, wgt, acc[c].x);                // src/tron.cu:573
+                            acc[c].y = fmaf(v.y, wgt, acc[c].y);
+                        }
+                    }
+            } else {
+                float wy[NS];
+                int ny = 0;
+#pragma unroll
+                for (int t = 0; t < NS; ++t) {
+                    wy[t] = 0.f;
+                    if ((float)(yu0 + t) <= (Y + W)) {                      // src/tron.cu:566
+                        wy[t] = kb_weight<KB>((float)(yu0 + t) - Y, kb);
+                        ny = t + 1;
+                    }
+                }
+                for (int xu = xu0; (float)xu <= (X + W); ++xu) {               // src/tron.cu:563
+                    const float wgtx = kb_weight<KB>((float)xu - X, kb);
+                    const float2 *trow = L.tile + (xu + lrow0) * TS + lcol0;
+#pragma unroll
+                    for (int t = 0; t < NS; ++t) {
+                        if (t < ny) {
+                            const float wgt = wgtx * wy[t];                         // src/tron.cu:568
+#pragma unroll
+                            for (int c = 0; c < CPB; ++c) {
+                                const float2 v = trow[c * (TS * TS) + t];
+                                acc[c].x += v.x * wgt;                              // src/tron.cu:573, unfused
                                 acc[c].y += v.y * wgt;
-                            } else {
-                                acc[c].x = fmaf(v.x, wgt, acc[c].x);
-                                acc[c].y = fmaf(v.y, wgt, acc[c].y);
                             }
                         }
                     }
                 }
             }
             float2 *o = dst + ((size_t)pe * p.nro + ro) * p.nrep + c0;
+            if (CPB % 2 == 0 && ncb == CPB && (p.nrep & 1) == 0) {          // c0 is a multiple of CPB: 16-byte aligned
 #pragma unroll
-            for (int c = 0; c < CPB; ++c)
-                if (c < ncb) o[c] = acc[c];
-          }
+                for (int c = 0; c < CPB; c += 2)
+                    *reinterpret_cast<float4 *>(o + c) = make_float4(acc[c].x, acc[c].y, acc[c + 1].x, acc[c + 1].y);
+            } else {
+#pragma unroll
+                for (int c = 0; c < CPB; ++c)
+                    if (c < ncb) o[c] = acc[c];
+            }
         }
         __syncthreads();
     }
@@ -226,12 +324,15 @@ static hipError_t launch_degrid_tile_cpb(const DegridParams &p, int kb_mode, hip
 template <int CW>
 static hipError_t launch_degrid_tile_cw(const DegridParams &p, int kb_mode, hipStream_t s)
 {
+    static const int force = getenv("TRON_DEGRID_CPB") ? atoi(getenv("TRON_DEGRID_CPB")) : 0;   // tuning knob
+    if (force == 2) return launch_degrid_tile_cpb<2, CW>(p, kb_mode, s);
+    if (force == 1) return launch_degrid_tile_cpb<1, CW>(p, kb_mode, s);
     if (p.nrep >= 4) return launch_degrid_tile_cpb<4, CW>(p, kb_mode, s);
     if (p.nrep >= 2) return launch_degrid_tile_cpb<2, CW>(p, kb_mode, s);
     return launch_degrid_tile_cpb<1, CW>(p, kb_mode, s);
 }
 
-// Requires n >= 32 + 2*(ceil(W)+1) (the halo must not wrap onto the tile itself) and W <= 3.
+// Requires W <= 3 (any n: the halo wraps periodically, onto the tile itself when n is small).
 hipError_t launch_degrid_tile(const DegridParams &p, int kb_mode, hipStream_t s)
 {
     const int cw = (int)ceilf(p.W);

@@ -52,6 +52,7 @@ struct DegridParams {
     const float2 *udata;      // Cartesian input
     float2 *nudata;           // [image][nrep*(ro + nro*pe) + c]
     const float2 *trig;       // (cos, sin) per spoke
+    const int *tile_order;    // degrid_tile_kernel: 32x32 tiles, centre first (nullptr: raster order)
     long long in_z, in_c;     // input strides per image and per coil
     int in_p, in_shift;       // pixel stride; 1: input is the raw FFT output (second fftshift folded into indexing)
     int n, nrep, nro, npe, nimg;

@@ -6,7 +6,9 @@
 //        [-r nro] [-s skip_angles] [-T threads] [-u data_undersamp] <infile.ra> [outfile.ra]
 //
 // Extensions, via the environment so the flag set stays the reference's:
-//   TRON_KB_MODE=exact|fast    Kaiser-Bessel evaluation (default exact)
+//   TRON_KB_MODE=fast|exact    Kaiser-Bessel evaluation.  fast (default): polynomial window + binned gridding,
+//                              within 1e-5 relative L2 of the reference arithmetic (measured ~1e-7);
+//                              exact: the reference's expression tree and summation order, bit for bit
 //   TRON_CHUNK_SLICES=n        slices per device batch
 // A complex-half input (eltype 4, elbyte 4) is accepted for -a and gridded from half storage.
 #include <stdio.h>
@@ -73,7 +75,8 @@ int main(int argc, char *argv[])
     }
     const char *infile = argv[optind];
     const char *outfile = optind + 1 < argc ? argv[optind + 1] : "img_tron.ra";   // src/tron.cu:877
-    if (const char *kb = getenv("TRON_KB_MODE")) cfg.kb_mode = strcmp(kb, "fast") == 0 ? TRON_KB_FAST : TRON_KB_EXACT;
+    cfg.kb_mode = TRON_KB_FAST;
+    if (const char *kb = getenv("TRON_KB_MODE")) cfg.kb_mode = strcmp(kb, "exact") == 0 ? TRON_KB_EXACT : TRON_KB_FAST;
 
 #define VPRINT(...) do { if (cfg.verbose) printf(__VA_ARGS__); } while (0)
 

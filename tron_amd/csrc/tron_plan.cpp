@@ -347,6 +347,7 @@ int forward_run(tron_plan *p, void *d_out, const void *d_in, int nimg)
         g.udata = p->d_grid;
         g.nudata = static_cast<float2 *>(d_out) + (size_t)k0 * p->nchan * d.nro * d.npe1work;
         g.trig = p->d_trig;
+        g.tile_order = p->d_tile_order32;
         g.in_z = (long long)p->nchan * n2;
         g.in_c = (long long)n2;
         g.in_p = 1;
@@ -462,6 +463,11 @@ extern "C" int tron_plan_create(tron_plan **out, const tron_config *cfg, const t
         build_trig_table(*cfg, d, trig.data(), p->ntrig);
         if ((rc = upload(&p->d_trig, trig.data(), trig.size() * sizeof(float)))) return bail(rc);
     }
+    {   // 32x32 tiles, centre first: binned gridding and tiled degridding
+        std::vector<int> order;
+        build_tile_order(d.nxos, kBinnedTile, order);
+        if ((rc = upload(&p->d_tile_order32, order.data(), order.size() * sizeof(int)))) return bail(rc);
+    }
     if (cfg->adjoint) {
         std::vector<uint32_t> band(n2);
         build_band_table(d.nxos, cfg->kernwidth, band.data());
@@ -471,8 +477,6 @@ extern "C" int tron_plan_create(tron_plan **out, const tron_config *cfg, const t
         p->tiles_per_row = (d.nxos + kTile - 1) / kTile;
         p->ntiles = (int)order.size();
         if ((rc = upload(&p->d_tile_order, order.data(), order.size() * sizeof(int)))) return bail(rc);
-        build_tile_order(d.nxos, kBinnedTile, order);
-        if ((rc = upload(&p->d_tile_order32, order.data(), order.size() * sizeof(int)))) return bail(rc);
         p->binned = p->kb_mode == TRON_KB_FAST && cfg->kernwidth <= 3.f;
         if (const char *gk = getenv("TRON_GRID_KERNEL")) p->binned = p->binned && strcmp(gk, "gather") != 0;
         std::vector<float> dea((size_t)d.nx * d.nx);
@@ -505,7 +509,24 @@ extern "C" int tron_plan_create(tron_plan **out, const tron_config *cfg, const t
         p->dual = false;
         if (const char *ds = getenv("TRON_DUAL_STREAM")) p->dual = d.nz > 1 && atoi(ds) != 0;
         if (p->dual) {
-            if (hipStreamCreateWithFlags(&p->stream2, hipStreamNonBlocking) != hipSuccess)
+            // TRON_CU_SPLIT=k: give the (HBM-bound) FFT lane every k-th CU and the (VALU/LDS-bound) gridding lane
+            // the rest, so the two overlap in space instead of queueing behind each other
+            int split = 0;
+            if (const char *cs = getenv("TRON_CU_SPLIT")) split = atoi(cs);
+            if (split >= 2) {
+                uint32_t mask_fft[8], mask_grid[8];
+                for (int w = 0; w < 8; ++w) { mask_fft[w] = 0; mask_grid[w] = 0; }
+                for (int cu = 0; cu < 256; ++cu) {
+                    if (cu % split == 0) mask_fft[cu / 32] |= 1u << (cu % 32);
+                    else mask_grid[cu / 32] |= 1u << (cu % 32);
+                }
+                hipStream_t masked = nullptr;
+                if (hipExtStreamCreateWithCUMask(&p->stream2, 8, mask_fft) != hipSuccess ||
+                    hipExtStreamCreateWithCUMask(&masked, 8, mask_grid) != hipSuccess)
+                    return bail(fail(TRON_ERR_HIP, "cannot create CU-masked streams"));
+                hipStreamDestroy(p->stream);
+                p->stream = masked;
+            } else if (hipStreamCreateWithFlags(&p->stream2, hipStreamNonBlocking) != hipSuccess)
                 return bail(fail(TRON_ERR_HIP, "cannot create the FFT lane"));
             for (int i = 0; i < 2; ++i)
                 if (hipEventCreateWithFlags(&p->ev_g[i], hipEventDisableTiming) != hipSuccess ||
@@ -696,6 +717,7 @@ extern "C" int tron_degridradial2d(tron_plan *p, void *d_nudata, const void *d_u
     g.udata = static_cast<const float2 *>(d_udata);
     g.nudata = static_cast<float2 *>(d_nudata);
     g.trig = p->d_trig;
+    g.tile_order = p->d_tile_order32;
     g.in_z = 0;
     g.in_c = 1;                           // udata[nrep*(i*n+j) + c], src/tron.cu:571-573
     g.in_p = p->nchan;
