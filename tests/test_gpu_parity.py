@@ -200,6 +200,23 @@ def test_metric_size_pipeline_vs_oracle(oracle, monkeypatch, nc, kb):
     assert rel_l2(got, ref) <= 2e-6
 
 
+@pytest.mark.parametrize("nc,kb", [(1, lib.KB_EXACT), (2, lib.KB_FAST), (8, lib.KB_FAST)])
+def test_metric_size_forward_vs_oracle(oracle, monkeypatch, nc, kb):
+    """256^2 image -> 512^2 grid -> 512-point spokes: the shape the fused pruned forward FFT (pad + deapodise +
+    shift + FFT, tron_fft512.hip) is specialised for.  Checked against the oracle and against the
+    pre_kernel + rocFFT path."""
+    img = synth.image(nc, 256, seed=717)
+    flags = dict(golden_angle=1, data_undersamp=40 / 512 + 1e-6)
+    want, p = oracle.recon(img, adjoint=0, golden=1, data_undersamp=40 / 512 + 1e-6)
+    assert (p.nxos, p.nx, p.nro, p.npe1work) == (512, 256, 512, 40)
+    got, _ = lib.recon(img, adjoint=False, kb_mode=kb, **flags)
+    assert rel_l2(got, want) <= TOL_PIPELINE
+    monkeypatch.setenv("TRON_FFT", "rocfft")
+    ref, _ = lib.recon(img, adjoint=False, kb_mode=kb, **flags)
+    assert rel_l2(ref, want) <= TOL_PIPELINE
+    assert rel_l2(got, ref) <= 2e-6
+
+
 def test_half_precision_kspace_input(oracle):
     """Config 5: k-space stored as complex-half (.ra eltype 4 / elbyte 4), converted with the reference's
     round-to-nearest-even (src/float16.cu); gridded from half storage with fp32 accumulation.  Parity is

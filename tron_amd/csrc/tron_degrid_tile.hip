@@ -83,7 +83,8 @@ __global__ void __launch_bounds__(kDgThreads) degrid_tile_kernel(const DegridPar
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int e = tid + it * kDgThreads;
-            const int r = e / TS, col = e - r * TS;
+            const int ea = e / TS, eb = e - ea * TS;
+            const int r = p.in_transposed ? eb : ea, col = p.in_transposed ? ea : eb;   // the fastest index follows memory
             int i = tx0 - HALO + r, j = ty0 - HALO + col;               // periodic wrap, src/tron.cu:569-570
             if (n >= TS) {                                              // -n <= i < 2n: one step each way
                 i += i < 0 ? n : 0; i -= i >= n ? n : 0;
@@ -96,7 +97,7 @@ __global__ void __launch_bounds__(kDgThreads) degrid_tile_kernel(const DegridPar
                 i += n / 2; if (i >= n) i -= n;
                 j += n / 2; if (j >= n) j -= n;
             }
-            const float2 *s = src + ((size_t)i * n + j) * p.in_p;
+            const float2 *s = src + (p.in_transposed ? (size_t)j * n + i : (size_t)i * n + j) * p.in_p;
 #pragma unroll
             for (int c = 0; c < CPB; ++c)
                 stage[it][c] = (e < TS * TS && c < ncb) ? s[(size_t)c * p.in_c] : make_float2(0.f, 0.f);
@@ -104,9 +105,11 @@ __global__ void __launch_bounds__(kDgThreads) degrid_tile_kernel(const DegridPar
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int e = tid + it * kDgThreads;
+            const int ea = e / TS, eb = e - ea * TS;
+            const int slot = p.in_transposed ? eb * TS + ea : e;
             if (e < TS * TS) {
 #pragma unroll
-                for (int c = 0; c < CPB; ++c) L.tile[c * (TS * TS) + e] = stage[it][c];
+                for (int c = 0; c < CPB; ++c) L.tile[c * (TS * TS) + slot] = stage[it][c];
             }
         }
     }

@@ -55,6 +55,7 @@ struct DegridParams {
     const int *tile_order;    // degrid_tile_kernel: 32x32 tiles, centre first (nullptr: raster order)
     long long in_z, in_c;     // input strides per image and per coil
     int in_p, in_shift;       // pixel stride; 1: input is the raw FFT output (second fftshift folded into indexing)
+    int in_transposed;        // degrid_tile_kernel: input planes are stored [col][row] (fused forward FFT)
     int n, nrep, nro, npe, nimg;
     float W, beta;
     float kb_poly[kKbPolyTerms];
@@ -78,5 +79,8 @@ hipError_t launch_degrid_tile(const DegridParams &p, int kb_mode, hipStream_t s)
 // fused pruned inverse FFT + crop + deapodise + SoS for nxos = 512, nx = 256 (tron_fft512.hip)
 hipError_t launch_fft512_adjoint(const float2 *grid, float2 *tmp, float2 *out, const float2 *tw, const float *inv_deapod,
                                  int nchan, int nslices, hipStream_t s);
+// fused pad + deapodise + shift + pruned forward FFT for nx = 256, nxos = 512 (tron_fft512.hip)
+hipError_t launch_fft512_forward(const float2 *img, float2 *tmp, float2 *out, const float2 *tw, const float *inv_deapod,
+                                 int nchan, int nimg, hipStream_t s);
 
 }  // namespace tron

@@ -419,7 +419,7 @@ __global__ void __launch_bounds__(256) degrid_kernel(const DegridParams p)
                 int i = (xu + n) % n;                                 // src/tron.cu:569-570
                 int j = (yu + n) % n;
                 if (p.in_shift) { i = (i + n / 2) % n; j = (j + n / 2) % n; }   // fftshift(INVERSE) of :646 folded in
-                const float2 *u = src + ((size_t)i * n + j) * p.in_p;
+                const float2 *u = src + (p.in_transposed ? (size_t)j * n + i : (size_t)i * n + j) * p.in_p;
 #pragma unroll
                 for (int c = 0; c < CPB; ++c)
                     if (c0 + c < p.nrep) {

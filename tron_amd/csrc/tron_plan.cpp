@@ -328,20 +328,27 @@ int forward_run(tron_plan *p, void *d_out, const void *d_in, int nimg)
     const size_t n2 = (size_t)d.nxos * d.nxos;
     for (int k0 = 0; k0 < nimg; k0 += p->chunk) {
         const int ck = std::min(p->chunk, nimg - k0);
-        PreParams a;
-        a.img = static_cast<const float2 *>(d_in) + (size_t)k0 * p->nchan * d.nx * d.nx;
-        a.fft = p->d_grid;
-        a.inv_deapod = p->d_deapod;
-        a.nx = d.nx;
-        a.nxos = d.nxos;
-        a.nchan = p->nchan;
-        a.nimg = ck;
-        {
-            StageTimer t(p, STAGE_PRE);
-            HIP_TRY(launch_pre(a, p->stream));
+        const float2 *img = static_cast<const float2 *>(d_in) + (size_t)k0 * p->nchan * d.nx * d.nx;
+        if (p->fft512) {
+            // fused: pad + deapodise + shift + pruned forward FFT (tron_fft512.hip)
+            StageTimer t(p, STAGE_FFT);
+            HIP_TRY(launch_fft512_forward(img, p->d_fft_tmp, p->d_grid, p->d_tw512, p->d_deapod, p->nchan, ck, p->stream));
+        } else {
+            PreParams a;
+            a.img = img;
+            a.fft = p->d_grid;
+            a.inv_deapod = p->d_deapod;
+            a.nx = d.nx;
+            a.nxos = d.nxos;
+            a.nchan = p->nchan;
+            a.nimg = ck;
+            {
+                StageTimer t(p, STAGE_PRE);
+                HIP_TRY(launch_pre(a, p->stream));
+            }
+            int rc = run_fft(p, p->d_grid, ck * p->nchan, 0);
+            if (rc) return rc;
         }
-        int rc = run_fft(p, p->d_grid, ck * p->nchan, 0);
-        if (rc) return rc;
         DegridParams g;
         memset(&g, 0, sizeof(g));
         g.udata = p->d_grid;
@@ -352,6 +359,7 @@ int forward_run(tron_plan *p, void *d_out, const void *d_in, int nimg)
         g.in_c = (long long)n2;
         g.in_p = 1;
         g.in_shift = 1;
+        g.in_transposed = p->fft512 ? 1 : 0;      // launch_fft512_forward stores the grid transposed
         g.n = d.nxos;
         g.nrep = p->nchan;
         g.nro = d.nro;
@@ -491,7 +499,7 @@ extern "C" int tron_plan_create(tron_plan **out, const tron_config *cfg, const t
     if ((rc = upload(&p->d_errflag, &zero, sizeof(zero)))) return bail(rc);
     if (hipMalloc(reinterpret_cast<void **>(&p->d_grid), (size_t)p->chunk * per_unit) != hipSuccess)
         return bail(fail(TRON_ERR_NOMEM, "cannot allocate %zu bytes of Cartesian work space", (size_t)p->chunk * per_unit));
-    if (cfg->adjoint && d.nxos == 512 && d.nx == 256) {
+    if (d.nxos == 512 && d.nx == 256) {
         p->fft512 = true;
         if (const char *ff = getenv("TRON_FFT")) p->fft512 = strcmp(ff, "rocfft") != 0;
     }
