@@ -30,25 +30,6 @@ struct DgLds {
     float2 tile[TS * TS * CPB + 8];    // [coil][row][col]: neighbouring samples read neighbouring banks; zeroed pad
 };
 
-typedef float v2f __attribute__((ext_vector_type(2)));
-
-// Two Kaiser-Bessel weights at once (v_pk_fma_f32): component-wise the same fmaf chain as kb_weight<TRON_KB_FAST>.
-__device__ __forceinline__ v2f kb_weight_fast2(const v2f x, const KbCoef &k)
-{
-    const v2f r = x * k.invW;
-    const v2f one = {1.0f, 1.0f};
-    const v2f s = __builtin_elementwise_fma(-r, r, one);
-    v2f acc = {k.poly[0], k.poly[0]};
-#pragma unroll
-    for (int t = 1; t < kKbPolyTerms; ++t) {
-        const v2f c = {k.poly[t], k.poly[t]};
-        acc = __builtin_elementwise_fma(acc, s, c);
-    }
-    if (!(fabsf(x.x) < k.W)) acc.x = 0.0f;
-    if (!(fabsf(x.y) < k.W)) acc.y = 0.0f;
-    return acc;
-}
-
 template <int CPB, int CW, int KB>
 __global__ void __launch_bounds__(kDgThreads) degrid_tile_kernel(const DegridParams p)
 {

@@ -57,6 +57,25 @@ __device__ __forceinline__ float kb_weight(const float x, const KbCoef &k)
     }
 }
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// Two Kaiser-Bessel weights at once (v_pk_fma_f32): component-wise the same fmaf chain as kb_weight<TRON_KB_FAST>.
+__device__ __forceinline__ v2f kb_weight_fast2(const v2f x, const KbCoef &k)
+{
+    const v2f r = x * k.invW;
+    const v2f one = {1.0f, 1.0f};
+    const v2f s = __builtin_elementwise_fma(-r, r, one);
+    v2f acc = {k.poly[0], k.poly[0]};
+#pragma unroll
+    for (int t = 1; t < kKbPolyTerms; ++t) {
+        const v2f c = {k.poly[t], k.poly[t]};
+        acc = __builtin_elementwise_fma(acc, s, c);
+    }
+    if (!(fabsf(x.x) < k.W)) acc.x = 0.0f;
+    if (!(fabsf(x.y) < k.W)) acc.y = 0.0f;
+    return acc;
+}
+
 __device__ __forceinline__ float safe_rcp(float c)
 {
     return fabsf(c) > 1e-12f ? 1.0f / c : copysignf(1e12f, c);

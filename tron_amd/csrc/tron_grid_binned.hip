@@ -270,10 +270,28 @@ grid_binned_kernel(const GridParams p)
                 float *wxr = L.wx + rec * C::NWP, *wyr = L.wy + rec * C::NWP;
                 wxr[0] = 0.f; wxr[C::NWP - 1] = 0.f;
                 wyr[0] = 0.f; wyr[C::NWP - 1] = 0.f;
+                {   // the 2 x NW weights as NW interleaved packed polynomials (x and y share an instruction); each
+                    // component is the fmaf chain of kb_weight<TRON_KB_FAST>                    src/tron.cu:516
+                    v2f dxy[C::NW], sxy[C::NW], wxy[C::NW];
+                    const v2f one = {1.0f, 1.0f};
 #pragma unroll
-                for (int i = 0; i < C::NW; ++i) {
-                    wxr[1 + i] = kb_weight<TRON_KB_FAST>(kx - (float)(bx + i), kb);       // src/tron.cu:516
-                    wyr[1 + i] = kb_weight<TRON_KB_FAST>(ky - (float)(by + i), kb);
+                    for (int i = 0; i < C::NW; ++i) {
+                        dxy[i] = (v2f){kx - (float)(bx + i), ky - (float)(by + i)};
+                        const v2f rr = dxy[i] * kb.invW;
+                        sxy[i] = __builtin_elementwise_fma(-rr, rr, one);
+                        wxy[i] = (v2f){kb.poly[0], kb.poly[0]};
+                    }
+#pragma unroll
+                    for (int t = 1; t < kKbPolyTerms; ++t) {
+                        const v2f cf = {kb.poly[t], kb.poly[t]};
+#pragma unroll
+                        for (int i = 0; i < C::NW; ++i) wxy[i] = __builtin_elementwise_fma(wxy[i], sxy[i], cf);
+                    }
+#pragma unroll
+                    for (int i = 0; i < C::NW; ++i) {
+                        wxr[1 + i] = fabsf(dxy[i].x) < kb.W ? wxy[i].x : 0.0f;
+                        wyr[1 + i] = fabsf(dxy[i].y) < kb.W ? wxy[i].y : 0.0f;
+                    }
                 }
                 const int ro = (p.nro == n ? r : (r * p.nro) / n) + p.nro / 2;
                 float sdc = 1.0f;
