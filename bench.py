@@ -65,7 +65,8 @@ def main():
     ap.add_argument("--slices", type=int, default=256, help="slices per GPU per step")
     ap.add_argument("--kb", choices=["fast", "exact"], default="fast")
     ap.add_argument("--chunk", type=int, default=0, help="slices per internal batch (0 = auto)")
-    ap.add_argument("--cpu-slices", type=int, default=2, help="slices of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-slices", type=int, default=-1,
+                    help="slices of the CPU-baseline sample (0 = skip; -1 = sized for about 12 s of wall time, 2..32 slices)")
     ap.add_argument("--no-check", action="store_true")
     args = ap.parse_args()
 
@@ -170,8 +171,12 @@ def main():
     result = None
     if rank == 0:
         cpu = None
-        if args.cpu_slices > 0:
-            cpu, _ = cpu_baseline(nc, args.cpu_slices)
+        if args.cpu_slices != 0:
+            n_cpu = args.cpu_slices
+            if n_cpu < 0:                                     # one probe slice sizes the bounded sample
+                probe, _ = cpu_baseline(nc, 1)
+                n_cpu = max(2, min(32, int(round(12.0 * probe["value"]))))
+            cpu, _ = cpu_baseline(nc, n_cpu)
             cpu["value"] = round(cpu["value"], 4)
         if not args.no_check:
             # the timed path produced real images: spot-check one slice of this rank against the oracle

@@ -259,6 +259,65 @@ __global__ void __launch_bounds__(256) fft512_fwd_rows_kernel(const Fft512FwdPar
     }
 }
 
+// Same pass with coalesced input: a workgroup takes `rows` consecutive image rows with ALL their coils (contiguous in the
+// coil-interleaved image), copies them through LDS into per-(row, coil) lines and transforms lines wave by wave.
+// grid = (256/rows, nimg); block = 256; dynamic LDS = rows*nchan*kInPitch float2.
+constexpr int kInPitch = kFKeep + 4;    // 260: the 8 coils of a pixel land 8 banks apart, consecutive pixels 2 apart
+
+__global__ void __launch_bounds__(256) fft512_fwd_rows_lds_kernel(const Fft512FwdParams p, const int rows)
+{
+    __shared__ float2 s_x[4 * kXch];
+    extern __shared__ __align__(16) float2 s_in[];              // [row in block][coil][kInPitch]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k = blockIdx.y;
+    const int r0 = blockIdx.x * rows;
+    const int nlines = rows * p.nchan;
+    const int per_row = kFKeep * p.nchan;
+    const float2 *src = p.img + ((size_t)k * kFKeep + r0) * per_row;
+    for (int e0 = 0; e0 < rows * per_row; e0 += 4 * 256) {      // four coalesced loads in flight per thread
+        float2 ld[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * 256 + threadIdx.x;
+            ld[u] = e < rows * per_row ? src[e] : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * 256 + threadIdx.x;
+            if (e < rows * per_row) {
+                const int rl = e / per_row, rem = e - rl * per_row;
+                const int y = rem / p.nchan, c = rem - y * p.nchan;
+                s_in[(rl * p.nchan + c) * kInPitch + y] = ld[u];
+            }
+        }
+    }
+    __syncthreads();
+    float2 *xch = s_x + wave * kXch;
+    for (int L = wave; L < nlines; L += 4) {
+        const int rl = L / p.nchan, c = L - rl * p.nchan;
+        const int r = r0 + rl;
+        const float2 *lin = s_in + L * kInPitch;
+        float2 v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {                           // same index map as fft512_fwd_rows_kernel
+            const int q = t < 2 ? t : t + 4;
+            const int y = t < 2 ? 128 + 64 * q + lane : 64 * (q - 6) + lane;
+            if (r > 0 && y > 0) {                                                   // src/tron.cu:449-450
+                float2 u = lin[y];
+                const float inv = p.inv_deapod[(size_t)(r + 128) * kF + (y + 128)];
+                u.x *= inv; u.y *= inv;
+                v[q] = cconj(u);
+            }
+        }
+        fft512_inv(v, xch, p.tw, lane);
+        float2 *line = p.tmp + ((size_t)(k * p.nchan + c) * kFKeep + r) * kF;
+#pragma unroll
+        for (int j2 = 0; j2 < 8; ++j2) line[lane + 64 * j2] = cconj(v[j2]);
+    }
+}
+
 // grid = (512/16, nimg*nchan); block = 256.  Column k2 of the row-transformed block, written as one contiguous
 // line: out is the TRANSPOSE of the FFT-native grid, out[k2][k1] (the degridding kernel swaps its indices instead).
 __global__ void __launch_bounds__(256) fft512_fwd_cols_kernel(const Fft512FwdParams p)
@@ -312,7 +371,15 @@ hipError_t launch_fft512_forward(const float2 *img, float2 *tmp, float2 *out, co
 {
     Fft512FwdParams p;
     p.img = img; p.tmp = tmp; p.out = out; p.tw = tw; p.inv_deapod = inv_deapod; p.nchan = nchan;
-    hipLaunchKernelGGL(fft512_fwd_rows_kernel, dim3(kFKeep / kLinesPerWg, nimg * nchan), dim3(256), 0, s, p);
+    if (nchan > 1 && nchan <= 16) {
+        int rows = 16 / nchan;                                  // about 16 lines per workgroup
+        if (rows < 1) rows = 1;
+        while (kFKeep % rows) --rows;
+        const size_t lds = (size_t)rows * nchan * kInPitch * sizeof(float2);   // <= 33 KiB
+        hipLaunchKernelGGL(fft512_fwd_rows_lds_kernel, dim3(kFKeep / rows, nimg), dim3(256), lds, s, p, rows);
+    } else {
+        hipLaunchKernelGGL(fft512_fwd_rows_kernel, dim3(kFKeep / kLinesPerWg, nimg * nchan), dim3(256), 0, s, p);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(fft512_fwd_cols_kernel, dim3(kF / kLinesPerWg, nimg * nchan), dim3(256), 0, s, p);
