@@ -38,7 +38,7 @@ def algorithmic_bytes(nc):
     return dict(grid=grid, fft=fft, post=post_cs + 8 * NX * NX / nc, per_cs=per_cs, per_slice=per_slice)
 
 
-def cpu_baseline(nc, sample_slices):
+def cpu_baseline(nc, sample_slices, undersamp=0.7852):
     """The CPU oracle (oracle/, a port of the reference's own algorithm: point-driven gather
     over every spoke, src/tron.cu:465-536) on `sample_slices` slices of the same shape."""
     import numpy as np
@@ -48,11 +48,11 @@ def cpu_baseline(nc, sample_slices):
     threads = os.cpu_count() or 1
     data = synth.kspace(nc, NRO, NPE * sample_slices, seed=synth.SEED_BASE)
     t0 = time.perf_counter()
-    out, p = pyoracle.recon(data, adjoint=1, golden=1, data_undersamp=0.7852, prof_slide=NPE)
+    out, p = pyoracle.recon(data, adjoint=1, golden=1, data_undersamp=undersamp, prof_slide=NPE)
     dt = time.perf_counter() - t0
     assert p.nz == sample_slices and p.npe1work == NPE
     return dict(value=sample_slices / dt, unit="slices/s", cores=threads, kind="port",
-                sample=f"{sample_slices} slice(s) x {nc} coil(s) of 512x402 golden-angle through the full oracle pipeline "
+                sample=f"{sample_slices} slice(s) x {nc} coil(s) of 512x{NPE} golden-angle through the full oracle pipeline "
                        f"(OpenMP over grid points, {threads} threads), {dt:.1f} s wall"), out
 
 
@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--coils", type=int, default=8)
     ap.add_argument("--slices", type=int, default=256, help="slices per GPU per step")
+    ap.add_argument("--spokes", type=int, default=402, help="spokes per slice (402 = the metric's shape; BASELINE config 4 has 804)")
     ap.add_argument("--kb", choices=["fast", "exact"], default="fast")
     ap.add_argument("--chunk", type=int, default=0, help="slices per internal batch (0 = auto)")
     ap.add_argument("--cpu-slices", type=int, default=-1,
@@ -91,8 +92,11 @@ def main():
     import numpy as np
     from tron_amd import lib
 
+    global NPE
+    NPE = args.spokes
+    undersamp = 0.7852 if NPE == 402 else (NPE + 0.5) / NRO    # tron -u: npe1work = int(nro*u), src/tron.cu:925
     nc, nz = args.coils, args.slices
-    cfg = lib.default_config(adjoint=1, golden_angle=1, data_undersamp=0.7852, prof_slide=NPE, device=local_rank,
+    cfg = lib.default_config(adjoint=1, golden_angle=1, data_undersamp=undersamp, prof_slide=NPE, device=local_rank,
                              kb_mode=lib.KB_FAST if args.kb == "fast" else lib.KB_EXACT, chunk_slices=args.chunk)
     dims = lib.derive_dims(cfg, (nc, 1, NRO, NPE * nz, 1))
     assert (dims.nz, dims.npe1work, dims.nxos, dims.nx) == (nz, NPE, NXOS, NX)
@@ -159,7 +163,7 @@ def main():
         traffic = None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "round1_v3_traffic.json")))["per_coil_slice_bytes_corrected"]
-            if dom == "grid" and args.kb == "fast" and nc == 8:
+            if dom == "grid" and args.kb == "fast" and nc == 8 and NPE == 402:
                 t = tj["grid_binned_kernel"]
                 traffic = int((t["read"] + t["write"]) * units_per_launch)
         except Exception:
@@ -174,16 +178,16 @@ def main():
         if args.cpu_slices != 0:
             n_cpu = args.cpu_slices
             if n_cpu < 0:                                     # one probe slice sizes the bounded sample
-                probe, _ = cpu_baseline(nc, 1)
+                probe, _ = cpu_baseline(nc, 1, undersamp)
                 n_cpu = max(2, min(32, int(round(12.0 * probe["value"]))))
-            cpu, _ = cpu_baseline(nc, n_cpu)
+            cpu, _ = cpu_baseline(nc, n_cpu, undersamp)
             cpu["value"] = round(cpu["value"], 4)
         if not args.no_check:
             # the timed path produced real images: spot-check one slice of this rank against the oracle
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             from oracle import pyoracle
             host = kspace[: 2 * nc * NRO * NPE].cpu().numpy().view(np.complex64).reshape((nc, 1, NRO, NPE, 1), order="F")
-            want, _ = pyoracle.recon(host, adjoint=1, golden=1, data_undersamp=0.7852, prof_slide=NPE)
+            want, _ = pyoracle.recon(host, adjoint=1, golden=1, data_undersamp=undersamp, prof_slide=NPE)
             got = images[: 2 * NX * NX].cpu().numpy().view(np.complex64)
             err = float(np.linalg.norm(got - want.reshape(-1, order="F")) / np.linalg.norm(want))
             if not err <= 1e-5:
@@ -191,15 +195,32 @@ def main():
         else:
             err = None
         hbm_gbps = ab["per_slice"] * value / world / 1e9      # per GPU
+        # what a plain device-to-device copy reaches on this GPU (read + write bytes): the practical HBM ceiling
+        copy_gbps = None
+        try:
+            a = torch.empty(1 << 28, device="cuda", dtype=torch.float32)
+            b = torch.empty_like(a)
+            b.copy_(a)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                b.copy_(a)
+            e1.record()
+            torch.cuda.synchronize()
+            copy_gbps = round(5 * 2 * a.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+            del a, b
+        except Exception:
+            copy_gbps = None
         result = {
             "metric": "2D slices/sec gridded (512^2 grid, 512x402 golden-angle) + achieved HBM GB/s",
             "value": round(value, 1), "unit": "slices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"adjoint gridding recon: {nz} slices/GPU/step x {nc} coils, 512 readout x 402 golden-angle spokes "
-                                   f"-> 512^2 oversampled grid -> 256^2 image (tron -a -G -u 0.7852 -d 402)",
+            "config": {"workload": f"adjoint gridding recon: {nz} slices/GPU/step x {nc} coils, 512 readout x {NPE} golden-angle spokes "
+                                   f"-> 512^2 oversampled grid -> 256^2 image (tron -a -G -u {undersamp:.4f} -d {NPE})",
                        "coils": nc, "slices_per_gpu": nz, "kb_mode": args.kb, "parallelism": f"slices sharded over {world} GPU(s), no collective"},
             "hbm_gbps_per_gpu": round(hbm_gbps, 1), "hbm_frac_of_peak": round(hbm_gbps / HBM_PEAK_GBPS, 4),
+            "copy_ceiling_gbps": copy_gbps, "hbm_frac_of_copy_ceiling": round(hbm_gbps / copy_gbps, 4) if copy_gbps else None,
             "coil_slices_per_s": round(value * nc, 1),
             "parity_rel_l2_vs_oracle": err,
             "roofline": roofline, "cpu_baseline": cpu,

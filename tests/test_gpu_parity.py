@@ -291,3 +291,19 @@ def test_sharded_cli_single_rank(tmp_path):
     r = subprocess.run([sys.executable, "-m", "tron_amd.shard"] + argv + [inp, o2], cwd=root, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert np.array_equal(ra.read(o1), ra.read(o2))
+
+
+@pytest.mark.parametrize("kb", [lib.KB_EXACT, lib.KB_FAST])
+def test_many_spokes_clip_rounds(oracle, kb):
+    """More spokes than one clip round holds (512 in the binned gridding kernel, 256 in the gather and in the tiled
+    degridding kernel): BASELINE config 4 has 804 spokes per slice."""
+    data = synth.kspace(2, 64, 804, seed=1101)
+    want, p = oracle.recon(data, adjoint=1, golden=1, data_undersamp=13.0)
+    assert p.npe1work == 804 and p.nz == 1
+    got, _ = lib.recon(data, adjoint=True, kb_mode=kb, golden_angle=1, data_undersamp=13.0)
+    assert rel_l2(got, want) <= TOL_PIPELINE
+    img = synth.image(2, 32, seed=1102)
+    want, p = oracle.recon(img, adjoint=0, golden=1, data_undersamp=9.4)
+    assert p.npe1work == 601
+    got, _ = lib.recon(img, adjoint=False, kb_mode=kb, golden_angle=1, data_undersamp=9.4)
+    assert rel_l2(got, want) <= TOL_PIPELINE
