@@ -32,7 +32,7 @@ $(LIB): $(OBJ)/tron_kernels.o $(OBJ)/tron_grid_binned.o $(OBJ)/tron_fft512.o $(O
 
 $(BIN): $(OBJ)/tron_main.o $(LIB)
 	@mkdir -p tron_amd/bin
-	$(HIPCC) $(OBJ)/tron_main.o -o $@ -Ltron_amd/lib -ltronhip -Wl,-rpath,'$$ORIGIN/../lib' $(LDFLAGS)
+	$(HIPCC) $(OBJ)/tron_main.o -o $@ -Ltron_amd/lib -ltronhip -Wl,-rpath,'$$ORIGIN/../lib' $(LDFLAGS) -pthread
 
 oracle:
 	$(MAKE) -C oracle
