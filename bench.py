@@ -175,7 +175,7 @@ def main():
     result = None
     if rank == 0:
         cpu = None
-        if args.cpu_slices != 0:
+        if args.cpu_slices != 0 and world == 1:               # the CPU baseline is reported at N = 1 only
             n_cpu = args.cpu_slices
             if n_cpu < 0:                                     # one probe slice sizes the bounded sample
                 probe, _ = cpu_baseline(nc, 1, undersamp)
