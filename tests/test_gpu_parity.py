@@ -192,7 +192,10 @@ def test_metric_size_pipeline_vs_oracle(oracle, monkeypatch, nc, kb):
     flags = dict(golden_angle=1, data_undersamp=npe / 512 + 1e-6, prof_slide=npe)
     want, p = oracle.recon(data, adjoint=1, golden=1, data_undersamp=npe / 512 + 1e-6, prof_slide=npe)
     assert (p.nz, p.nxos, p.nx, p.npe1work) == (2, 512, 256, npe)
+    # the fused path neither stores nor loads grid points beyond the sampled disc: NaN-fill the work grid to prove it
+    monkeypatch.setenv("TRON_POISON_GRID", "1")
     got, _ = lib.recon(data, adjoint=True, kb_mode=kb, **flags)
+    assert np.isfinite(got).all()
     assert rel_l2(got, want) <= TOL_PIPELINE
     monkeypatch.setenv("TRON_FFT", "rocfft")
     ref, _ = lib.recon(data, adjoint=True, kb_mode=kb, **flags)

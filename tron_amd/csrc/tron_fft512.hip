@@ -91,6 +91,7 @@ struct Fft512Params {
     const float2 *tw;        // exp(+2 pi i k / 512), k = 0..511
     const float *inv_deapod; // 256*256
     int nchan, nslices;
+    int rzero2;              // pass 1: elements with X^2 + Y^2 > rzero2 are known zeros and are not loaded (<= 0: load all)
 };
 
 // cropped index of kept output k (k < 128 or k >= 384), cf. post_kernel: mr = (row + w - n/2 + n) % n
@@ -110,8 +111,16 @@ __global__ void __launch_bounds__(256) fft512_rows_kernel(const Fft512Params p)
         const int lr = wave * 4 + j;
         const float2 *line = src + (size_t)(row0 + lr) * kF;
         float2 v[8];
+        // the gridded spokes fill a disc of radius nxos/2 - 1 + W (src/tron.cu:498-502): 21 % of the square is zero
+        const int row = row0 + lr;
+        const int Y = row < kF / 2 ? row : row - kF;
+        const int lim = p.rzero2 > 0 ? p.rzero2 - Y * Y : 0x7fffffff;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = line[q * 64 + lane];
+        for (int q = 0; q < 8; ++q) {
+            const int col = q * 64 + lane;
+            const int X = col < kF / 2 ? col : col - kF;
+            v[q] = X * X <= lim ? line[col] : make_float2(0.f, 0.f);
+        }
         fft512_inv(v, xch, p.tw, lane);
         // keep k = lane + 64*j2 for j2 in {0,1,6,7}
 #pragma unroll
@@ -187,10 +196,11 @@ __global__ void __launch_bounds__(256) fft512_cols_post_kernel(const Fft512Param
     }
 }
 
-hipError_t launch_fft512_adjoint(const float2 *grid, float2 *tmp, float2 *out, const float2 *tw, const float *inv_deapod,
+hipError_t launch_fft512_adjoint(const float2 *grid, float2 *tmp, float2 *out, const float2 *tw, const float *inv_deapod, int rzero,
                                  int nchan, int nslices, hipStream_t s)
 {
     Fft512Params p;
+    p.rzero2 = rzero > 0 ? rzero * rzero : 0;
     p.in = grid; p.tmp = tmp; p.out = out; p.tw = tw; p.inv_deapod = inv_deapod; p.nchan = nchan; p.nslices = nslices;
     hipLaunchKernelGGL(fft512_rows_kernel, dim3(kF / kLinesPerWg, nslices * nchan), dim3(256), 0, s, p);
     hipError_t e = hipGetLastError();

@@ -90,6 +90,12 @@ grid_binned_kernel(const GridParams p)
 
     const int x0 = (tile % p.tiles_per_row) * kBinTile - h;     // tile origin, centred coordinates
     const int y0 = (tile / p.tiles_per_row) * kBinTile - h;
+    if (p.skip_outside) {
+        // nearest point of the tile to the k-space centre; beyond rmax + W every band is empty (src/tron.cu:498-502,512)
+        const int ax = max(max(x0, -(x0 + kBinTile - 1)), 0), ay = max(max(y0, -(y0 + kBinTile - 1)), 0);
+        const float lim = (float)rmax + p.W + 1.0f;
+        if ((float)(ax * ax + ay * ay) > lim * lim) return;
+    }
     const int mx = 2 * (lane & 15);                             // this thread's 2x2 points, tile-relative
     const int my = 8 * wave + 2 * (lane >> 4);
     const int X0 = x0 + mx, Y0 = y0 + my;

@@ -31,6 +31,8 @@ struct GridParams {
     int out_p;               // output stride per pixel
     int out_shift;           // 1: rows/cols stored in FFT-native order ((Y+n)%n), 0: centred (Y+n/2)
     float kb_poly[kKbPolyTerms];  // fast mode: highest power first, includes the 0.5/W factor
+    int skip_outside;        // binned kernel: tiles wholly beyond radius nxos/2-1+W (always zero, src/tron.cu:498-502) are not stored;
+                             // only set when the consumer (launch_fft512_adjoint) does not read them either
     int debug;               // TRON_DEBUG_SKIP: 1 = skip the gather phase, 2 = skip staging too (timing experiments only)
 };
 
@@ -77,7 +79,8 @@ hipError_t warm_degrid_tile();   // ... and of tron_degrid_tile.hip
 // tiled degridding (tron_degrid_tile.hip), W <= 3
 hipError_t launch_degrid_tile(const DegridParams &p, int kb_mode, hipStream_t s);
 // fused pruned inverse FFT + crop + deapodise + SoS for nxos = 512, nx = 256 (tron_fft512.hip)
-hipError_t launch_fft512_adjoint(const float2 *grid, float2 *tmp, float2 *out, const float2 *tw, const float *inv_deapod,
+// rzero: grid points at integer radius > rzero hold zeros by construction and are not read (0 = read everything)
+hipError_t launch_fft512_adjoint(const float2 *grid, float2 *tmp, float2 *out, const float2 *tw, const float *inv_deapod, int rzero,
                                  int nchan, int nslices, hipStream_t s);
 // fused pad + deapodise + shift + pruned forward FFT for nx = 256, nxos = 512 (tron_fft512.hip)
 hipError_t launch_fft512_forward(const float2 *img, float2 *tmp, float2 *out, const float2 *tw, const float *inv_deapod,
