@@ -112,6 +112,7 @@ __global__ void __launch_bounds__(256) fft512_rows_kernel(const Fft512Params p)
         const float2 *line = src + (size_t)(row0 + lr) * kF;
         float2 v[8];
         // the gridded spokes fill a disc of radius nxos/2 - 1 + W (src/tron.cu:498-502): 21 % of the square is zero
+        // (prefetching the next line here costs occupancy: measured 308 -> 380 us per 512 images)
         const int row = row0 + lr;
         const int Y = row < kF / 2 ? row : row - kF;
         const int lim = p.rzero2 > 0 ? p.rzero2 - Y * Y : 0x7fffffff;
@@ -160,14 +161,25 @@ __global__ void __launch_bounds__(256) fft512_cols_post_kernel(const Fft512Param
             val[j][jj] = 0.f;
             single[j][jj] = make_float2(0.f, 0.f);
         }
+    // software pipeline over the nchan x 4 lines of this wave: line i+1 is in flight while line i is transformed
+    const float2 *base = p.in + (size_t)z * p.nchan * (size_t)kFKeep * kF + (size_t)(col0 + wave * 4) * kF;
+    float2 nxt[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) nxt[q] = base[q * 64 + lane];
     for (int c = 0; c < p.nchan; ++c) {
-        const float2 *src = p.in + ((size_t)z * p.nchan + c) * (size_t)kFKeep * kF;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float2 *line = src + (size_t)(col0 + wave * 4 + j) * kF;
             float2 v[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = line[q * 64 + lane];
+            for (int q = 0; q < 8; ++q) v[q] = nxt[q];
+            {
+                const int jn = (j + 1) & 3, cn = c + (j == 3 ? 1 : 0);
+                if (cn < p.nchan) {
+                    const float2 *line = base + (size_t)cn * kFKeep * kF + (size_t)jn * kF;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) nxt[q] = line[q * 64 + lane];
+                }
+            }
             fft512_inv(v, xch, p.tw, lane);
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
