@@ -28,9 +28,9 @@ NRO, NPE, NXOS, NX = 512, 402, 512, 256
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 
 
-def algorithmic_bytes(nc):
+def algorithmic_bytes(nc, half=False):
     """bytes that must cross HBM per coil-slice and per slice."""
-    grid = 8 * NRO * NPE + 8 * NXOS * NXOS          # read samples once + write grid once
+    grid = (4 if half else 8) * NRO * NPE + 8 * NXOS * NXOS   # read samples once + write grid once
     fft = 2 * 8 * NXOS * NXOS                       # one read + one write
     post_cs = 8 * NX * NX                           # read centre crop
     per_cs = grid + fft + post_cs                   # 8 462 336
@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--slices", type=int, default=256, help="slices per GPU per step")
     ap.add_argument("--spokes", type=int, default=402, help="spokes per slice (402 = the metric's shape; BASELINE config 4 has 804)")
     ap.add_argument("--kb", choices=["fast", "exact"], default="fast")
+    ap.add_argument("--half", action="store_true", help="k-space stored as complex-half in HBM (BASELINE config 5); fp32 accumulate and FFT")
     ap.add_argument("--chunk", type=int, default=0, help="slices per internal batch (0 = auto)")
     ap.add_argument("--cpu-slices", type=int, default=-1,
                     help="slices of the CPU-baseline sample (0 = skip; -1 = sized for about 12 s of wall time, 2..32 slices)")
@@ -97,7 +98,8 @@ def main():
     undersamp = 0.7852 if NPE == 402 else (NPE + 0.5) / NRO    # tron -u: npe1work = int(nro*u), src/tron.cu:925
     nc, nz = args.coils, args.slices
     cfg = lib.default_config(adjoint=1, golden_angle=1, data_undersamp=undersamp, prof_slide=NPE, device=local_rank,
-                             kb_mode=lib.KB_FAST if args.kb == "fast" else lib.KB_EXACT, chunk_slices=args.chunk)
+                             kb_mode=lib.KB_FAST if args.kb == "fast" else lib.KB_EXACT, chunk_slices=args.chunk,
+                             input_half=1 if args.half else 0)
     dims = lib.derive_dims(cfg, (nc, 1, NRO, NPE * nz, 1))
     assert (dims.nz, dims.npe1work, dims.nxos, dims.nx) == (nz, NPE, NXOS, NX)
     plan = lib.Plan(cfg, dims)
@@ -106,6 +108,8 @@ def main():
     g = torch.Generator(device="cuda")
     g.manual_seed(0x54524F4E + rank)
     kspace = torch.rand(2 * nc * NRO * NPE * nz, device="cuda", generator=g, dtype=torch.float32) * 2 - 1
+    if args.half:
+        kspace = kspace.to(torch.float16)        # round-to-nearest-even, as src/float16.cu
     images = torch.empty(2 * NX * NX * nz, device="cuda", dtype=torch.float32)
     d_in, d_out = ctypes.c_void_p(kspace.data_ptr()), ctypes.c_void_p(images.data_ptr())
 
@@ -133,7 +137,7 @@ def main():
     value = world * nz * args.steps / dt
 
     # per-kernel durations, measured live with hipEvents on the library's own stream
-    ab = algorithmic_bytes(nc)
+    ab = algorithmic_bytes(nc, args.half)
     roofline = None
     stages = {}
     if rank == 0:
@@ -186,7 +190,7 @@ def main():
             # the timed path produced real images: spot-check one slice of this rank against the oracle
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             from oracle import pyoracle
-            host = kspace[: 2 * nc * NRO * NPE].cpu().numpy().view(np.complex64).reshape((nc, 1, NRO, NPE, 1), order="F")
+            host = kspace[: 2 * nc * NRO * NPE].float().cpu().numpy().view(np.complex64).reshape((nc, 1, NRO, NPE, 1), order="F")
             want, _ = pyoracle.recon(host, adjoint=1, golden=1, data_undersamp=undersamp, prof_slide=NPE)
             got = images[: 2 * NX * NX].cpu().numpy().view(np.complex64)
             err = float(np.linalg.norm(got - want.reshape(-1, order="F")) / np.linalg.norm(want))
@@ -215,7 +219,7 @@ def main():
             "metric": "2D slices/sec gridded (512^2 grid, 512x402 golden-angle) + achieved HBM GB/s",
             "value": round(value, 1), "unit": "slices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if not args.half else "f32 (k-space stored as f16)", "data": "synthetic",
             "config": {"workload": f"adjoint gridding recon: {nz} slices/GPU/step x {nc} coils, 512 readout x {NPE} golden-angle spokes "
                                    f"-> 512^2 oversampled grid -> 256^2 image (tron -a -G -u {undersamp:.4f} -d {NPE})",
                        "coils": nc, "slices_per_gpu": nz, "kb_mode": args.kb, "parallelism": f"slices sharded over {world} GPU(s), no collective"},

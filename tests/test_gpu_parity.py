@@ -220,11 +220,12 @@ def test_metric_size_forward_vs_oracle(oracle, monkeypatch, nc, kb):
     assert rel_l2(got, ref) <= 2e-6
 
 
-def test_half_precision_kspace_input(oracle):
+@pytest.mark.parametrize("nc", [2, 8])
+def test_half_precision_kspace_input(oracle, nc):
     """Config 5: k-space stored as complex-half (.ra eltype 4 / elbyte 4), converted with the reference's
     round-to-nearest-even (src/float16.cu); gridded from half storage with fp32 accumulation.  Parity is
     against the fp32 oracle run on the SAME half-rounded values."""
-    nc, nro, npe = 2, 64, 90
+    nro, npe = 64, 90                       # 8 coils: the 16-byte (four-coil) load path of the binned kernel
     data = synth.kspace(nc, nro, npe, seed=808)
     halves = np.asfortranarray(data).reshape(-1, order="F").view(np.float32).astype(np.float16)
     L = lib.load()

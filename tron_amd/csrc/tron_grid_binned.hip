@@ -241,6 +241,20 @@ grid_binned_kernel(const GridParams p)
                             pf_d[j][2 * c] = make_float2(v.x, v.y);
                             pf_d[j][2 * c + 1] = make_float2(v.z, v.w);
                         }
+                    } else if (HALF && CPB % 4 == 0 && ncb == CPB && (p.nchan & 3) == 0 && (c0 & 3) == 0) {
+                        // complex-half storage: four coils of one sample per 16-byte load
+                        const uint4 *src4 = reinterpret_cast<const uint4 *>(reinterpret_cast<const __half2 *>(in_bytes) + sbase);
+#pragma unroll
+                        for (int c = 0; c < CPB / 4; ++c) {
+                            const uint4 v = src4[c];
+                            const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                __half2 hh;
+                                __builtin_memcpy(&hh, &w[k], 4);
+                                pf_d[j][4 * c + k] = __half22float2(hh);
+                            }
+                        }
                     } else {
 #pragma unroll
                         for (int c = 0; c < CPB; ++c)
