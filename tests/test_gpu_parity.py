@@ -99,6 +99,8 @@ ADJ_CASES = [
     (8, 32, 40, dict(golden_angle=1, data_undersamp=1.0)),                           # > MAXCHAN of the reference
     (1, 64, 40, dict(golden_angle=1, data_undersamp=2.0, gridos=1.5)),
     (1, 48, 30, dict(golden_angle=1, data_undersamp=2.0, kernwidth=2.5)),
+    (2, 24, 81, dict(golden_angle=1, data_undersamp=1.0, prof_slide=8, gridos=1.5, kernwidth=1.5)),   # nxos 18: nxos/2 odd
+    (4, 16, 50, dict(golden_angle=0, data_undersamp=4.0, gridos=1.25, kernwidth=3.0)),                # nxos 10
     (2, 64, 64, dict(golden_angle=0, data_undersamp=0.25, prof_slide=16)),           # linear angle windows
 ]
 

@@ -1,0 +1,69 @@
+"""Random-shape cross-check (tooling): the fast paths (binned gridding, tiled degridding with packed polynomials,
+fused FFTs) against the reference-order exact mode on the GPU, and both against the CPU oracle when the case is
+small enough.  usage: python tools/fuzz.py [ncases] [seed]"""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import synth
+from tron_amd import lib
+from oracle import pyoracle
+
+def rel(a, b):
+    return float(np.linalg.norm((a - b).ravel()) / max(np.linalg.norm(b.ravel()), 1e-30))
+
+def run(n, seed, verbose=True):
+    """Returns (worst error, list of failing case descriptions)."""
+    rng = np.random.default_rng(seed)
+    worst = 0.0
+    failures = []
+    for it in range(n):
+        adjoint = bool(rng.integers(0, 2))
+        nc = int(rng.choice([1, 2, 4, 6, 8]))
+        W = float(rng.choice([1.5, 2.0, 2.0, 2.0, 2.5, 3.0]))
+        gridos = float(rng.choice([1.25, 1.5, 2.0, 2.0, 2.0]))
+        golden = int(rng.integers(0, 2))
+        skip = int(rng.integers(0, 50))
+        if adjoint:
+            nro = int(rng.choice([16, 24, 32, 48, 64, 96, 128, 200, 512]))
+            npe_w = int(rng.integers(1, 700 if nro <= 128 else 60))
+            nz = int(rng.integers(1, 5))
+            slide = int(rng.integers(1, npe_w + 1))
+            npe1 = npe_w + (nz - 1) * slide
+            us = (npe_w + 0.5) / nro
+            flags = dict(golden_angle=golden, data_undersamp=us, prof_slide=slide, kernwidth=W, gridos=gridos, skip_angles=skip)
+            data = synth.kspace(nc, nro, npe1, seed=1000 + it)
+            desc = f"adj nc={nc} nro={nro} npe={npe_w} nz={nz} slide={slide} W={W} os={gridos} G={golden} skip={skip}"
+            small = nro <= 128 and npe_w * nz <= 1500
+        else:
+            nx = int(rng.choice([8, 12, 16, 24, 32, 50, 64, 256]))
+            nro = int(gridos * nx)
+            npe = int(rng.integers(1, 300 if nx <= 64 else 40))
+            us = (npe + 0.5) / nro
+            flags = dict(golden_angle=golden, data_undersamp=us, kernwidth=W, gridos=gridos, skip_angles=skip)
+            data = synth.image(nc, nx, seed=2000 + it)
+            desc = f"fwd nc={nc} nx={nx} nro={nro} npe={npe} W={W} os={gridos} G={golden} skip={skip}"
+            small = nx <= 64
+        try:
+            ex, d = lib.recon(data, adjoint=adjoint, kb_mode=lib.KB_EXACT, **flags)
+            fa, _ = lib.recon(data, adjoint=adjoint, kb_mode=lib.KB_FAST, **flags)
+        except Exception as e:
+            print("ERROR", desc, str(e)[:200]); worst = 1.0; failures.append(desc + ": " + str(e)[:200]); continue
+        e1 = rel(fa, ex)
+        e2 = e3 = float("nan")
+        if small:
+            oflags = {("golden" if k == "golden_angle" else k): v for k, v in flags.items()}
+            want, p = pyoracle.recon(data, adjoint=int(adjoint), **oflags)
+            e2, e3 = rel(ex, want), rel(fa, want)
+        bad = (not np.isfinite(e1)) or e1 > 5e-6 or (small and (e2 > 1e-5 or e3 > 1e-5))
+        worst = max(worst, e1, 0 if not small else max(e2, e3))
+        if bad:
+            failures.append(f"{desc}: {e1:.2e} {e2:.2e} {e3:.2e}")
+        if verbose:
+            print(("BAD " if bad else "ok  ") + f"{desc}: fast-vs-exact {e1:.2e} exact-vs-oracle {e2:.2e} fast-vs-oracle {e3:.2e}", flush=True)
+    return worst, failures
+
+
+if __name__ == "__main__":
+    w, f = run(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    print("worst", w, "failures", len(f))

@@ -490,7 +490,9 @@ grid_binned_kernel(const GridParams p)
         if (Y + h >= n) continue;
         const int row = p.out_shift ? (Y < 0 ? Y + n : Y) : Y + h;     // both fftshifts of src/tron.cu:631 folded in
         const int colA = p.out_shift ? (X0 < 0 ? X0 + n : X0) : X0 + h;
-        const bool pair = (X0 + 1 + h < n) && p.out_p == 1;            // X0 is even and n/2 is even: X0, X0+1 never straddle the wrap
+        // one 16-byte store for the two columns needs an even first column; then X0 is even too (n is), so X0 != -1 and
+        // the pair does not straddle the periodic wrap.  n/2 odd (e.g. nxos 18, 150) makes every X0 odd: scalar stores.
+        const bool pair = (X0 + 1 + h < n) && p.out_p == 1 && (colA & 1) == 0;
         float2 *out = p.udata + (size_t)z * p.out_z + ((size_t)row * n + colA) * p.out_p;
 #pragma unroll
         for (int c = 0; c < CPB; ++c)
