@@ -19,8 +19,9 @@ def run(n, seed, verbose=True):
     failures = []
     for it in range(n):
         adjoint = bool(rng.integers(0, 2))
+        half = False
         nc = int(rng.choice([1, 2, 4, 6, 8]))
-        W = float(rng.choice([1.5, 2.0, 2.0, 2.0, 2.5, 3.0]))
+        W = float(rng.choice([1.5, 2.0, 2.0, 2.0, 2.5, 3.0, 3.5, 4.0]))   # > 3: the fallback kernels
         gridos = float(rng.choice([1.25, 1.5, 2.0, 2.0, 2.0]))
         golden = int(rng.integers(0, 2))
         skip = int(rng.integers(0, 50))
@@ -33,7 +34,12 @@ def run(n, seed, verbose=True):
             us = (npe_w + 0.5) / nro
             flags = dict(golden_angle=golden, data_undersamp=us, prof_slide=slide, kernwidth=W, gridos=gridos, skip_angles=skip)
             data = synth.kspace(nc, nro, npe1, seed=1000 + it)
-            desc = f"adj nc={nc} nro={nro} npe={npe_w} nz={nz} slide={slide} W={W} os={gridos} G={golden} skip={skip}"
+            half = bool(rng.integers(0, 5) == 0)             # complex-half storage (config 5)
+            if half:
+                h16 = np.asfortranarray(data).reshape(-1, order="F").view(np.float32).astype(np.float16)
+                data = h16.astype(np.float32).view(np.complex64).reshape(data.shape, order="F")   # what the oracle sees
+                gpu_in, flags = h16.reshape((2,) + data.shape, order="F"), dict(flags, input_half=1)
+            desc = ("half " if half else "") + f"adj nc={nc} nro={nro} npe={npe_w} nz={nz} slide={slide} W={W} os={gridos} G={golden} skip={skip}"
             small = nro <= 128 and npe_w * nz <= 1500
         else:
             nx = int(rng.choice([8, 12, 16, 24, 32, 50, 64, 256]))
@@ -45,8 +51,10 @@ def run(n, seed, verbose=True):
             desc = f"fwd nc={nc} nx={nx} nro={nro} npe={npe} W={W} os={gridos} G={golden} skip={skip}"
             small = nx <= 64
         try:
-            ex, d = lib.recon(data, adjoint=adjoint, kb_mode=lib.KB_EXACT, **flags)
-            fa, _ = lib.recon(data, adjoint=adjoint, kb_mode=lib.KB_FAST, **flags)
+            src = gpu_in if (adjoint and half) else data
+            ex, d = lib.recon(src, adjoint=adjoint, kb_mode=lib.KB_EXACT, **flags)
+            fa, _ = lib.recon(src, adjoint=adjoint, kb_mode=lib.KB_FAST, **flags)
+            flags.pop("input_half", None)
         except Exception as e:
             print("ERROR", desc, str(e)[:200]); worst = 1.0; failures.append(desc + ": " + str(e)[:200]); continue
         e1 = rel(fa, ex)
