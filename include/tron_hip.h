@@ -125,6 +125,12 @@ int tron_nufft_adj_radial2d(tron_plan *plan, void *d_out, const void *d_in,
    back to back: d_in[nchan*nx*ny*k + nchan*id + c] -> d_out[nchan*nro*npe*k + nchan*(ro+nro*pe) + c]. */
 int tron_nufft_radial2d(tron_plan *plan, void *d_out, const void *d_in, int nimg);
 
+/* = the precompensate kernel, src/tron.cu:405-416: Ram-Lak density compensation of ONE window of
+   npe1work spokes, in place, d_nudata[nchan*(nro*pe + ro) + c] *= a*|ro - nro/2| + b.  The
+   pipelines above fuse this factor into the gridding kernel's loads and never modify their input;
+   this stage entry exists for callers that drive tron_gridradial2d themselves. */
+int tron_precompensate(tron_plan *plan, void *d_nudata);
+
 /* = the gridradial2d kernel, src/tron.cu:465-536, for ONE image in the reference's own
    layouts: d_nudata[nchan*(nro*pe + ro) + c] (already density compensated),
    d_udata[nchan*(Y*nxos + X) + c] (centred, not shifted).  skip = the kernel's

@@ -42,15 +42,18 @@ def _plan(in_dims, adjoint, **flags):
 ])
 def test_grid_stage_vs_oracle(oracle, golden, nchan, nxos, nro, npe, W, kb):
     """tron_gridradial2d == gridradial2d kernel (src/tron.cu:465-536), reference layouts."""
-    nu = synth.uniform_c64(npe * nro * nchan, 101).reshape(npe, nro, nchan)
-    nu = oracle.precompensate(nu)
+    raw = synth.uniform_c64(npe * nro * nchan, 101).reshape(npe, nro, nchan)
+    nu = oracle.precompensate(raw)
     skip = 7
     want = oracle.gridradial2d(nu, nxos, W=W, gridos=nxos / (nro / 2), skip_angles=skip, golden=golden)
     # a plan whose derived dims are (nxos, nro, npe): adjoint, -o nxos/(nro/2), -u big
     with _plan((nchan, 1, nro, npe, 1), 1, golden_angle=golden, gridos=nxos / (nro / 2), kernwidth=W,
                data_undersamp=1e6, kb_mode=kb) as plan:
         assert plan.dims.nxos == nxos and plan.dims.npe1work == npe
-        d_in = lib.DeviceBuffer.from_numpy(nu)
+        d_in = lib.DeviceBuffer.from_numpy(raw)
+        plan.precompensate_device(d_in.ptr)            # = the precompensate kernel, src/tron.cu:405-416, in place
+        plan.sync()
+        assert np.array_equal(d_in.to_numpy(np.complex64, npe * nro * nchan).view(np.uint32), np.ascontiguousarray(nu).reshape(-1).view(np.uint32))
         d_out = lib.DeviceBuffer(nxos * nxos * nchan * 8)
         plan.grid_device(d_out.ptr, d_in.ptr, skip)
         plan.sync()

@@ -70,6 +70,7 @@ hipError_t launch_grid_binned(const GridParams &p, int half_in, hipStream_t s);
 constexpr int kBinnedTile = 32;
 hipError_t launch_post(const PostParams &p, hipStream_t s);
 hipError_t launch_pre(const PreParams &p, hipStream_t s);
+hipError_t launch_precompensate(float2 *nudata, int nchan, int nro, int npe, float a, float b, hipStream_t s);
 hipError_t launch_degrid(const DegridParams &p, int kb_mode, hipStream_t s);
 size_t grid_lds_bytes(int cpb, int cw);
 hipError_t warm_kernels();       // force-load the code object of tron_kernels.hip

@@ -383,6 +383,29 @@ hipError_t launch_pre(const PreParams &p, hipStream_t s)
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------- density compensation
+//
+// = precompensate, src/tron.cu:405-416, as a stage of its own (the pipelines apply the same factor while the
+// gridding kernels load their samples).  In place, one thread per complex sample (the reference: one per spoke).
+__global__ void __launch_bounds__(256) precompensate_kernel(float2 *nudata, const int nchan, const int nro, const long long total,
+                                                            const float a, const float b)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int r = (int)((i / nchan) % nro);
+    const float sdc = a * fabsf((float)r - (float)(nro / 2)) + b;       // src/tron.cu:412
+    float2 v = nudata[i];
+    v.x *= sdc; v.y *= sdc;                                             // src/tron.cu:414
+    nudata[i] = v;
+}
+
+hipError_t launch_precompensate(float2 *nudata, int nchan, int nro, int npe, float a, float b, hipStream_t s)
+{
+    const long long total = (long long)nchan * nro * npe;
+    hipLaunchKernelGGL(precompensate_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, nudata, nchan, nro, total, a, b);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------- degridding
 
 // = degridradial2d, src/tron.cu:540-577: one thread per k-space sample, accumulation order

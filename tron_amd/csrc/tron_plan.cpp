@@ -684,6 +684,15 @@ extern "C" int tron_recon_radial2d(tron_plan *p, tron_float2 *h_out, const tron_
     return tron_recon_radial2d_range(p, h_out, h_in, 0, p->d.nz);
 }
 
+extern "C" int tron_precompensate(tron_plan *p, void *d_nudata)
+{
+    if (!p || !d_nudata) return fail(TRON_ERR_INVALID, "tron_precompensate: null argument");
+    if (!p->cfg.adjoint) return fail(TRON_ERR_INVALID, "plan was created for the forward direction");
+    HIP_TRY(hipSetDevice(p->cfg.device));
+    HIP_TRY(launch_precompensate(static_cast<float2 *>(d_nudata), p->nchan, p->d.nro, p->d.npe1work, p->dcf_a, p->dcf_b, p->stream));
+    return TRON_OK;
+}
+
 extern "C" int tron_gridradial2d(tron_plan *p, void *d_udata, const void *d_nudata, int skip)
 {
     if (!p || !d_udata || !d_nudata) return fail(TRON_ERR_INVALID, "tron_gridradial2d: null argument");

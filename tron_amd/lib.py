@@ -52,7 +52,7 @@ class Dims(ctypes.Structure):
 EXPORTS = [
     "tron_config_default", "tron_derive_dims", "tron_plan_create", "tron_plan_destroy",
     "tron_recon_radial2d", "tron_recon_radial2d_range", "tron_nufft_adj_radial2d", "tron_nufft_radial2d",
-    "tron_gridradial2d", "tron_degridradial2d", "tron_plan_sync",
+    "tron_precompensate", "tron_gridradial2d", "tron_degridradial2d", "tron_plan_sync",
     "tron_plan_timing", "tron_plan_timing_get", "tron_plan_timing_reset",
     "tron_host_trig_table", "tron_host_band_table", "tron_host_deapod_table",
     "tron_device_count", "tron_device_malloc", "tron_device_free", "tron_memcpy_h2d", "tron_memcpy_d2h",
@@ -82,6 +82,7 @@ def load():
     L.tron_recon_radial2d_range.restype = i; L.tron_recon_radial2d_range.argtypes = [p, p, p, i, i]
     L.tron_nufft_adj_radial2d.restype = i; L.tron_nufft_adj_radial2d.argtypes = [p, p, p, i, i, i]
     L.tron_nufft_radial2d.restype = i; L.tron_nufft_radial2d.argtypes = [p, p, p, i]
+    L.tron_precompensate.restype = i; L.tron_precompensate.argtypes = [p, p]
     L.tron_gridradial2d.restype = i; L.tron_gridradial2d.argtypes = [p, p, p, i]
     L.tron_degridradial2d.restype = i; L.tron_degridradial2d.argtypes = [p, p, p]
     L.tron_plan_sync.restype = i; L.tron_plan_sync.argtypes = [p]
@@ -212,6 +213,9 @@ class Plan:
 
     def forward_device(self, d_out, d_in, nimg):
         check(load().tron_nufft_radial2d(self._h, d_out, d_in, int(nimg)))
+
+    def precompensate_device(self, d_nudata):
+        check(load().tron_precompensate(self._h, d_nudata))
 
     def grid_device(self, d_udata, d_nudata, skip):
         check(load().tron_gridradial2d(self._h, d_udata, d_nudata, int(skip)))
