@@ -17,6 +17,7 @@ namespace tron {
 constexpr int kDgTile = 32;
 constexpr int kDgThreads = 256;
 constexpr int kDgMaxSpokes = 256;   // spokes clipped per round (one per thread)
+constexpr int kDgMaxBlocks = 256;   // 64-record blocks indexed by the inverse map (more records: 8-ary search)
 
 template <int CPB, int CW>
 struct DgLds {
@@ -27,6 +28,7 @@ struct DgLds {
     int sp_start[kDgMaxSpokes + 1];   // exclusive scan of len
     float2 sp_cs[kDgMaxSpokes];        // (cos, sin) of the accepted spokes: the sample loop stays off global memory
     int wcnt[8];
+    unsigned short first[kDgMaxBlocks];   // spoke slot holding record 64*b: starts the per-lane spoke search
     float2 tile[TS * TS * CPB + 8];    // [coil][row][col]: neighbouring samples read neighbouring banks; zeroed pad
 };
 
@@ -169,28 +171,59 @@ __global__ void __launch_bounds__(kDgThreads) degrid_tile_kernel(const DegridPar
             __syncthreads();
         }
         const int nrec = L.sp_start[nacc];
+        const bool mapped = nrec <= 64 * kDgMaxBlocks;
+        if (mapped) {
+            // inverse map: which spoke holds record 64*b (a wave pass covers exactly one such block)
+            for (int sidx = tid; sidx < nacc; sidx += kDgThreads) {
+                const int st = L.sp_start[sidx], en = L.sp_start[sidx + 1];
+                for (int b = (st + 63) >> 6; 64 * b < en; ++b) L.first[b] = (unsigned short)sidx;
+            }
+            __syncthreads();
+        }
+        const float inv_nro = 1.0f / (float)p.nro;
+        const bool nro_pow2 = (p.nro & (p.nro - 1)) == 0;               // then ro / nro == ro * (1 / nro) exactly
 
         // ---- samples, dealt out flat over the 256 threads -------------------------------------------
+        // (keeping the tile loads in flight across the first clip round was tried: the registers it pins cost more
+        //  than the exposed latency, 2.78 -> 2.91 us per coil image)
         for (int rec = tid; rec < nrec; rec += kDgThreads) {
-            // spoke holding record `rec`: largest s with sp_start[s] <= rec.  8-ary search: the seven
-            // splitters of a round are independent LDS reads, so a round costs one LDS latency.
-            int lo = 0, span = nacc;
-            while (span > 1) {
-                const int step = (span + 7) >> 3;
-                const int end = lo + span;
-                int sv[7];
+            // spoke holding record `rec`: largest s with sp_start[s] <= rec
+            int lo;
+            if (mapped) {
+                // start at the spoke of the pass's first record, then count the segment starts up to `rec`, four
+                // independent LDS reads at a time (segments are tens of records long: one round as a rule)
+                lo = L.first[rec >> 6];
+                for (;;) {
+                    int sv[4];
 #pragma unroll
-                for (int j = 1; j < 8; ++j) sv[j - 1] = L.sp_start[min(lo + j * step, kDgMaxSpokes)];   // unconditional: one batch
-                int cnt = 0;
+                    for (int j = 0; j < 4; ++j) sv[j] = L.sp_start[min(lo + 1 + j, nacc)];   // sp_start[nacc] = nrec > rec
+                    int cnt = 0;
 #pragma unroll
-                for (int j = 1; j < 8; ++j) cnt += (lo + j * step < end && sv[j - 1] <= rec) ? 1 : 0;
-                lo += cnt * step;
-                span = min(step, end - lo);
+                    for (int j = 0; j < 4; ++j) cnt += sv[j] <= rec ? 1 : 0;
+                    lo += cnt;
+                    if (cnt < 4) break;
+                }
+            } else {
+                // 8-ary search: the seven splitters of a round are independent LDS reads
+                lo = 0;
+                int span = nacc;
+                while (span > 1) {
+                    const int step = (span + 7) >> 3;
+                    const int end = lo + span;
+                    int sv[7];
+#pragma unroll
+                    for (int j = 1; j < 8; ++j) sv[j - 1] = L.sp_start[min(lo + j * step, kDgMaxSpokes)];
+                    int cnt = 0;
+#pragma unroll
+                    for (int j = 1; j < 8; ++j) cnt += (lo + j * step < end && sv[j - 1] <= rec) ? 1 : 0;
+                    lo += cnt * step;
+                    span = min(step, end - lo);
+                }
             }
             const int pe = L.sp_pe[lo];
             const int ro = (L.sp_seg[lo] & 0xffff) + (rec - L.sp_start[lo]);
             // thread's polar and Cartesian coordinates, src/tron.cu:554-561
-            const float R = (float)ro / (float)p.nro - 0.5f;
+            const float R = (nro_pow2 ? (float)ro * inv_nro : (float)ro / (float)p.nro) - 0.5f;
             const float2 cs = L.sp_cs[lo];
             float X = cs.y, Y = cs.x;                                   // X = sin, Y = cos (src/tron.cu:559)
             X = (float)n * R * X + half;
