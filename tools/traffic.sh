@@ -12,6 +12,6 @@ for f in glob.glob('$out/*/*/*_counter_collection.csv'):
         k=r['Kernel_Name'].split('(')[0][-44:]
         agg[k][r['Counter_Name']]+=float(r['Counter_Value']); n[(k,r['Counter_Name'])].add(r['Dispatch_Id'])
 for k,v in agg.items():
-    if any(t in k for t in ('grid','fft','post')):
+    if any(t in k for t in ('grid','fft','post','pre')):
         print(k, {c: (val, len(n[(k,c)])) for c,val in v.items()})
 PY

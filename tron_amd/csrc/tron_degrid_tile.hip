@@ -44,9 +44,17 @@ __global__ void __launch_bounds__(kDgThreads) degrid_tile_kernel(const DegridPar
     const int n = p.n;
     const int tpr = (n + kDgTile - 1) / kDgTile;
     // centre tiles hold the most samples (density ~ 1/r): they are dispatched first, all images of a tile together
-    const int tile = p.tile_order ? p.tile_order[blockIdx.x / p.nimg] : (int)(blockIdx.x % (tpr * tpr));
-    const int k = p.tile_order ? (int)(blockIdx.x % p.nimg) : (int)(blockIdx.x / (tpr * tpr));   // image
-    const int c0 = blockIdx.y * CPB;
+    // Workgroup id -> (tile, image, coil chunk).  The coil chunks of one (tile, image) write interleaved 8*CPB-byte
+    // pieces of the same output lines (samples are coil-interleaved, src/tron.cu:550): they are placed 8 ids apart, i.e.
+    // on the same XCD and next to each other in time, so its L2 merges the pieces before they reach HBM (dispatched
+    // far apart they cost 2 us per coil image in partial-line writes).
+    const int chunks = (p.nrep + CPB - 1) / CPB;
+    const int grp = blockIdx.x / (8 * chunks), within = blockIdx.x % (8 * chunks);
+    const int ti = grp * 8 + (within & 7);                      // (tile, image) index
+    if (ti >= tpr * tpr * p.nimg) return;
+    const int tile = p.tile_order ? p.tile_order[ti / p.nimg] : ti % (tpr * tpr);
+    const int k = p.tile_order ? ti % p.nimg : ti / (tpr * tpr);     // image
+    const int c0 = (within >> 3) * CPB;
     const int ncb = min(CPB, p.nrep - c0);
     const int tx0 = (tile / tpr) * kDgTile;                     // first row (sine axis, "X" of the reference)
     const int ty0 = (tile % tpr) * kDgTile;                     // first column (cosine axis, "Y")
@@ -104,7 +112,7 @@ __global__ void __launch_bounds__(kDgThreads) degrid_tile_kernel(const DegridPar
     const float by_lo = (float)ty0 - eps, by_hi = (float)(ty0 + kDgTile) + eps;
     float2 *dst = p.nudata + (size_t)k * p.nro * p.npe * p.nrep;
 
-    for (int round0 = 0; round0 < p.npe; round0 += kDgMaxSpokes) {
+    for (int round0 = 0; round0 < p.npe && p.debug < 2; round0 += kDgMaxSpokes) {
         // ---- clip: thread = spoke; X(ro) = n*(ro/nro - 1/2)*sin + half, Y likewise with cos ----------
         if (tid == 0) L.sp_start[0] = 0;
         int nacc = 0;
@@ -186,7 +194,7 @@ __global__ void __launch_bounds__(kDgThreads) degrid_tile_kernel(const DegridPar
         // ---- samples, dealt out flat over the 256 threads -------------------------------------------
         // (keeping the tile loads in flight across the first clip round was tried: the registers it pins cost more
         //  than the exposed latency, 2.78 -> 2.91 us per coil image)
-        for (int rec = tid; rec < nrec; rec += kDgThreads) {
+        for (int rec = tid; rec < nrec && p.debug < 1; rec += kDgThreads) {
             // spoke holding record `rec`: largest s with sp_start[s] <= rec
             int lo;
             if (mapped) {
@@ -328,7 +336,8 @@ static hipError_t launch_degrid_tile_cpb(const DegridParams &p, int kb_mode, hip
 {
     const int tpr = (p.n + kDgTile - 1) / kDgTile;
     const int chunks = (p.nrep + CPB - 1) / CPB;
-    dim3 grid((unsigned)((size_t)tpr * tpr * p.nimg), (unsigned)chunks);
+    const size_t nti = (size_t)tpr * tpr * p.nimg;
+    dim3 grid((unsigned)(((nti + 7) / 8) * 8 * chunks));
     const size_t lds = sizeof(DgLds<CPB, CW>);
     static_assert(sizeof(DgLds<CPB, CW>) <= 64 * 1024, "degrid tile must fit the default dynamic LDS limit");
     if (kb_mode == TRON_KB_EXACT)

@@ -58,6 +58,7 @@ struct DegridParams {
     long long in_z, in_c;     // input strides per image and per coil
     int in_p, in_shift;       // pixel stride; 1: input is the raw FFT output (second fftshift folded into indexing)
     int in_transposed;        // degrid_tile_kernel: input planes are stored [col][row] (fused forward FFT)
+    int debug;                // TRON_DEBUG_SKIP (timing bisection): 1 = no sample loop, 2 = tile load only
     int n, nrep, nro, npe, nimg;
     float W, beta;
     float kb_poly[kKbPolyTerms];

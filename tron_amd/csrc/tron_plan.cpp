@@ -363,6 +363,7 @@ int forward_run(tron_plan *p, void *d_out, const void *d_in, int nimg)
         g.in_p = 1;
         g.in_shift = 1;
         g.in_transposed = p->fft512 ? 1 : 0;      // launch_fft512_forward stores the grid transposed
+        if (const char *dbg = getenv("TRON_DEBUG_SKIP")) g.debug = atoi(dbg);
         g.n = d.nxos;
         g.nrep = p->nchan;
         g.nro = d.nro;
