@@ -19,6 +19,8 @@
 //   D  apply   a thread reads, for each of the 2CW+1 cell rows its 2x2 points can see, ONE contiguous
 //              id range, and accumulates weight pair x weight pair x sample for all coils in registers.
 // No floating-point atomics anywhere; the output is written once, coil-planar, in FFT-native order.
+#include <stdlib.h>
+
 #include "tron_device.h"
 
 namespace tron {
@@ -232,12 +234,12 @@ grid_binned_kernel(const GridParams p)
                     pf_r[j] = r;
                     const int ro = (p.nro == n ? r : (r * p.nro) / n) + p.nro / 2;   // src/tron.cu:517,519 (truncating division)
                     const size_t sbase = ((size_t)p.nro * pe + ro) * p.nchan + c0;
-                    if (!HALF && CPB % 2 == 0 && ncb == CPB && (p.nchan & 1) == 0 && (c0 & 1) == 0) {
-                        // the coils of one sample are contiguous: 16-byte loads
+                    if (!HALF && CPB % 2 == 0 && (ncb & 1) == 0 && (p.nchan & 1) == 0 && (c0 & 1) == 0) {
+                        // the coils of one sample are contiguous: 16-byte loads (coils beyond ncb are zero padding)
                         const float4 *src4 = reinterpret_cast<const float4 *>(reinterpret_cast<const float2 *>(in_bytes) + sbase);
 #pragma unroll
                         for (int c = 0; c < CPB / 2; ++c) {
-                            const float4 v = src4[c];
+                            const float4 v = 2 * c < ncb ? src4[c] : make_float4(0.f, 0.f, 0.f, 0.f);
                             pf_d[j][2 * c] = make_float2(v.x, v.y);
                             pf_d[j][2 * c + 1] = make_float2(v.z, v.w);
                         }
@@ -547,7 +549,12 @@ template <int CW>
 static hipError_t launch_binned_cw(const GridParams &p, int half_in, hipStream_t s)
 {
     const int nc = p.nchan - p.coil0;
-    if (nc >= 8 && nc % 8 == 0) return launch_binned_cpb<8, CW>(p, half_in, s);
+    static const int force = getenv("TRON_GRID_CPB") ? atoi(getenv("TRON_GRID_CPB")) : 0;   // tuning knob
+    if (force == 8) return launch_binned_cpb<8, CW>(p, half_in, s);
+    if (force == 4) return launch_binned_cpb<4, CW>(p, half_in, s);
+    // one padded 8-coil pass beats two 4-coil passes: the per-sample work (weights, sort) is paid per pass
+    // (6 coils: 3.3 vs 4.9 us per coil-slice; 12 coils: 4.1 vs 4.4)
+    if (nc >= 5) return launch_binned_cpb<8, CW>(p, half_in, s);
     if (nc >= 4) return launch_binned_cpb<4, CW>(p, half_in, s);
     if (nc >= 2) return launch_binned_cpb<2, CW>(p, half_in, s);
     return launch_binned_cpb<1, CW>(p, half_in, s);

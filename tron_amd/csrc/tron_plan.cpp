@@ -102,6 +102,7 @@ struct tron_plan {
     void *d_stage_out = nullptr;
     size_t stage_out_bytes = 0;
     float2 *d_trig_tmp = nullptr;  // stage-level gridding calls
+    int chunk_cap = 0;             // slices the work buffers hold (1.5 x chunk for the adjoint)
     bool fft512 = false;           // fused pruned FFT path (nxos 512 -> nx 256)
     float2 *d_tw512 = nullptr;     // exp(+2 pi i k / 512)
     float2 *d_fft_tmp = nullptr;   // chunk * nchan * 256 * 512
@@ -248,7 +249,12 @@ int adjoint_run(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, int 
     // VALUs idle.  All gridding launches go to `stream`, all FFT launches to `stream2`; chunk k's FFT waits
     // for chunk k's gridding, and gridding of chunk k+2 waits until the FFT has released buffer k&1.
     const bool dual = p->dual && p->fft512 && combine && zcount > 1;
-    const int step = dual ? std::max(1, std::min(p->chunk, (zcount + 1) / 2)) : p->chunk;
+    // equal batches: a short last launch would be bound by the centre tile's serial chain (e.g. 128 slices = 64 + 64, not 85 + 43)
+    // (the work buffers hold 1.5 x chunk so that the batches can be evened out upwards)
+    int nbatch = std::max(1, (zcount + p->chunk / 2) / p->chunk);
+    if ((zcount + nbatch - 1) / nbatch > p->chunk_cap) nbatch = (zcount + p->chunk_cap - 1) / p->chunk_cap;
+    const int even = (zcount + nbatch - 1) / nbatch;
+    const int step = dual ? std::max(1, std::min(even, (zcount + 1) / 2)) : even;
     int lane_idx = 0;
     for (int z0 = 0; z0 < zcount; z0 += step, ++lane_idx) {
         const int cz = std::min(step, zcount - z0);
@@ -459,10 +465,14 @@ extern "C" int tron_plan_create(tron_plan **out, const tron_config *cfg, const t
     int units = cfg->adjoint ? d.nz : 1;
     // The heaviest tile (the k-space centre, crossed by every spoke) is one wave's serial work, so a
     // launch needs enough slices in flight to cover that critical path: batch up to 1 GiB of grid.
-    int chunk = cfg->chunk_slices > 0 ? cfg->chunk_slices : (int)std::max<size_t>(1, ((size_t)1 << 30) / per_unit);
+    // ... or 64 slices when the coils are many (still at most 6 GiB of grid: 288 GB of HBM make that cheap)
+    size_t auto_chunk = std::max<size_t>(1, ((size_t)1 << 30) / per_unit);
+    if (auto_chunk < 64) auto_chunk = std::max<size_t>(auto_chunk, std::min<size_t>(64, ((size_t)6 << 30) / per_unit));
+    int chunk = cfg->chunk_slices > 0 ? cfg->chunk_slices : (int)std::max<size_t>(1, auto_chunk);
     if (const char *env = getenv("TRON_CHUNK_SLICES")) chunk = std::max(1, atoi(env));
     p->chunk = std::max(1, std::min(chunk, std::max(units, 1)));
-    if (!cfg->adjoint) p->chunk = std::max(1, chunk);
+    p->chunk_cap = std::max(p->chunk, std::min(std::max(units, 1), p->chunk + p->chunk / 2));
+    if (!cfg->adjoint) p->chunk = p->chunk_cap = std::max(1, chunk);
 
     int rc = TRON_OK;
     auto bail = [&](int code) { tron_plan_destroy(p); return code; };
@@ -501,10 +511,10 @@ extern "C" int tron_plan_create(tron_plan **out, const tron_config *cfg, const t
     }
     unsigned int zero = 0;
     if ((rc = upload(&p->d_errflag, &zero, sizeof(zero)))) return bail(rc);
-    if (hipMalloc(reinterpret_cast<void **>(&p->d_grid), (size_t)p->chunk * per_unit) != hipSuccess)
-        return bail(fail(TRON_ERR_NOMEM, "cannot allocate %zu bytes of Cartesian work space", (size_t)p->chunk * per_unit));
+    if (hipMalloc(reinterpret_cast<void **>(&p->d_grid), (size_t)p->chunk_cap * per_unit) != hipSuccess)
+        return bail(fail(TRON_ERR_NOMEM, "cannot allocate %zu bytes of Cartesian work space", (size_t)p->chunk_cap * per_unit));
     if (getenv("TRON_POISON_GRID"))      // tests: NaN-fill the work grid so a read of a never-written point shows up
-        hipMemset(p->d_grid, 0xff, (size_t)p->chunk * per_unit);
+        hipMemset(p->d_grid, 0xff, (size_t)p->chunk_cap * per_unit);
     if (d.nxos == 512 && d.nx == 256) {
         p->fft512 = true;
         if (const char *ff = getenv("TRON_FFT")) p->fft512 = strcmp(ff, "rocfft") != 0;
@@ -516,7 +526,7 @@ extern "C" int tron_plan_create(tron_plan **out, const tron_config *cfg, const t
             tw[2 * k + 1] = (float)sin(2.0 * M_PI * k / 512.0);
         }
         if ((rc = upload(&p->d_tw512, tw.data(), tw.size() * sizeof(float)))) return bail(rc);
-        if (hipMalloc(reinterpret_cast<void **>(&p->d_fft_tmp), (size_t)p->chunk * p->nchan * 256 * 512 * sizeof(float2)) != hipSuccess)
+        if (hipMalloc(reinterpret_cast<void **>(&p->d_fft_tmp), (size_t)p->chunk_cap * p->nchan * 256 * 512 * sizeof(float2)) != hipSuccess)
             return bail(fail(TRON_ERR_NOMEM, "cannot allocate the FFT intermediate buffer"));
         // off by default: measured +2 % (the gridding kernel already fills every CU's LDS, so the FFT
         // lane only gets the tail); TRON_DUAL_STREAM=1 turns it on
@@ -546,7 +556,7 @@ extern "C" int tron_plan_create(tron_plan **out, const tron_config *cfg, const t
                 if (hipEventCreateWithFlags(&p->ev_g[i], hipEventDisableTiming) != hipSuccess ||
                     hipEventCreateWithFlags(&p->ev_f[i], hipEventDisableTiming) != hipSuccess)
                     return bail(fail(TRON_ERR_HIP, "cannot create pipeline events"));
-            if (hipMalloc(reinterpret_cast<void **>(&p->d_grid2), (size_t)p->chunk * per_unit) != hipSuccess)
+            if (hipMalloc(reinterpret_cast<void **>(&p->d_grid2), (size_t)p->chunk_cap * per_unit) != hipSuccess)
                 return bail(fail(TRON_ERR_NOMEM, "cannot allocate the second Cartesian buffer"));
         }
     }
