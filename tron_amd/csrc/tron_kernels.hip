@@ -289,7 +289,7 @@ template <int CW>
 static hipError_t launch_grid_cw(const GridParams &p, int kb_mode, int half_in, hipStream_t s)
 {
     const int nc = p.nchan - p.coil0;
-    if (nc >= 8 && nc % 8 == 0) return launch_grid_kb<8, CW>(p, kb_mode, half_in, s);
+    if (nc >= 5) return launch_grid_kb<8, CW>(p, kb_mode, half_in, s);      // padded 8-coil passes, as launch_binned_cw
     if (nc >= 4) return launch_grid_kb<4, CW>(p, kb_mode, half_in, s);
     if (nc >= 2) return launch_grid_kb<2, CW>(p, kb_mode, half_in, s);
     return launch_grid_kb<1, CW>(p, kb_mode, half_in, s);
