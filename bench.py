@@ -163,10 +163,10 @@ def main():
                  "fft": "fft512_rows_kernel + fft512_cols_post_kernel" if "post" not in stages else "rocFFT 512x512 C2C inverse (batched)",
                  "post": "post_kernel"}[dom]
         # HBM bytes the dominant kernel actually moved, from rocprofv3 PMC passes of this round
-        # (profiles/round1_v4_traffic.json: FETCH_SIZE x2 + WRITE_SIZE, separate passes), scaled to one launch
+        # (profiles/round1_v5_traffic.json: FETCH_SIZE x2 + WRITE_SIZE, separate passes), scaled to one launch
         traffic = None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "round1_v4_traffic.json")))["per_coil_slice_bytes_corrected"]
+            tj = json.load(open(os.path.join(ROOT, "profiles", "round1_v5_traffic.json")))["per_coil_slice_bytes_corrected"]
             if dom == "grid" and args.kb == "fast" and nc == 8 and NPE == 402:
                 t = tj["grid_binned_kernel"]
                 traffic = int((t["read"] + t["write"]) * units_per_launch)
