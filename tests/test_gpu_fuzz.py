@@ -17,3 +17,27 @@ def test_random_shapes_fast_vs_exact_vs_oracle(oracle):
     worst, failures = fuzz.run(40, 20261002, verbose=False)
     assert not failures, failures
     assert worst <= 1e-5
+
+
+def test_tiny_problem_sizes(oracle):
+    """Readouts of 2..8 samples and images of 1..5 pixels: grids far smaller than one tile, single spokes."""
+    import numpy as np
+    import synth
+    from conftest import rel_l2
+    from tron_amd import lib
+    for kb in (lib.KB_EXACT, lib.KB_FAST):
+        for nro in (2, 3, 5, 8):
+            for npe in (1, 7):
+                for nc in (1, 2):
+                    data = synth.kspace(nc, nro, npe, seed=nro * 100 + npe)
+                    want, _ = oracle.recon(data, adjoint=1, golden=1, data_undersamp=10.0)
+                    got, _ = lib.recon(data, adjoint=True, kb_mode=kb, golden_angle=1, data_undersamp=10.0)
+                    assert got.shape == want.shape
+                    assert not want.size or rel_l2(got, want) <= 1e-5, (nro, npe, nc, kb)
+        for nx in (1, 2, 3, 5):
+            for nc in (1, 2):
+                img = synth.image(nc, nx, seed=nx)
+                want, _ = oracle.recon(img, adjoint=0, golden=1)
+                got, _ = lib.recon(img, adjoint=False, kb_mode=kb, golden_angle=1)
+                assert got.shape == want.shape
+                assert not want.size or rel_l2(got, want) <= 1e-5, (nx, nc, kb)
