@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 #include <sysexits.h>
 #include <unistd.h>
 
@@ -163,6 +164,17 @@ extern "C" int ra_read(ra_t *a, const char *path)
     if (rc) {
         close(fd);
         return rc;
+    }
+    {   // a regular file cannot hold more payload than its length: refuse before allocating what a corrupt header asks for
+        struct stat st;
+        const uint64_t head_bytes = (6 + a->ndims) * sizeof(uint64_t);
+        if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && ((uint64_t)st.st_size < head_bytes || a->size > (uint64_t)st.st_size - head_bytes)) {
+            fprintf(stderr, "RawArray: file holds fewer than the %llu data bytes its header declares.\n", (unsigned long long)a->size);
+            close(fd);
+            free(a->dims);
+            a->dims = nullptr;
+            return EX_IOERR;
+        }
     }
     a->data = static_cast<uint8_t *>(malloc(a->size ? a->size : 1));
     if (!a->data) {
