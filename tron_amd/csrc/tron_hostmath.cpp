@@ -247,7 +247,7 @@ extern "C" void tron_config_default(tron_config *cfg)
     cfg->data_undersamp = 1.f;    // src/tron.cu:69
     cfg->blocks = 4096;           // src/tron.cu:59
     cfg->threads = 128;           // src/tron.cu:58
-    cfg->kb_mode = TRON_KB_EXACT;
+    cfg->kb_mode = TRON_KB_FAST;
 }
 
 // main()'s dimension logic.  Adjoint: src/tron.cu:905-935; forward: :936-961; the int <- float

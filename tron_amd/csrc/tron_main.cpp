@@ -77,7 +77,6 @@ int main(int argc, char *argv[])
     }
     const char *infile = argv[optind];
     const char *outfile = optind + 1 < argc ? argv[optind + 1] : "img_tron.ra";   // src/tron.cu:877
-    cfg.kb_mode = TRON_KB_FAST;
     if (const char *kb = getenv("TRON_KB_MODE")) cfg.kb_mode = strcmp(kb, "exact") == 0 ? TRON_KB_EXACT : TRON_KB_FAST;
 
 #define VPRINT(...) do { if (cfg.verbose) printf(__VA_ARGS__); } while (0)
