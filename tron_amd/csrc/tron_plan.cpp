@@ -3,8 +3,9 @@
 // (tron_init / tron_shutdown / tron_nufft_adj_radial2d / tron_nufft_radial2d / recon_radial2d).
 //
 // Differences of structure (not of results) from the reference:
-//   * all slices of a run are batched: one gridding launch, one batched rocFFT and one fused tail
-//     kernel per chunk of slices, instead of 8 kernels + 2 copies per slice on alternating streams;
+//   * all slices of a run are batched: one gridding launch and one fused FFT + tail (two kernels at the
+//     512 -> 256 size, batched rocFFT + one tail kernel otherwise) per chunk of slices, instead of
+//     8 kernels + 2 copies per slice on alternating streams;
 //   * the spoke stream is uploaded ONCE and sliding windows (src/tron.cu:738-739) are views into
 //     it; the reference re-uploads every window (each spoke ~10x for the whole-body run);
 //   * the Cartesian data is coil-planar and stored in FFT-native order, so both fftshift passes,
