@@ -67,3 +67,19 @@ def test_hip_forward_agrees_with_irt_on_shepp_logan():
     from tron_amd import lib
     scale, resid, magdiff = _compare(lambda img: lib.recon(img, adjoint=False, kb_mode=lib.KB_FAST)[0], N=128)
     assert abs(scale - 1) < 5e-3 and resid < 5e-3 and magdiff < 5e-3, (scale, resid, magdiff)
+
+
+def test_irt_constants_match_survey_probe():
+    """The survey's own (independent) restatement of nufft_alpha_kb_fit / nufft_scale / nufft_T printed these values for
+    N = 256, J = 4, K = 512; two restatements of the same MATLAB lines agreeing to seven digits
+    pins this one beyond the DTFT check."""
+    from oracle import irt_nufft as irt
+    alpha, beta = irt.alpha_kb_fit(256, 4, 512)
+    want = [1.392145, -0.5501213, 0.2323376, -0.1017725, 0.04418496, -0.01836131, 7.103336e-3, -2.495337e-3,
+            7.757259e-4, -2.069705e-4, 4.547892e-5, -7.724912e-6, 9.039789e-7, -5.489152e-8]
+    assert len(alpha) == len(want)
+    assert np.allclose(alpha, want, rtol=2e-6, atol=0)
+    sn = irt.nufft_scale(256, 512, alpha, beta)
+    assert abs(sn[0].real - 0.99917) < 1e-5 and abs(sn[127].real - 0.61511) < 1e-5
+    T = irt.nufft_T(256, 4, 512, alpha, beta)
+    assert np.allclose(np.diag(T), [10.054, 25.238, 25.238, 10.054], atol=1e-3)
