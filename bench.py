@@ -56,6 +56,41 @@ def cpu_baseline(nc, sample_slices, undersamp=0.7852):
                        f"(OpenMP over grid points, {threads} threads), {dt:.1f} s wall"), out
 
 
+def irt_baseline(nc, sample_slices):
+    """The comparator the reference measures itself against: Fessler's IRT NUFFT (contrib/irt, MATLAB), here the
+    numpy/scipy restatement oracle/irt_nufft.py (double precision, sparse interpolation matrix with 16 non-zeros per
+    sample), used as the reference's own scripts do (src/RUNME4_others_grid_slcmt.m:112-130): nufft_init per slice
+    (the trajectory rotates with the window), density weights multiplied in by the caller, nufft_adj per coil."""
+    import numpy as np
+    from oracle import irt_nufft as irt
+    rng = np.random.default_rng(5)
+    r = np.arange(NRO) / NRO - 0.5
+    dcf = np.abs(r)[:, None] * np.ones((1, NPE))
+    t_init = t_adj = 0.0
+    for z in range(sample_slices):
+        pe = (np.arange(NPE) + z * NPE).astype(np.float32)
+        th = np.fmod((np.float32(1.9416089796736116) * pe).astype(np.float64), 2 * np.pi)     # src/tron.cu:90,509
+        kx = (r[:, None] * np.cos(th)[None, :]).reshape(-1, order="F")
+        ky = (r[:, None] * np.sin(th)[None, :]).reshape(-1, order="F")
+        om = 2 * np.pi * np.stack([kx, ky], axis=1)
+        t0 = time.perf_counter()
+        st = irt.Nufft(om, (NX, NX), (4, 4), (NXOS, NXOS), (NX // 2, NX // 2))
+        t1 = time.perf_counter()
+        sos = np.zeros((NX, NX))
+        for c in range(nc):
+            X = (rng.random(NRO * NPE) * 2 - 1) + 1j * (rng.random(NRO * NPE) * 2 - 1)
+            img = st.adjoint(X * dcf.reshape(-1, order="F"))
+            sos += np.abs(img) ** 2
+        t2 = time.perf_counter()
+        t_init += t1 - t0
+        t_adj += t2 - t1
+    tot = t_init + t_adj
+    return dict(value=round(sample_slices / tot, 4), unit="slices/s", cores=1, kind="irt-restatement",
+                value_excluding_init=round(sample_slices / t_adj, 3),
+                sample=f"{sample_slices} slice(s) x {nc} coil(s) of 512x{NPE} golden-angle: nufft_init per slice "
+                       f"({t_init / sample_slices:.2f} s) + {nc} nufft_adj ({t_adj / sample_slices:.2f} s), numpy/scipy, double precision, 1 thread")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -69,6 +104,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=0, help="slices per internal batch (0 = auto)")
     ap.add_argument("--cpu-slices", type=int, default=-1,
                     help="slices of the CPU-baseline sample (0 = skip; -1 = sized for about 12 s of wall time, 2..32 slices)")
+    ap.add_argument("--irt-slices", type=int, default=2, help="slices of the IRT (contrib/irt restatement) CPU comparator sample (0 = skip)")
     ap.add_argument("--no-check", action="store_true")
     args = ap.parse_args()
 
@@ -186,6 +222,7 @@ def main():
                 n_cpu = max(2, min(32, int(round(12.0 * probe["value"]))))
             cpu, _ = cpu_baseline(nc, n_cpu, undersamp)
             cpu["value"] = round(cpu["value"], 4)
+        irt_cpu = irt_baseline(nc, args.irt_slices) if (args.irt_slices > 0 and world == 1 and args.cpu_slices != 0) else None
         if not args.no_check:
             # the timed path produced real images: spot-check one slice of this rank against the oracle
             sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -227,7 +264,7 @@ def main():
             "copy_ceiling_gbps": copy_gbps, "hbm_frac_of_copy_ceiling": round(hbm_gbps / copy_gbps, 4) if copy_gbps else None,
             "coil_slices_per_s": round(value * nc, 1),
             "parity_rel_l2_vs_oracle": err,
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "irt_baseline": irt_cpu,
         }
     plan.close()
     if world > 1:
