@@ -456,9 +456,12 @@ grid_binned_kernel(const GridParams p)
                     }
                     if (CPB % 2 == 0) {
                         const float4 *d4 = reinterpret_cast<const float4 *>(L.d) + id;
+                        float4 dd[CPB / 2 > 0 ? CPB / 2 : 1];
+#pragma unroll
+                        for (int c = 0; c < CPB / 2; ++c) dd[c] = d4[c * C::NREC];
 #pragma unroll
                         for (int c = 0; c < CPB / 2; ++c) {
-                            const float4 d = d4[c * C::NREC];
+                            const float4 d = dd[c];
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
                                 acc[q][2 * c].x = fmaf(d.x, wq[q], acc[q][2 * c].x);              // src/tron.cu:519
