@@ -313,12 +313,27 @@ __global__ void __launch_bounds__(256) fft512_fwd_rows_lds_kernel(const Fft512Fw
             }
         }
     }
+    // the 1/w factors depend on (row, column) only: fetched once per image row and wave, the first set while the
+    // image rows are still on their way into LDS
+    float inv[4];
+    int inv_rl = -1;
+    auto load_inv = [&](int rl) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int q = t < 2 ? t : t + 4;
+            const int y = t < 2 ? 128 + 64 * q + lane : 64 * (q - 6) + lane;
+            inv[t] = p.inv_deapod[(size_t)(r0 + rl + 128) * kF + (y + 128)];
+        }
+        inv_rl = rl;
+    };
+    if (wave < nlines) load_inv(wave / p.nchan);
     __syncthreads();
     float2 *xch = s_x + wave * kXch;
     for (int L = wave; L < nlines; L += 4) {
         const int rl = L / p.nchan, c = L - rl * p.nchan;
         const int r = r0 + rl;
         const float2 *lin = s_in + L * kInPitch;
+        if (rl != inv_rl) load_inv(rl);
         float2 v[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) v[q] = make_float2(0.f, 0.f);
@@ -328,8 +343,7 @@ __global__ void __launch_bounds__(256) fft512_fwd_rows_lds_kernel(const Fft512Fw
             const int y = t < 2 ? 128 + 64 * q + lane : 64 * (q - 6) + lane;
             if (r > 0 && y > 0) {                                                   // src/tron.cu:449-450
                 float2 u = lin[y];
-                const float inv = p.inv_deapod[(size_t)(r + 128) * kF + (y + 128)];
-                u.x *= inv; u.y *= inv;
+                u.x *= inv[t]; u.y *= inv[t];
                 v[q] = cconj(u);
             }
         }
