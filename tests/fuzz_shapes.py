@@ -1,6 +1,6 @@
 """Random-shape cross-check (tooling): the fast paths (binned gridding, tiled degridding with packed polynomials,
 fused FFTs) against the reference-order exact mode on the GPU, and both against the CPU oracle when the case is
-small enough.  usage: python tools/fuzz.py [ncases] [seed]"""
+small enough.  usage: python tests/fuzz_shapes.py [ncases] [seed]   (test infrastructure: the only users of oracle/ live under tests/)"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
