@@ -316,3 +316,40 @@ def test_many_spokes_clip_rounds(oracle, kb):
     assert p.npe1work == 601
     got, _ = lib.recon(img, adjoint=False, kb_mode=kb, golden_angle=1, data_undersamp=9.4)
     assert rel_l2(got, want) <= TOL_PIPELINE
+
+
+def test_cli_complex_half_input_and_flag_variants(oracle, tmp_path):
+    """The `tron` binary end to end: a complex-half .ra input (eltype 4 / elbyte 4, BASELINE config 5) is gridded from
+    half storage; non-default -k / -o / -s / -d travel through getopt to the kernels."""
+    import os, subprocess
+    from tron_amd import ra
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tron = os.path.join(root, "tron_amd", "bin", "tron")
+    data = synth.kspace(4, 48, 70, seed=1201)
+    h16 = np.asfortranarray(data).reshape(-1, order="F").view(np.float32).astype(np.float16)
+    rounded = h16.astype(np.float32).view(np.complex64).reshape(data.shape, order="F")
+    inp, out = str(tmp_path / "half.ra"), str(tmp_path / "img.ra")
+    ra.write(inp, h16.reshape((2,) + data.shape, order="F"), complex_half=True)
+    assert subprocess.run([tron, "-a", "-G", "-u", "0.5", "-d", "9", inp, out]).returncode == 0
+    want, _ = oracle.recon(rounded, adjoint=1, golden=1, data_undersamp=0.5, prof_slide=9)
+    got = ra.read(out)
+    assert got.shape == want.shape and rel_l2(got, want) <= TOL_PIPELINE
+    # fp32 input, wider kernel, lower oversampling, angle offset
+    inp2 = str(tmp_path / "f32.ra")
+    ra.write(inp2, data)
+    assert subprocess.run([tron, "-a", "-G", "-k", "2.5", "-o", "1.5", "-s", "17", "-u", "0.6", "-d", "20", inp2, out]).returncode == 0
+    want, _ = oracle.recon(data, adjoint=1, golden=1, kernwidth=2.5, gridos=1.5, skip_angles=17, data_undersamp=0.6, prof_slide=20)
+    got = ra.read(out)
+    assert got.shape == want.shape and rel_l2(got, want) <= TOL_PIPELINE
+    # forward, linear angles, two coils
+    img = synth.image(2, 24, seed=1202)
+    ra.write(inp2, img)
+    assert subprocess.run([tron, "-k", "1.5", inp2, out]).returncode == 0
+    want, _ = oracle.recon(img, adjoint=0, golden=0, kernwidth=1.5)
+    # the reference's forward header keeps dims[0] = 1 while the payload holds all coils (SURVEY Q11): compare the payload
+    h = ra.read_header(out)
+    assert h.dims[0] == 1 and h.size == want.size * 8
+    with open(out, "rb") as f:
+        f.seek(h.nbytes_header)
+        got = np.frombuffer(f.read(h.size), np.complex64)
+    assert rel_l2(got, want.reshape(-1, order="F")) <= TOL_PIPELINE
