@@ -353,3 +353,37 @@ def test_cli_complex_half_input_and_flag_variants(oracle, tmp_path):
         f.seek(h.nbytes_header)
         got = np.frombuffer(f.read(h.size), np.complex64)
     assert rel_l2(got, want.reshape(-1, order="F")) <= TOL_PIPELINE
+
+
+def test_two_plans_alive_and_threads(oracle):
+    """Plans are independent objects (no globals, unlike src/tron.cu:54-87): an adjoint and a forward plan alive at once,
+    used alternately, and two plans driven from two host threads, give the results of isolated runs."""
+    import threading
+    data = synth.kspace(2, 64, 60, seed=1301)
+    img = synth.image(2, 32, seed=1302)
+    fa = dict(golden_angle=1, data_undersamp=0.5, prof_slide=10)
+    ff = dict(golden_angle=1)
+    ref_a, _ = lib.recon(data, adjoint=True, **fa)
+    ref_f, _ = lib.recon(img, adjoint=False, **ff)
+    ca, cf = lib.default_config(adjoint=1, **fa), lib.default_config(adjoint=0, **ff)
+    da, df = lib.derive_dims(ca, data.shape), lib.derive_dims(cf, img.shape)
+    flat_a = np.asfortranarray(data).reshape(-1, order="F")
+    flat_f = np.asfortranarray(img).reshape(-1, order="F")
+    with lib.Plan(ca, da) as pa, lib.Plan(cf, df) as pf:
+        for _ in range(3):
+            oa = np.zeros(da.out_bytes // 8, np.complex64)
+            of = np.zeros(df.out_bytes // 8, np.complex64)
+            pa.recon(flat_a, out=oa)
+            pf.recon(flat_f, out=of)
+            assert np.array_equal(oa, ref_a.reshape(-1, order="F")) and np.array_equal(of, ref_f.reshape(-1, order="F"))
+        res = {}
+
+        def work(name, plan, flat, nbytes):
+            o = np.zeros(nbytes // 8, np.complex64)
+            for _ in range(4):
+                plan.recon(flat, out=o)
+            res[name] = o
+        ta = threading.Thread(target=work, args=("a", pa, flat_a, da.out_bytes))
+        tf = threading.Thread(target=work, args=("f", pf, flat_f, df.out_bytes))
+        ta.start(); tf.start(); ta.join(); tf.join()
+        assert np.array_equal(res["a"], ref_a.reshape(-1, order="F")) and np.array_equal(res["f"], ref_f.reshape(-1, order="F"))
