@@ -1,0 +1,55 @@
+/* Minimal C99 client of the C ABI (include/tron_hip.h, include/rawarray.h): what a TRON maintainer's
+   main() does after getopt -- read a .ra file, run recon_radial2d's replacement, write a .ra file.
+     gcc -std=c99 -Iinclude examples/recon_c_abi.c -Ltron_amd/lib -ltronhip -Wl,-rpath,$PWD/tron_amd/lib -o recon_c_abi
+     ./recon_c_abi -a in.ra out.ra        (adjoint, golden angle)      ./recon_c_abi in.ra out.ra   (forward) */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "rawarray.h"
+#include "tron_hip.h"
+
+int main(int argc, char **argv)
+{
+    int adjoint = 0, arg = 1;
+    if (argc > 1 && strcmp(argv[1], "-a") == 0) { adjoint = 1; arg = 2; }
+    if (argc - arg < 2) {
+        fprintf(stderr, "usage: %s [-a] in.ra out.ra\n", argv[0]);
+        return 1;
+    }
+    ra_t in, out;
+    if (ra_read(&in, argv[arg]) != 0) return 1;
+    if (in.ndims != 5 || in.eltype != RA_TYPE_COMPLEX || in.elbyte != 8) {
+        fprintf(stderr, "expected a 5-D complex64 array\n");
+        return 1;
+    }
+    tron_config cfg;
+    tron_config_default(&cfg);            /* the reference's defaults, src/tron.cu:58-87 */
+    cfg.adjoint = adjoint;
+    cfg.golden_angle = 1;
+    tron_dims dims;
+    tron_plan *plan = NULL;
+    if (tron_derive_dims(&cfg, in.dims, &dims) != TRON_OK || tron_plan_create(&plan, &cfg, &dims) != TRON_OK) {
+        fprintf(stderr, "%s\n", tron_last_error());
+        return 1;
+    }
+    memset(&out, 0, sizeof(out));
+    out.eltype = RA_TYPE_COMPLEX;
+    out.elbyte = 8;
+    out.ndims = 5;
+    out.size = dims.out_bytes;
+    out.dims = (uint64_t *)malloc(5 * sizeof(uint64_t));
+    out.data = (uint8_t *)calloc(dims.out_bytes ? dims.out_bytes : 1, 1);
+    memcpy(out.dims, dims.out_dims, 5 * sizeof(uint64_t));
+    if (tron_recon_radial2d(plan, (tron_float2 *)out.data, (const tron_float2 *)in.data) != TRON_OK) {
+        fprintf(stderr, "%s\n", tron_last_error());
+        return 1;
+    }
+    tron_plan_destroy(plan);
+    if (ra_write(&out, argv[arg + 1]) != 0) return 1;
+    printf("%s: %d slice(s) of %d x %d -> %s (libtronhip %s)\n", adjoint ? "adjoint" : "forward", dims.nz, dims.nx, dims.ny,
+           argv[arg + 1], tron_version());
+    ra_free(&in);
+    ra_free(&out);
+    return 0;
+}

@@ -387,3 +387,18 @@ def test_two_plans_alive_and_threads(oracle):
         tf = threading.Thread(target=work, args=("f", pf, flat_f, df.out_bytes))
         ta.start(); tf.start(); ta.join(); tf.join()
         assert np.array_equal(res["a"], ref_a.reshape(-1, order="F")) and np.array_equal(res["f"], ref_f.reshape(-1, order="F"))
+
+
+def test_c_client_matches_the_tron_binary(tmp_path):
+    """examples/recon_c_abi.c (a C99 program against the C ABI) writes the same bytes as the tron binary."""
+    import os, subprocess
+    from test_host import _build_c_example
+    from tron_amd import ra
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = _build_c_example(tmp_path)
+    data = synth.kspace(2, 32, 40, seed=1401)
+    inp, o1, o2 = (str(tmp_path / n) for n in ("in.ra", "c.ra", "t.ra"))
+    ra.write(inp, data)
+    assert subprocess.run([exe, "-a", inp, o1]).returncode == 0
+    assert subprocess.run([os.path.join(root, "tron_amd", "bin", "tron"), "-a", "-G", inp, o2]).returncode == 0
+    assert open(o1, "rb").read() == open(o2, "rb").read()

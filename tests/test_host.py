@@ -283,3 +283,24 @@ def test_half_matches_numpy_on_normals():
     x = (rng.uniform(-4, 4, 20000)).astype(np.float32)
     got = np.array([mine.ra_float_to_half_bits(int(b)) for b in x.view(np.uint32)], np.uint16)
     assert np.array_equal(got, x.astype(np.float16).view(np.uint16))
+
+
+def _build_c_example(tmp_path):
+    import shutil, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "recon_c_abi")
+    cmd = ["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(root, "include"),
+           os.path.join(root, "examples", "recon_c_abi.c"), "-L" + os.path.join(root, "tron_amd", "lib"), "-ltronhip",
+           "-Wl,-rpath," + os.path.join(root, "tron_amd", "lib"), "-Wl,-rpath-link,/opt/rocm/lib", "-L/opt/rocm/lib", "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return exe
+
+
+def test_headers_are_plain_c99_and_the_c_example_links(tmp_path):
+    """include/tron_hip.h and include/rawarray.h compile as pedantic C99 (no HIP or C++ types at the boundary) and a C
+    client links against libtronhip.so (examples/recon_c_abi.c)."""
+    import shutil
+    if shutil.which("gcc") is None:
+        pytest.skip("needs gcc")
+    _build_c_example(tmp_path)
