@@ -402,3 +402,19 @@ def test_c_client_matches_the_tron_binary(tmp_path):
     assert subprocess.run([exe, "-a", inp, o1]).returncode == 0
     assert subprocess.run([os.path.join(root, "tron_amd", "bin", "tron"), "-a", "-G", inp, o2]).returncode == 0
     assert open(o1, "rb").read() == open(o2, "rb").read()
+
+
+def test_two_lane_pipeline_option(monkeypatch):
+    """TRON_DUAL_STREAM=1 (gridding and FFT on two streams, two work grids) gives the bytes of the default
+    single-stream pipeline, with enough batches to recycle both buffers."""
+    data = synth.kspace(2, 512, 9 * 20, seed=1501)
+    flags = dict(golden_angle=1, data_undersamp=20 / 512 + 1e-6, prof_slide=20)
+    monkeypatch.setenv("TRON_CHUNK_SLICES", "2")
+    ref, d = lib.recon(data, adjoint=True, **flags)
+    assert d.nz == 9 and d.nxos == 512
+    monkeypatch.setenv("TRON_DUAL_STREAM", "1")
+    got, _ = lib.recon(data, adjoint=True, **flags)
+    assert np.array_equal(got, ref)
+    monkeypatch.setenv("TRON_CU_SPLIT", "4")
+    got, _ = lib.recon(data, adjoint=True, **flags)
+    assert np.array_equal(got, ref)
