@@ -91,6 +91,89 @@ def irt_baseline(nc, sample_slices):
                        f"({t_init / sample_slices:.2f} s) + {nc} nufft_adj ({t_adj / sample_slices:.2f} s), numpy/scipy, double precision, 1 thread")
 
 
+def forward_bench(args, rank, local_rank, world, torch, dist, lib):
+    """Secondary line (not the headline metric): the forward NUFFT, src/tron.cu:639-649 -- pad, deapodise, FFT, degrid --
+    on `--slices` images of 256^2 x C coils per step -> 512 readout x 512 golden-angle spokes each, device resident."""
+    import ctypes
+    import numpy as np
+    nc, nimg = args.coils, min(args.slices, 64)
+    cfg = lib.default_config(adjoint=0, golden_angle=1, device=local_rank, kb_mode=lib.KB_FAST if args.kb == "fast" else lib.KB_EXACT)
+    dims = lib.derive_dims(cfg, (nc, 1, NX, NX, 1))
+    nro, npe = dims.nro, dims.npe1work
+    plan = lib.Plan(cfg, dims)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(0x54524F4E + 100 + rank)
+    imgs = torch.rand(2 * nc * NX * NX * nimg, device="cuda", generator=g, dtype=torch.float32) * 2 - 1
+    out = torch.empty(2 * nc * nro * npe * nimg, device="cuda", dtype=torch.float32)
+    d_in, d_out = ctypes.c_void_p(imgs.data_ptr()), ctypes.c_void_p(out.data_ptr())
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        plan.forward_device(d_out, d_in, nimg)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        plan.forward_device(d_out, d_in, nimg)
+    fence()
+    dt = time.perf_counter() - t0
+    plan.sync()
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    value = world * nimg * args.steps / dt
+    result = None
+    if rank == 0:
+        plan.timing(True)
+        plan.timing_reset()
+        reps = 3
+        for _ in range(reps):
+            plan.forward_device(d_out, d_in, nimg)
+        stages = {}
+        for st, name in {lib.STAGE_PRE: "pre", lib.STAGE_FFT: "fft", lib.STAGE_DEGRID: "degrid"}.items():
+            ms, n = plan.timing_get(st)
+            if n:
+                stages[name] = (ms, n)
+        plan.timing(False)
+        # SURVEY 8(d), forward: image + padded grid write + FFT read/write + grid read + samples
+        per_ci = 8 * NX * NX + 8 * NXOS * NXOS + 16 * NXOS * NXOS + 8 * NXOS * NXOS + 8 * nro * npe
+        ms, n = stages["degrid"]
+        alg = 8 * NXOS * NXOS + 8 * nro * npe                    # degridding alone: grid read + sample write
+        achieved = alg * nc * nimg * reps / n / (ms / n * 1e-3) / 1e9
+        err = None
+        if not args.no_check:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from oracle import pyoracle
+            host = imgs[: 2 * nc * NX * NX].cpu().numpy().view(np.complex64).reshape((nc, 1, NX, NX, 1), order="F")
+            want, _ = pyoracle.recon(host, adjoint=0, golden=1)
+            got = out[: 2 * nc * nro * npe].cpu().numpy().view(np.complex64)
+            err = float(np.linalg.norm(got - want.reshape(-1, order="F")) / np.linalg.norm(want))
+        gbps = per_ci * nc * value / world / 1e9
+        result = {
+            "metric": "2D images/sec degridded (256^2 image -> 512^2 grid -> 512x512 golden-angle spokes) + achieved HBM GB/s",
+            "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"forward NUFFT: {nimg} images/GPU/step x {nc} coils, 256^2 -> 512^2 grid -> {nro} readout x {npe} golden-angle spokes (tron -G)",
+                       "coils": nc, "images_per_gpu": nimg, "kb_mode": args.kb},
+            "hbm_gbps_per_gpu": round(gbps, 1), "hbm_frac_of_peak": round(gbps / HBM_PEAK_GBPS, 4),
+            "parity_rel_l2_vs_oracle": err,
+            "roofline": {"bound": "hbm", "kernel": "degrid_tile_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "launch_ms": round(ms / n, 4),
+                         "stage_share": {k: round(v[0] / sum(x[0] for x in stages.values()), 3) for k, v in stages.items()}},
+            "cpu_baseline": None,
+        }
+    plan.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -105,6 +188,8 @@ def main():
     ap.add_argument("--cpu-slices", type=int, default=-1,
                     help="slices of the CPU-baseline sample (0 = skip; -1 = sized for about 12 s of wall time, 2..32 slices)")
     ap.add_argument("--irt-slices", type=int, default=2, help="slices of the IRT (contrib/irt restatement) CPU comparator sample (0 = skip)")
+    ap.add_argument("--forward", action="store_true",
+                    help="measure the forward (degridding) direction instead: --slices images of 256^2 -> 512 x 512 golden-angle spokes")
     ap.add_argument("--no-check", action="store_true")
     args = ap.parse_args()
 
@@ -129,6 +214,8 @@ def main():
     import numpy as np
     from tron_amd import lib
 
+    if args.forward:
+        return forward_bench(args, rank, local_rank, world, torch, dist, lib)
     global NPE
     NPE = args.spokes
     undersamp = 0.7852 if NPE == 402 else (NPE + 0.5) / NRO    # tron -u: npe1work = int(nro*u), src/tron.cu:925
