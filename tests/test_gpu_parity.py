@@ -418,3 +418,28 @@ def test_two_lane_pipeline_option(monkeypatch):
     monkeypatch.setenv("TRON_CU_SPLIT", "4")
     got, _ = lib.recon(data, adjoint=True, **flags)
     assert np.array_equal(got, ref)
+
+
+def test_forward_batches_split_into_chunks(oracle, monkeypatch):
+    """tron_nufft_radial2d on more images than one internal batch holds (fused 256 -> 512 path and the rocFFT path):
+    every image equals the oracle's forward of that image."""
+    nc, nimg = 2, 7
+    imgs = [synth.image(nc, 256, seed=1600 + k) for k in range(nimg)]
+    flags = dict(golden_angle=1, data_undersamp=24 / 512 + 1e-6)
+    wants = [oracle.recon(im, adjoint=0, golden=1, data_undersamp=24 / 512 + 1e-6)[0].reshape(-1, order="F") for im in imgs[:2] + imgs[-1:]]
+    flat = np.concatenate([np.asfortranarray(im).reshape(-1, order="F") for im in imgs])
+    for fft in ("fused", "rocfft"):
+        if fft == "rocfft":
+            monkeypatch.setenv("TRON_FFT", "rocfft")
+        monkeypatch.setenv("TRON_CHUNK_SLICES", "3")
+        cfg = lib.default_config(adjoint=0, **flags)
+        dims = lib.derive_dims(cfg, imgs[0].shape)
+        per = nc * dims.nro * dims.npe1work
+        with lib.Plan(cfg, dims) as plan:
+            d_in = lib.DeviceBuffer.from_numpy(flat)
+            d_out = lib.DeviceBuffer(nimg * per * 8)
+            plan.forward_device(d_out.ptr, d_in.ptr, nimg)
+            plan.sync()
+            got = d_out.to_numpy(np.complex64, nimg * per)
+        for k, want in zip((0, 1, nimg - 1), wants):
+            assert rel_l2(got[k * per:(k + 1) * per], want) <= TOL_PIPELINE, (fft, k)
