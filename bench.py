@@ -1,14 +1,17 @@
 #!/usr/bin/env python3
 """Throughput of the radial gridding reconstruction (adjoint NUFFT) on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--coils C] [--slices S] [--kb fast|exact]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--coils C] [--slices S] [--kb fast|exact] [--scaling weak|strong]
 
 One "step" = one pass of the hot path (density compensation + Kaiser-Bessel gridding + 2-D FFT +
 crop/deapodise/coil-combine) over one batch of S slices of synthetic golden-angle radial k-space,
 512 readout x 402 spokes x C coils per slice onto a 512^2 grid -> 256^2 images, inputs and
-outputs resident in HBM.  For N > 1 every rank (one process per GPU, launched by
-torch.distributed.run) processes its own S slices: slices are independent, there is no
-collective on the data path, scaling is weak.
+outputs resident in HBM.  For N > 1 there is one process per GPU -- started by torch.distributed.run
+(RANK/LOCAL_RANK/WORLD_SIZE in the environment) or, when those are absent, spawned by this script
+itself before anything touches the GPU.  Slices are independent, so there is no collective on the
+data path; ranks meet over gloo on the host only for the barrier and the max-over-ranks time.
+--scaling weak (default): every rank its own S slices; --scaling strong: S slices in total, rank r
+takes the contiguous block partition(S, N, r) (BASELINE config 4 literally).
 
 Prints ONE JSON line (rank 0): whole-job slices/s plus
   roofline      the dominant kernel's algorithmic bytes / its mean hipEvent duration, vs 8 TB/s
@@ -91,7 +94,7 @@ def irt_baseline(nc, sample_slices):
                        f"({t_init / sample_slices:.2f} s) + {nc} nufft_adj ({t_adj / sample_slices:.2f} s), numpy/scipy, double precision, 1 thread")
 
 
-def forward_bench(args, rank, local_rank, world, torch, dist, lib):
+def forward_bench(args, rank, local_rank, world, torch, group, lib):
     """Secondary line (not the headline metric): the forward NUFFT, src/tron.cu:639-649 -- pad, deapodise, FFT, degrid --
     on `--slices` images of 256^2 x C coils per step -> 512 readout x 512 golden-angle spokes each, device resident."""
     import ctypes
@@ -108,9 +111,10 @@ def forward_bench(args, rank, local_rank, world, torch, dist, lib):
     d_in, d_out = ctypes.c_void_p(imgs.data_ptr()), ctypes.c_void_p(out.data_ptr())
 
     def fence():
-        if world > 1:
-            dist.barrier()
         torch.cuda.synchronize()
+        group.barrier()
+        torch.cuda.synchronize()
+    torch.cuda.synchronize()          # inputs were generated on torch's stream, the library runs on its own
     for _ in range(args.warmup):
         plan.forward_device(d_out, d_in, nimg)
     fence()
@@ -120,10 +124,7 @@ def forward_bench(args, rank, local_rank, world, torch, dist, lib):
     fence()
     dt = time.perf_counter() - t0
     plan.sync()
-    if world > 1:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = group.max(dt)
     value = world * nimg * args.steps / dt
     result = None
     if rank == 0:
@@ -159,7 +160,7 @@ def forward_bench(args, rank, local_rank, world, torch, dist, lib):
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"forward NUFFT: {nimg} images/GPU/step x {nc} coils, 256^2 -> 512^2 grid -> {nro} readout x {npe} golden-angle spokes (tron -G)",
                        "coils": nc, "images_per_gpu": nimg, "kb_mode": args.kb},
-            "hbm_gbps_per_gpu": round(gbps, 1), "hbm_frac_of_peak": round(gbps / HBM_PEAK_GBPS, 4),
+            "algorithmic_gbps_per_gpu": round(gbps, 1), "algorithmic_frac_of_peak": round(gbps / HBM_PEAK_GBPS, 4),
             "parity_rel_l2_vs_oracle": err,
             "roofline": {"bound": "hbm", "kernel": "degrid_tile_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "launch_ms": round(ms / n, 4),
@@ -167,20 +168,20 @@ def forward_bench(args, rank, local_rank, world, torch, dist, lib):
             "cpu_baseline": None,
         }
     plan.close()
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    group.close()
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--coils", type=int, default=8)
-    ap.add_argument("--slices", type=int, default=256, help="slices per GPU per step")
+    ap.add_argument("--slices", type=int, default=256, help="slices per GPU per step (weak) or in total (strong)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: every rank its own --slices; strong: --slices in total, contiguous blocks per rank (BASELINE config 4)")
     ap.add_argument("--spokes", type=int, default=402, help="spokes per slice (402 = the metric's shape; BASELINE config 4 has 804)")
     ap.add_argument("--kb", choices=["fast", "exact"], default="fast")
     ap.add_argument("--half", action="store_true", help="k-space stored as complex-half in HBM (BASELINE config 5); fp32 accumulate and FFT")
@@ -191,38 +192,97 @@ def main():
     ap.add_argument("--forward", action="store_true",
                     help="measure the forward (degridding) direction instead: --slices images of 256^2 -> 512 x 512 golden-angle spokes")
     ap.add_argument("--no-check", action="store_true")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without an external launcher: N children, one per GPU, started before this
+    process has made any torch / HIP call.  The JSON line of rank 0 is printed only if every rank exited 0."""
+    from tron_amd import launch
+    code, out0 = launch.spawn_ranks([os.path.abspath(__file__)] + sys.argv[1:], args.gpus)
+    line = None
+    for ln in out0.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+    if code != 0 or line is None:
+        sys.stderr.write(f"bench.py: {args.gpus}-rank run failed (exit code {code}); no result line printed\n")
+        return code if code != 0 else 1
+    if json.loads(line).get("n_gpus") != args.gpus:
+        sys.stderr.write("bench.py: result line does not carry the requested rank count; refusing to print it\n")
+        return 1
+    print(line, flush=True)
+    return 0
+
+
+def traffic_capture(kernel_prefix, units_per_launch_now):
+    """HBM bytes per launch of the dominant kernel from the PMC capture under profiles/ -- used only when that
+    capture was taken on THESE kernel sources (tools/traffic.sh stamps it with buildinfo.kernel_source_hash()).
+    Returns (bytes_per_launch or None, stale flag, note)."""
+    from tron_amd.buildinfo import kernel_source_hash
+    path = os.path.join(ROOT, "profiles", "traffic_current.json")
+    try:
+        tj = json.load(open(path))
+    except Exception:
+        return None, True, "no capture"
+    if tj.get("source_hash") != kernel_source_hash():
+        return None, True, f"capture {tj.get('source_hash')} != sources {kernel_source_hash()}"
+    for name, c in tj.get("kernels", {}).items():
+        if name.startswith(kernel_prefix) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            per_launch = (2.0 * c["FETCH_SIZE"]["kib"] / c["FETCH_SIZE"]["dispatches"]
+                          + c["WRITE_SIZE"]["kib"] / c["WRITE_SIZE"]["dispatches"]) * 1024.0
+            scale = units_per_launch_now / float(tj.get("coil_slices_per_launch", units_per_launch_now))
+            return int(per_launch * scale), False, tj.get("command", "")
+    return None, True, "kernel not in capture"
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     # torch first: it brings the HIP runtime every later library (ours included) binds to
     import torch
-    import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
+    ndev = torch.cuda.device_count()
+    share = os.environ.get("TRON_BENCH_SHARE_GPU") == "1"      # plumbing tests on a 1-GPU box only; flagged on the line
+    if ndev <= local_rank:
+        if not share:
+            raise SystemExit(f"rank {rank}: {ndev} GPU(s) visible, --gpus {args.gpus} requested")
+        local_rank %= ndev
     torch.cuda.set_device(local_rank)
     torch.zeros(1, device="cuda")
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    from tron_amd import launch
+    group = launch.HostGroup(rank, world)      # gloo on the host: barrier + max of wall times, nothing on the data path
 
     import ctypes
     import numpy as np
     from tron_amd import lib
+    from tron_amd.shard import partition
 
     if args.forward:
-        return forward_bench(args, rank, local_rank, world, torch, dist, lib)
+        return forward_bench(args, rank, local_rank, world, torch, group, lib)
     global NPE
     NPE = args.spokes
     undersamp = 0.7852 if NPE == 402 else (NPE + 0.5) / NRO    # tron -u: npe1work = int(nro*u), src/tron.cu:925
-    nc, nz = args.coils, args.slices
+    nc = args.coils
+    if args.scaling == "strong":
+        zfirst, nz = partition(args.slices, world, rank)       # contiguous block of the ONE job (src/tron.cu:735-736 made contiguous)
+        if nz < 1:
+            raise SystemExit(f"rank {rank}: --scaling strong with {args.slices} slices leaves this rank without work")
+        total_slices = args.slices
+    else:
+        zfirst, nz = 0, args.slices
+        total_slices = world * nz
     cfg = lib.default_config(adjoint=1, golden_angle=1, data_undersamp=undersamp, prof_slide=NPE, device=local_rank,
                              kb_mode=lib.KB_FAST if args.kb == "fast" else lib.KB_EXACT, chunk_slices=args.chunk,
-                             input_half=1 if args.half else 0)
+                             input_half=1 if args.half else 0, skip_angles=zfirst * NPE)    # global angle index of this rank's first spoke
     dims = lib.derive_dims(cfg, (nc, 1, NRO, NPE * nz, 1))
     assert (dims.nz, dims.npe1work, dims.nxos, dims.nx) == (nz, NPE, NXOS, NX)
     plan = lib.Plan(cfg, dims)
@@ -235,14 +295,15 @@ def main():
         kspace = kspace.to(torch.float16)        # round-to-nearest-even, as src/float16.cu
     images = torch.empty(2 * NX * NX * nz, device="cuda", dtype=torch.float32)
     d_in, d_out = ctypes.c_void_p(kspace.data_ptr()), ctypes.c_void_p(images.data_ptr())
+    torch.cuda.synchronize()                     # inputs were generated on torch's stream, the library runs on its own
 
     def step():
         plan.adjoint_device(d_out, d_in, 0, nz, combine=1)
 
     def fence():
-        if world > 1:
-            dist.barrier()
         torch.cuda.synchronize()
+        plan.sync()                              # the library's stream is non-blocking: wait for it explicitly
+        group.barrier()
 
     for _ in range(args.warmup):
         step()
@@ -253,11 +314,8 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     plan.sync()   # surfaces a device-side error flag, if any
-    if world > 1:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    value = world * nz * args.steps / dt
+    dt = group.max(dt)
+    value = total_slices * args.steps / dt
 
     # per-kernel durations, measured live with hipEvents on the library's own stream
     ab = algorithmic_bytes(nc, args.half)
@@ -285,18 +343,14 @@ def main():
         kname = {"grid": "grid_binned_kernel" if args.kb == "fast" else "grid_tile_kernel",
                  "fft": "fft512_rows_kernel + fft512_cols_post_kernel" if "post" not in stages else "rocFFT 512x512 C2C inverse (batched)",
                  "post": "post_kernel"}[dom]
-        # HBM bytes the dominant kernel actually moved, from rocprofv3 PMC passes of this round
-        # (profiles/round1_v5_traffic.json: FETCH_SIZE x2 + WRITE_SIZE, separate passes), scaled to one launch
-        traffic = None
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "round1_v5_traffic.json")))["per_coil_slice_bytes_corrected"]
-            if dom == "grid" and args.kb == "fast" and nc == 8 and NPE == 402:
-                t = tj["grid_binned_kernel"]
-                traffic = int((t["read"] + t["write"]) * units_per_launch)
-        except Exception:
-            traffic = None
+        # HBM bytes the dominant kernel actually moved: rocprofv3 PMC capture of THIS build (FETCH_SIZE x2 + WRITE_SIZE,
+        # separate passes, MI355X_MICROARCH.md HBM section), else null + traffic_stale
+        traffic, stale, note = (None, True, "not the default workload")
+        if dom == "grid" and args.kb == "fast" and nc == 8 and NPE == 402 and not args.half:
+            traffic, stale, note = traffic_capture("grid_binned_kernel", units_per_launch)
         roofline = dict(bound="hbm", kernel=kname, achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
-                        frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=traffic, bytes_per_launch=int(bytes_per_launch),
+                        frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=traffic, traffic_stale=stale, traffic_source=note,
+                        bytes_per_launch=int(bytes_per_launch),
                         launch_ms=round(ms / n, 4), stage_share={k: round(v[0] / tot, 3) for k, v in stages.items()})
 
     result = None
@@ -311,18 +365,21 @@ def main():
             cpu["value"] = round(cpu["value"], 4)
         irt_cpu = irt_baseline(nc, args.irt_slices) if (args.irt_slices > 0 and world == 1 and args.cpu_slices != 0) else None
         if not args.no_check:
-            # the timed path produced real images: spot-check one slice of this rank against the oracle
+            # the timed path produced real images: spot-check the first and the last slice of this rank against the oracle
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             from oracle import pyoracle
-            host = kspace[: 2 * nc * NRO * NPE].float().cpu().numpy().view(np.complex64).reshape((nc, 1, NRO, NPE, 1), order="F")
-            want, _ = pyoracle.recon(host, adjoint=1, golden=1, data_undersamp=undersamp, prof_slide=NPE)
-            got = images[: 2 * NX * NX].cpu().numpy().view(np.complex64)
-            err = float(np.linalg.norm(got - want.reshape(-1, order="F")) / np.linalg.norm(want))
+            err = 0.0
+            for z in sorted({0, nz - 1}):
+                lo = 2 * nc * NRO * NPE * z
+                host = kspace[lo: lo + 2 * nc * NRO * NPE].float().cpu().numpy().view(np.complex64).reshape((nc, 1, NRO, NPE, 1), order="F")
+                want, _ = pyoracle.recon(host, adjoint=1, golden=1, data_undersamp=undersamp, prof_slide=NPE, skip_angles=(zfirst + z) * NPE)
+                got = images[2 * NX * NX * z: 2 * NX * NX * (z + 1)].cpu().numpy().view(np.complex64)
+                err = max(err, float(np.linalg.norm(got - want.reshape(-1, order="F")) / np.linalg.norm(want)))
             if not err <= 1e-5:
                 raise SystemExit(f"bench output disagrees with the oracle: rel L2 {err:.3e}")
         else:
             err = None
-        hbm_gbps = ab["per_slice"] * value / world / 1e9      # per GPU
+        alg_gbps = ab["per_slice"] * value / world / 1e9      # per GPU, SURVEY 8(d)'s algorithmic bytes (not measured traffic)
         # what a plain device-to-device copy reaches on this GPU (read + write bytes): the practical HBM ceiling
         copy_gbps = None
         try:
@@ -339,26 +396,28 @@ def main():
             del a, b
         except Exception:
             copy_gbps = None
+        per_gpu = f"{nz} slices/GPU/step" if args.scaling == "weak" else f"{total_slices} slices/step in total ({nz} on rank 0)"
         result = {
             "metric": "2D slices/sec gridded (512^2 grid, 512x402 golden-angle) + achieved HBM GB/s",
             "value": round(value, 1), "unit": "slices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32" if not args.half else "f32 (k-space stored as f16)", "data": "synthetic",
-            "config": {"workload": f"adjoint gridding recon: {nz} slices/GPU/step x {nc} coils, 512 readout x {NPE} golden-angle spokes "
+            "config": {"workload": f"adjoint gridding recon: {per_gpu} x {nc} coils, 512 readout x {NPE} golden-angle spokes "
                                    f"-> 512^2 oversampled grid -> 256^2 image (tron -a -G -u {undersamp:.4f} -d {NPE})",
-                       "coils": nc, "slices_per_gpu": nz, "kb_mode": args.kb, "parallelism": f"slices sharded over {world} GPU(s), no collective"},
-            "hbm_gbps_per_gpu": round(hbm_gbps, 1), "hbm_frac_of_peak": round(hbm_gbps / HBM_PEAK_GBPS, 4),
-            "copy_ceiling_gbps": copy_gbps, "hbm_frac_of_copy_ceiling": round(hbm_gbps / copy_gbps, 4) if copy_gbps else None,
+                       "coils": nc, "slices_per_gpu": nz, "kb_mode": args.kb,
+                       "parallelism": f"slices sharded over {world} GPU(s), one process each, no collective on the data path (gloo barrier only)",
+                       **({"ranks_share_one_gpu": True} if share and ndev < world else {})},
+            "algorithmic_gbps_per_gpu": round(alg_gbps, 1), "algorithmic_frac_of_peak": round(alg_gbps / HBM_PEAK_GBPS, 4),
+            "copy_ceiling_gbps": copy_gbps, "algorithmic_frac_of_copy_ceiling": round(alg_gbps / copy_gbps, 4) if copy_gbps else None,
+            "copy_ceiling_guide_gbps": 6290.0,      # MI355X_MICROARCH.md: float4 copy, 79 % of the 8 TB/s spec
             "coil_slices_per_s": round(value * nc, 1),
             "parity_rel_l2_vs_oracle": err,
             "roofline": roofline, "cpu_baseline": cpu, "irt_baseline": irt_cpu,
         }
     plan.close()
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    group.close()
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":

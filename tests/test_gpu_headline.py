@@ -1,0 +1,92 @@
+"""The headline shapes of BASELINE.json at their stated sizes, HIP path (through the C ABI, host-buffer entry
+point) against the CPU oracle on more than one slice of a launch-sized batch:
+
+  (i)   metric shape: 512 readout x 402 golden-angle spokes x 8 coils, 64 slices in one launch (the real record
+        batch size, centre-tile clip rounds and disc skipping are in play), slices first / middle / last;
+  (ii)  BASELINE config 4's slice shape: 512 x 804 spokes x 8 coils (two clip rounds per tile);
+  (iii) config 5 at its stated size: complex-half k-space, 512^2 grid, 8 coils;
+  (iv)  config 2 / RUNME1+RUNME3 shape: 256^2 image -> 512 x 512 LINEAR spokes, 1 coil, through the fused forward
+        FFT, and the adjoint of that data back to 256^2.
+
+Tolerance: north_star's 1e-5 relative L2 per slice (src/tron.cu:465-536, 540-577 via the oracle).
+"""
+import numpy as np
+import pytest
+
+from conftest import rel_l2
+import synth
+from tron_amd import lib
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+NRO = 512
+
+
+def _check_slices(oracle, data, got, slices, **oflags):
+    worst = 0.0
+    for z in slices:
+        want, _ = oracle.recon(data, adjoint=1, zfirst=z, zcount=1, **oflags)
+        err = rel_l2(got[..., z], want[..., z])
+        assert err <= TOL, (z, err)
+        worst = max(worst, err)
+    return worst
+
+
+@pytest.fixture(scope="module")
+def metric_stream():
+    """64 slices x 8 coils x 512 x 402: one full default-size launch of the gridding kernel (843 MB)."""
+    return synth.kspace(8, NRO, 402 * 64, seed=synth.SEED_BASE + 21)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("kb", [lib.KB_FAST, lib.KB_EXACT])
+def test_metric_shape_402_spokes_8_coils_64_slices(oracle, metric_stream, kb):
+    flags = dict(golden_angle=1, data_undersamp=0.7852, prof_slide=402)        # tron -a -G -u 0.7852 -d 402
+    got, dims = lib.recon(metric_stream, adjoint=True, kb_mode=kb, **flags)
+    assert (dims.nz, dims.npe1work, dims.nxos, dims.nx) == (64, 402, 512, 256)
+    assert np.isfinite(got).all()
+    _check_slices(oracle, metric_stream, got, (0, 31, 63), golden=1, data_undersamp=0.7852, prof_slide=402)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("kb", [lib.KB_FAST, lib.KB_EXACT])
+def test_config4_shape_804_spokes_8_coils(oracle, kb):
+    nz = 32                                                                     # config 4 over 8 GPUs = 32 slices per GPU
+    data = synth.kspace(8, NRO, 804 * nz, seed=synth.SEED_BASE + 22)
+    flags = dict(golden_angle=1, data_undersamp=1.5704, prof_slide=804)        # 512 * 1.5704f -> 804
+    got, dims = lib.recon(data, adjoint=True, kb_mode=kb, **flags)
+    assert (dims.nz, dims.npe1work) == (nz, 804)
+    _check_slices(oracle, data, got, (0, nz - 1), golden=1, data_undersamp=1.5704, prof_slide=804)
+
+
+@pytest.mark.timeout(900)
+def test_config5_complex_half_at_512_grid_8_coils(oracle):
+    nz = 16
+    data = synth.kspace(8, NRO, 402 * nz, seed=synth.SEED_BASE + 23)
+    halves = np.asfortranarray(data).reshape(-1, order="F").view(np.float32).astype(np.float16)   # RNE, as src/float16.cu
+    rounded = halves.astype(np.float32).view(np.complex64).reshape(data.shape, order="F")
+    flags = dict(golden_angle=1, data_undersamp=0.7852, prof_slide=402)
+    h = halves.reshape((2,) + data.shape, order="F")
+    for kb in (lib.KB_FAST, lib.KB_EXACT):
+        got, dims = lib.recon(h, adjoint=True, input_half=1, kb_mode=kb, **flags)
+        assert dims.nz == nz
+        _check_slices(oracle, rounded, got, (0, nz - 1), golden=1, data_undersamp=0.7852, prof_slide=402)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("kb", [lib.KB_FAST, lib.KB_EXACT])
+def test_config2_linear_256_image_to_512x512_spokes_and_back(oracle, kb):
+    """`tron sl.ra data.ra` (src/RUNME1_tron_degrid_phantom.sh:5) then `tron -a data.ra img.ra`
+    (src/RUNME3_tron_grid_all.sh:6): default flags = linear angles, 512 readout x 512 spokes, 1 coil."""
+    img = synth.image(1, 256, seed=synth.SEED_BASE + 24)
+    want, p = oracle.recon(img, adjoint=0)
+    assert (p.nxos, p.nro, p.npe1work) == (512, 512, 512)
+    got, dims = lib.recon(img, adjoint=False, kb_mode=kb)
+    assert (dims.nro, dims.npe1work) == (512, 512)
+    assert rel_l2(got, want) <= TOL
+    # adjoint of the oracle's data (so both sides grid identical inputs); Q5: the two linear conventions differ, parity is per direction
+    back_want, q = oracle.recon(want, adjoint=1)
+    assert (q.nx, q.npe1work) == (256, 512)
+    back, _ = lib.recon(want, adjoint=True, kb_mode=kb)
+    assert rel_l2(back, back_want) <= TOL

@@ -1,0 +1,42 @@
+"""Regression guard for the lazy code-object-load fault of round 1: a kernel launched on the plan's
+non-blocking stream right after process start could run before its code object was resident ("memory access fault
+... address (nil)", ~15 % of processes).  tron_plan_create now force-loads every translation unit; this test starts
+many short-lived processes that create a plan and launch a metric-size reconstruction immediately."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import synth
+from tron_amd import ra
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TRON = os.path.join(ROOT, "tron_amd", "bin", "tron")
+NPROC = 40
+
+
+@pytest.mark.timeout(1200)
+def test_fresh_processes_launch_immediately_without_faults(tmp_path):
+    data = synth.kspace(8, 512, 402, seed=synth.SEED_BASE + 31)        # one metric-shape slice, 8 coils
+    src = str(tmp_path / "in.ra")
+    ra.write(src, data)
+    first = None
+    for i in range(NPROC):
+        dst = str(tmp_path / f"out{i % 2}.ra")
+        r = subprocess.run([TRON, "-a", "-G", "-u", "0.7852", src, dst], capture_output=True, text=True, timeout=120)
+        if r.returncode != 0:
+            # name the failing stage: same run, synchronising after every launch
+            dbg = subprocess.run([TRON, "-a", "-G", "-u", "0.7852", src, dst], capture_output=True, text=True, timeout=120,
+                                 env=dict(os.environ, TRON_SYNC_EACH="1"))
+            pytest.fail(f"process {i} of {NPROC} failed (rc {r.returncode}): {r.stderr[-400:]}\n"
+                        f"TRON_SYNC_EACH=1 rerun rc {dbg.returncode}: {dbg.stderr[-400:]}")
+        out = open(dst, "rb").read()
+        if first is None:
+            first = out
+            img = ra.read(dst)
+            assert img.shape == (1, 1, 256, 256, 1) and np.isfinite(img).all() and np.abs(img).max() > 0
+        else:
+            assert out == first, f"process {i}: output bytes differ from the first run"

@@ -1,0 +1,72 @@
+"""`bench.py --gpus N` starts its own ranks (tron_amd/launch.py): the spawner, the gloo barrier / max-reduce the
+ranks use instead of an RCCL group, and the refusal to print a line for an incomplete run -- all on CPU."""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+from tron_amd import launch
+from tron_amd.shard import partition
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _child(tmp_path, body):
+    f = tmp_path / "child.py"
+    f.write_text("import os, sys\nsys.path.insert(0, %r)\n" % ROOT + textwrap.dedent(body))
+    return str(f)
+
+
+@pytest.mark.timeout(300)
+def test_spawn_ranks_env_barrier_and_max(tmp_path):
+    child = _child(tmp_path, """
+        from tron_amd import launch
+        rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+        assert os.environ["LOCAL_RANK"] == os.environ["RANK"] and os.environ["MASTER_ADDR"] == "127.0.0.1"
+        g = launch.HostGroup(rank, world)
+        g.barrier()
+        slow = g.max(1.0 + rank)            # max over ranks of a per-rank time
+        tot = g.sum(float(rank + 1))
+        g.close()
+        if rank == 0:
+            print('{"metric": "x", "n_gpus": %d, "max": %g, "sum": %g}' % (world, slow, tot))
+    """)
+    code, out = launch.spawn_ranks([child], 3, timeout=240)
+    assert code == 0
+    line = json.loads(out.strip().splitlines()[-1])
+    assert line == {"metric": "x", "n_gpus": 3, "max": 3.0, "sum": 6.0}
+
+
+@pytest.mark.timeout(300)
+def test_spawn_ranks_reports_a_failing_rank(tmp_path):
+    child = _child(tmp_path, """
+        if os.environ["RANK"] == "1":
+            sys.exit(7)
+        print('{"metric": "x", "n_gpus": 2}')
+    """)
+    code, out = launch.spawn_ranks([child], 2, timeout=120)
+    assert code == 7 and '"n_gpus": 2' in out        # rank 0's line exists but the caller must not print it
+
+
+@pytest.mark.timeout(600)
+def test_bench_gpus_2_without_gpus_fails_loudly():
+    """On a box without GPUs `python bench.py --gpus 2` must exit non-zero and print no result line
+    (round 1 silently ran one rank and printed n_gpus: 1)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=540)
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs present: this is the no-GPU behaviour test")
+    assert r.returncode != 0
+    assert '"metric"' not in r.stdout
+    assert "no result line printed" in r.stderr
+
+
+def test_strong_scaling_partition_matches_config4():
+    # BASELINE config 4: 256 slices in total over 8 GPUs = 32 contiguous slices each, global angle index z*npe
+    blocks = [partition(256, 8, r) for r in range(8)]
+    assert blocks == [(32 * r, 32) for r in range(8)]

@@ -1,0 +1,97 @@
+"""One process per GPU without an external launcher, and the only cross-rank traffic the path
+needs: a barrier and a max-reduce of wall times, over gloo on the host.
+
+Slices are independent (src/tron.cu:732-783) and the reference's own multi-GPU sketch is a slice
+round-robin with no inter-GPU traffic (src/tron.cu:582-597,735-736), so no RCCL group is opened
+anywhere: ranks meet on the host only to line up their clocks.
+
+`spawn_ranks` must run BEFORE the calling process touches the GPU (no torch.cuda / HIP call):
+children are fresh interpreters started with subprocess, never an exec of a GPU-initialised one.
+"""
+from __future__ import annotations
+
+import os
+import socket
+import subprocess
+import sys
+
+
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def rank_env(rank: int, world: int, port: int, base=None) -> dict:
+    env = dict(os.environ if base is None else base)
+    env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return env
+
+
+def spawn_ranks(argv, world: int, timeout=None):
+    """Starts `world` children running ``python argv...`` with RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set.
+    Returns (exit_code, rank0_stdout): exit_code is 0 only if EVERY rank exited 0; rank 0's stdout is
+    captured (not forwarded) so the caller can decide to print it only for a complete run."""
+    port = free_port()
+    procs = []
+    for r in range(world):
+        procs.append(subprocess.Popen([sys.executable] + list(argv), env=rank_env(r, world, port),
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, code = "", 0
+    try:
+        out0, _ = procs[0].communicate(timeout=timeout)
+        for p in procs:
+            rc = p.wait(timeout=timeout)
+            if rc != 0 and code == 0:
+                code = rc
+    except subprocess.TimeoutExpired:
+        code = 124
+    finally:
+        for p in procs:          # exact PIDs we started, nothing else
+            if p.poll() is None:
+                p.kill()
+                p.wait()
+    return code, out0
+
+
+class HostGroup:
+    """Barrier + max-reduce over gloo (CPU tensors).  world == 1 needs no process group."""
+
+    def __init__(self, rank: int, world: int):
+        self.rank, self.world = rank, world
+        self._dist = None
+        if world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            self._dist = dist
+
+    def barrier(self):
+        if self._dist is not None:
+            self._dist.barrier()
+
+    def max(self, value: float) -> float:
+        if self._dist is None:
+            return float(value)
+        import torch
+        t = torch.tensor([float(value)], dtype=torch.float64)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum(self, value: float) -> float:
+        if self._dist is None:
+            return float(value)
+        import torch
+        t = torch.tensor([float(value)], dtype=torch.float64)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM)
+        return float(t.item())
+
+    def close(self):
+        if self._dist is not None:
+            self._dist.barrier()
+            self._dist.destroy_process_group()
+            self._dist = None
