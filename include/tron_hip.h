@@ -64,7 +64,7 @@ typedef struct tron_config {
     float data_undersamp;  /* -u  data_undersamp = 1   (src/tron.cu:69)  */
     int   prof_slide;      /* -d  prof_slide = 0       (src/tron.cu:71)  */
     int   skip_angles;     /* -s  skip_angles = 0      (src/tron.cu:72)  */
-    int   niter;           /* -i  niter = 0            (src/tron.cu:74)  >0 -> TRON_ERR_UNSUPPORTED */
+    int   niter;           /* -i  niter = 0            (src/tron.cu:74)  >0: CGNR iterations (adjoint only) */
     int   blocks;          /* -B  accepted, ignored (launch shapes are chosen per kernel) */
     int   threads;         /* -T  accepted, ignored */
     int   device;          /* -g  HIP device ordinal   (src/tron.cu:838) */
@@ -72,6 +72,12 @@ typedef struct tron_config {
     int   kb_mode;         /* TRON_KB_FAST (default) or TRON_KB_EXACT */
     int   input_half;      /* adjoint only: k-space is complex-half (2 x IEEE binary16 per sample) */
     int   chunk_slices;    /* slices per internal batch; 0 = choose from the grid size */
+    int   pin_host;        /* tron_recon_radial2d[_range]: hipHostRegister the caller's buffers for the call (the
+                              reference pins its output with cudaMallocHost, src/tron.cu:967); default 1; a buffer that
+                              cannot be registered (already pinned by the caller, ...) is copied as pageable memory */
+    int   cgnr_consistent; /* CGNR with linear angles: 0 = each operator keeps the reference's own convention (grid
+                              src/tron.cu:509, degrid :555 -- not a matched pair), 1 = the forward operator
+                              inside the iteration uses the gridding convention.  Golden angle: no effect */
 } tron_config;
 
 /* Everything main() derives from the input header and the flags (src/tron.cu:76-79,
@@ -113,6 +119,21 @@ int tron_recon_radial2d(tron_plan *plan, tron_float2 *h_out, const tron_float2 *
 int tron_recon_radial2d_range(tron_plan *plan, tron_float2 *h_out, const tron_float2 *h_in,
                               int zfirst, int zcount);
 
+/* The same with BLOCK-relative host pointers (adjoint only): h_in_block points at the first spoke of slice zfirst's
+   window (spoke zfirst*prof_slide of the stream, src/tron.cu:738-739), h_out_block at slice zfirst's image.  A process
+   that holds only its own share of the stream (one rank per GPU) calls this; the angle index stays
+   global (src/tron.cu:630). */
+int tron_recon_radial2d_block(tron_plan *plan, tron_float2 *h_out_block, const void *h_in_block,
+                              int zfirst, int zcount);
+
+/* = recon_radial2d over several GPUs inside ONE process: the reference's (compiled-out) MULTI_GPU scheme,
+   src/tron.cu:582-597,735-736, with contiguous slice blocks instead of its round-robin.  One host worker thread and
+   one plan per entry of `devices` (HIP ordinals; NULL = 0..n_devices-1; n_devices <= 0 = every visible device; an
+   ordinal may repeat), each reconstructing its block straight into h_out -- no gather, no inter-GPU traffic.
+   cfg->device is ignored.  Forward plans (one image) run on the first device. */
+int tron_recon_radial2d_multi(const tron_config *cfg, const tron_dims *dims, const int *devices, int n_devices,
+                              tron_float2 *h_out, const tron_float2 *h_in);
+
 /* = tron_nufft_adj_radial2d(d_out, d_in, j), src/tron.cu:623-637, batched over slices and
    device resident.  d_in: the whole spoke stream [nc,nt,nro,npe1*npe2] on the device
    (never modified: the density compensation of src/tron.cu:628 is applied on the fly);
@@ -122,6 +143,14 @@ int tron_recon_radial2d_range(tron_plan *plan, tron_float2 *h_out, const tron_fl
    Asynchronous on the plan's stream; call tron_plan_sync() before reading d_out. */
 int tron_nufft_adj_radial2d(tron_plan *plan, void *d_out, const void *d_in,
                             int zfirst, int zcount, int combine);
+
+/* = tron_cgnr_radial2d(d_out, d_in, j, niter), src/tron.cu:665-720: cfg.niter iterations of CGNR (Knopp et al. 2007,
+   Alg. 1, density-weighted) per slice, device resident, same buffers and layouts as tron_nufft_adj_radial2d.  The
+   reference marks its version "NOT WORKING CORRECTLY YET" (:670); this is the algorithm it cites with the operators it
+   wires in -- squared norms in the step sizes, image vectors of the adjoint's output size, the gridding scale divided
+   out, the slice's own angle indices in the forward operator (DESIGN.md lists the repairs).  The host entry points
+   (tron_recon_radial2d*) take this path when cfg.niter > 0, as recon_radial2d does (:754-755). */
+int tron_cgnr_radial2d(tron_plan *plan, void *d_out, const void *d_in, int zfirst, int zcount, int combine);
 
 /* = tron_nufft_radial2d(d_out, d_in, j), src/tron.cu:639-649, for `nimg` images stored
    back to back: d_in[nchan*nx*ny*k + nchan*id + c] -> d_out[nchan*nro*npe*k + nchan*(ro+nro*pe) + c]. */

@@ -324,10 +324,12 @@ void oracle_gridradial2d(cfloat *udata, const cfloat *nudata, const int nxos,
     free(ct_tab);
 }
 
-/* tron.cu:540-577.  X is the sine (row) coordinate, Y the cosine (column) one. */
-void oracle_degridradial2d(cfloat *nudata, const cfloat *udata, const int n, const int nrep,
+/* tron.cu:540-577.  X is the sine (row) coordinate, Y the cosine (column) one.
+   grid_convention != 0 takes the spoke angle from the GRIDDING kernel's formula (tron.cu:509) instead of :555 --
+   only the CGNR restatement below asks for that (the two linear-angle conventions differ). */
+void oracle_degridradial2d_conv(cfloat *nudata, const cfloat *udata, const int n, const int nrep,
     const int nro, const int npe, const float W, const float gridos, const int skip_angles,
-    const int flag_golden_angle)
+    const int flag_golden_angle, const int grid_convention)
 {
 #ifdef _OPENMP
 #pragma omp parallel for schedule(static)
@@ -337,7 +339,8 @@ void oracle_degridradial2d(cfloat *nudata, const cfloat *udata, const int n, con
         int pe = id / nro;
         int ro = id % nro;
         float R = (float)ro/(float)nro - 0.5f;
-        float T = oracle_degrid_angle(pe, npe, skip_angles, flag_golden_angle);
+        float T = grid_convention ? oracle_grid_angle(pe, npe, skip_angles, flag_golden_angle)
+                                  : oracle_degrid_angle(pe, npe, skip_angles, flag_golden_angle);
         float X, Y;
         sincosf(T, &X, &Y);
         X = n*R*X + (n + 1)/2;
@@ -356,6 +359,13 @@ void oracle_degridradial2d(cfloat *nudata, const cfloat *udata, const int n, con
             }
         }
     }
+}
+
+void oracle_degridradial2d(cfloat *nudata, const cfloat *udata, const int n, const int nrep,
+    const int nro, const int npe, const float W, const float gridos, const int skip_angles,
+    const int flag_golden_angle)
+{
+    oracle_degridradial2d_conv(nudata, udata, n, nrep, nro, npe, W, gridos, skip_angles, flag_golden_angle, 0);
 }
 
 /* ------------------------------------------------------------------ DFT (stands for cuFFT) */
@@ -559,6 +569,98 @@ int oracle_recon_radial2d(const oracle_params *p, cfloat *h_out, const cfloat *h
     }
     free(d_u);
     free(d_v);
+    return rc;
+}
+
+/* ------------------------------------------------------------------ CGNR (tron.cu:658-720)
+ *
+ * The reference's tron_cgnr_radial2d carries the comment "NOT WORKING CORRECTLY YET" (:670).  This restates the
+ * algorithm it cites -- Knopp, Kunis, Potts 2007, Algorithm 1 (CGNR with density weights W) -- with the SAME
+ * operators the reference wires in (A = tron_nufft_radial2d :639-649, A^H W = tron_nufft_adj_radial2d :623-637) and the
+ * same update order (:686-712), and repairs, each marked below, exactly what keeps the reference's version from being
+ * that algorithm:
+ *   F1  step sizes use SQUARED norms (the reference divides cublasScnrm2 norms, :695-697,704-709);
+ *   F2  image-space vectors have nchan*nx*ny elements, the adjoint's output size (the reference uses N = nxos*nxos*nc*nt
+ *       and clears a quarter of p, :680,683);
+ *   F3  the adjoint's output scale 1/nxos/npe (:532) is divided out, so that it IS A^H W;
+ *   F4  the forward operator uses the slice's angle index skip_angles + peoffset like the adjoint (:630; the reference
+ *       passes skip_angles alone, :647) and, when `consistent`, the gridding kernel's linear-angle convention (Q5);
+ *   F5  the residual is kept in its own buffer and the adjoint is applied to a COPY (precompensate works in place, :628).
+ * Dot products accumulate in double (cuBLAS's order is unspecified).  niter = 0 is the plain adjoint (:754-757).
+ */
+static double dot_self(const cfloat *a, size_t n)
+{
+    double s = 0.0;
+    for (size_t i = 0; i < n; ++i) s += (double)a[i].x * a[i].x + (double)a[i].y * a[i].y;
+    return s;
+}
+
+void oracle_cgnr_radial2d(const oracle_params *p, cfloat *d_out, const cfloat *d_in, int peoffset, int niter, int consistent)
+{
+    const int nchan = p->nc * p->nt;
+    const size_t N = (size_t)nchan * p->nx * p->ny;                 /* F2 */
+    const size_t n = (size_t)nchan * p->nro * p->npe1work;
+    const size_t nbuf = (size_t)nchan * imax(p->nro * p->npe1work, p->nxos * p->nyos);
+    cfloat *u = (cfloat*)malloc(nbuf * sizeof(cfloat)), *v = (cfloat*)malloc(nbuf * sizeof(cfloat));
+    cfloat *zt = (cfloat*)malloc(N * sizeof(cfloat)), *pt = (cfloat*)malloc(N * sizeof(cfloat));
+    cfloat *x = (cfloat*)calloc(N, sizeof(cfloat)), *r = (cfloat*)malloc(n * sizeof(cfloat));
+    const float unscale = (float)p->nxos * (float)p->npe1work;      /* F3: 1 / (1.f/nxos/npe) */
+    oracle_params pf = *p;
+    pf.skip_angles = p->skip_angles + peoffset;                      /* F4 */
+    memcpy(r, d_in, n * sizeof(cfloat));                             /* r = y          (:685) */
+    memcpy(u, r, n * sizeof(cfloat));                                /* F5 */
+    oracle_nufft_adj_radial2d(p, v, u, peoffset);                    /* ztilde = A^H W r (:686) */
+    for (size_t i = 0; i < N; ++i) { zt[i].x = v[i].x * unscale; zt[i].y = v[i].y * unscale; }
+    memcpy(pt, zt, N * sizeof(cfloat));                              /* ptilde = ztilde (:687) */
+    double zz = dot_self(zt, N);
+    for (int t = 0; t < niter; ++t) {
+        memcpy(u, pt, N * sizeof(cfloat));                           /* (:690) */
+        {   /* v = A ptilde (:691), stage order of tron_nufft_radial2d :639-649 */
+            oracle_pad(v, pf.nxos, u, pf.nx, nchan);
+            oracle_deapod(v, pf.nxos, nchan, pf.kernwidth, 1.f);
+            oracle_fftshift(u, v, pf.nxos, nchan, 0);
+            oracle_fft2(v, u, pf.nxos, nchan, -1);
+            oracle_fftshift(u, v, pf.nxos, nchan, 1);
+            oracle_degridradial2d_conv(v, u, pf.nxos, nchan, pf.nro, pf.npe1work, pf.kernwidth, pf.gridos,
+                                       pf.skip_angles, pf.golden_angle, consistent);
+        }
+        memcpy(u, v, n * sizeof(cfloat));                            /* (:692) */
+        oracle_precompensate(u, nchan, p->nro, p->npe1work);         /* W v (:693) */
+        double vwv = 0.0;                                            /* Re <W v, v> (:696) */
+        for (size_t i = 0; i < n; ++i) vwv += (double)u[i].x * v[i].x + (double)u[i].y * v[i].y;
+        const float alpha = (float)(zz / vwv);                       /* F1 (:697) */
+        for (size_t i = 0; i < N; ++i) { x[i].x = x[i].x + alpha * pt[i].x; x[i].y = x[i].y + alpha * pt[i].y; }   /* (:699) */
+        if (t == niter - 1) break;                                   /* (:701) */
+        for (size_t i = 0; i < n; ++i) { r[i].x = r[i].x + (-alpha) * v[i].x; r[i].y = r[i].y + (-alpha) * v[i].y; }   /* (:703) */
+        memcpy(u, r, n * sizeof(cfloat));                            /* (:706) */
+        oracle_nufft_adj_radial2d(p, v, u, peoffset);                /* ztilde = A^H W r (:707) */
+        for (size_t i = 0; i < N; ++i) { zt[i].x = v[i].x * unscale; zt[i].y = v[i].y * unscale; }
+        const double zz_new = dot_self(zt, N);
+        const float beta = (float)(zz_new / zz);                     /* F1 (:709) */
+        zz = zz_new;
+        for (size_t i = 0; i < N; ++i) { pt[i].x = zt[i].x + beta * pt[i].x; pt[i].y = zt[i].y + beta * pt[i].y; }   /* (:710) */
+    }
+    if (niter > 0) memcpy(d_out, x, N * sizeof(cfloat));             /* (:713) */
+    else { for (size_t i = 0; i < N; ++i) { d_out[i].x = zt[i].x / unscale; d_out[i].y = zt[i].y / unscale; } }
+    free(u); free(v); free(zt); free(pt); free(x); free(r);
+}
+
+/* recon_radial2d with niter > 0 (tron.cu:754-755,764): CGNR per slice, then coilcombinesos. */
+int oracle_recon_cgnr(const oracle_params *p, cfloat *h_out, const cfloat *h_in, int zfirst, int zcount, int niter, int consistent)
+{
+    if (!p->adjoint) return -3;
+    const int nchan = p->nc * p->nt;
+    const size_t N = (size_t)nchan * p->nx * p->ny;
+    cfloat *img = (cfloat*)malloc(N * sizeof(cfloat)), *comb = (cfloat*)malloc((size_t)p->nx * p->ny * sizeof(cfloat));
+    int rc = 0;
+    for (int z = zfirst; z < zfirst + zcount && z < p->nz; ++z) {
+        const int peoffset = z * p->prof_slide;
+        if ((long long)peoffset + p->npe1work > (long long)p->npe1 * (p->npe2 > 0 ? p->npe2 : 1)) { rc = -2; break; }
+        oracle_cgnr_radial2d(p, img, h_in + (size_t)nchan * p->nro * peoffset, peoffset, niter, consistent);
+        oracle_coilcombinesos(comb, img, p->nx, p->nc);
+        memcpy(h_out + (size_t)p->nt * p->nx * p->ny * z, comb, (size_t)p->nx * p->ny * p->nt * sizeof(cfloat));
+    }
+    free(img); free(comb);
     return rc;
 }
 

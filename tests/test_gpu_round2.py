@@ -1,0 +1,94 @@
+"""Round-2 host-side features on the GPU: the chunked upload / compute / download pipeline of the host-buffer entry
+point, block-relative buffers, in-process multi-GPU workers, split centre tiles of small launches."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import rel_l2
+import synth
+from tron_amd import lib, ra
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TRON = os.path.join(ROOT, "tron_amd", "bin", "tron")
+FLAGS = dict(golden_angle=1, data_undersamp=0.5, prof_slide=11)       # sliding windows: 32 spokes, hop 11
+
+
+def _stream(nc=2, nro=64, npe1=160, seed=1201):
+    return synth.kspace(nc, nro, npe1, seed=seed)
+
+
+def test_host_pipeline_chunking_and_pinning_do_not_change_bytes(oracle, monkeypatch):
+    """tron_recon_radial2d cuts the slice range into chunks (upload k+1 || kernels k || download k-1, each spoke
+    uploaded once although windows overlap, src/tron.cu:732-783): any chunk size, pinned or pageable, same bytes."""
+    data = _stream()
+    want, p = oracle.recon(data, adjoint=1, golden=1, data_undersamp=0.5, prof_slide=11)
+    base, dims = lib.recon(data, adjoint=True, **FLAGS)
+    assert dims.nz == p.nz == 12 and rel_l2(base, want) <= 1e-5
+    for chunk in (1, 3, 4):
+        got, _ = lib.recon(data, adjoint=True, chunk_slices=chunk, **FLAGS)
+        assert np.array_equal(got.view(np.uint32), base.view(np.uint32)), chunk
+    got, _ = lib.recon(data, adjoint=True, chunk_slices=3, pin_host=1, **FLAGS)
+    assert np.array_equal(got.view(np.uint32), base.view(np.uint32))
+    monkeypatch.setenv("TRON_PIN_HOST", "1")
+    got, _ = lib.recon(data, adjoint=True, **FLAGS)
+    assert np.array_equal(got.view(np.uint32), base.view(np.uint32))
+
+
+def test_block_relative_buffers_match_the_full_run():
+    """tron_recon_radial2d_block: a caller that holds only the spokes of its own slices (one rank per GPU)."""
+    data = _stream()
+    full, dims = lib.recon(data, adjoint=True, **FLAGS)
+    cfg = lib.default_config(adjoint=1, **FLAGS)
+    flat = np.asfortranarray(data).reshape(-1, order="F")
+    per_spoke = dims.nc * dims.nro
+    with lib.Plan(cfg, dims) as plan:
+        for z0, zc in ((0, 4), (4, 3), (7, 5)):
+            s0, ns = z0 * dims.prof_slide, (zc - 1) * dims.prof_slide + dims.npe1work
+            block = np.ascontiguousarray(flat[s0 * per_spoke: (s0 + ns) * per_spoke])      # ONLY this block's spokes
+            out = plan.recon_block(block, z0, zc)
+            img = dims.nx * dims.ny
+            want = full.reshape(-1, order="F")[z0 * img: (z0 + zc) * img]
+            assert np.array_equal(out.view(np.uint32), np.ascontiguousarray(want).view(np.uint32)), (z0, zc)
+
+
+def test_multi_device_workers_in_one_process(tmp_path):
+    """tron_recon_radial2d_multi with two workers mapped to the same GPU = the single-plan bytes (no gather: each worker
+    writes its slice block into the shared output); the `tron -g 0,0` CLI form likewise (src/tron.cu:582-597,735-736)."""
+    data = _stream(nc=2, npe1=150)
+    single, dims = lib.recon(data, adjoint=True, **FLAGS)
+    for devs in ([0, 0], [0, 0, 0]):
+        multi, _ = lib.recon_multi(data, adjoint=True, devices=devs, **FLAGS)
+        assert np.array_equal(multi.view(np.uint32), single.view(np.uint32))
+    with pytest.raises(lib.TronError):
+        lib.recon_multi(data, adjoint=True, devices=[0, 99], **FLAGS)
+    src, a, b = str(tmp_path / "in.ra"), str(tmp_path / "a.ra"), str(tmp_path / "b.ra")
+    ra.write(src, data)
+    args = ["-a", "-G", "-u", "0.5", "-d", "11", src]
+    assert subprocess.run([TRON] + args + [a], timeout=120).returncode == 0
+    assert subprocess.run([TRON, "-g", "0,0"] + args + [b], timeout=120).returncode == 0
+    assert open(a, "rb").read() == open(b, "rb").read()
+
+
+def test_split_centre_tiles_are_deterministic_and_agree_with_unsplit(oracle, monkeypatch):
+    """Launches of fewer than 64 slices deal the k-space-centre tiles to several workgroups over disjoint spoke ranges
+    and add the partial tiles in a fixed order: bit-identical run to run, and equal to the unsplit kernel up to fp32
+    summation order (src/tron.cu:507-530 sums spoke by spoke)."""
+    data = synth.kspace(2, 512, 402 * 3, seed=1301)
+    flags = dict(golden_angle=1, data_undersamp=0.7852, prof_slide=402)
+    a, dims = lib.recon(data, adjoint=True, **flags)
+    b, _ = lib.recon(data, adjoint=True, **flags)
+    assert dims.nz == 3 and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    monkeypatch.setenv("TRON_SPLIT_BELOW", "0")                      # never split
+    c, _ = lib.recon(data, adjoint=True, **flags)
+    assert not np.array_equal(a.view(np.uint32), c.view(np.uint32)), "the split path did not run"
+    assert rel_l2(a, c) <= 2e-6
+    want, _ = oracle.recon(data, adjoint=1, zfirst=1, zcount=1, golden=1, data_undersamp=0.7852, prof_slide=402)
+    assert rel_l2(a[..., 1], want[..., 1]) <= 1e-5
+    monkeypatch.setenv("TRON_SPLIT_BELOW", "64")
+    monkeypatch.setenv("TRON_SPLIT_TARGET", "700")                   # many tiles split, up to 8 parts
+    e, _ = lib.recon(data, adjoint=True, **flags)
+    assert rel_l2(e, c) <= 2e-6

@@ -70,3 +70,18 @@ def test_strong_scaling_partition_matches_config4():
     # BASELINE config 4: 256 slices in total over 8 GPUs = 32 contiguous slices each, global angle index z*npe
     blocks = [partition(256, 8, r) for r in range(8)]
     assert blocks == [(32 * r, 32) for r in range(8)]
+
+
+@pytest.mark.timeout(120)
+def test_spawn_ranks_does_not_wait_for_a_rendezvous_that_cannot_happen(tmp_path):
+    """Rank 1 dies before the rendezvous; rank 0 would sit in gloo's 30-minute timeout.  The spawner ends the run."""
+    child = _child(tmp_path, """
+        if os.environ["RANK"] == "1":
+            sys.exit(3)
+        from tron_amd import launch
+        launch.HostGroup(0, 2)          # blocks: its peer is gone
+    """)
+    import time
+    t0 = time.monotonic()
+    code, out = launch.spawn_ranks([child], 2, timeout=100)
+    assert code == 3 and time.monotonic() - t0 < 60

@@ -4,4 +4,4 @@
  | grep -E "Function Name|VGPRs:|ScratchSize|Occupancy|LDS Size|TotalSGPRs" \
  | sed -E 's/^.*remark: +//; s/ \[-Rpass.*$//' \
  | awk '/Function Name/{if(line)print line; line=$3} /VGPRs:/{line=line" vgpr="$2} /TotalSGPRs/{line=line" sgpr="$2} /ScratchSize/{line=line" scratch="$4} /Occupancy/{line=line" occ="$3} /LDS Size/{line=line" lds="$4} END{print line}' \
- | while read l; do n=$(echo $l | cut -d' ' -f1 | /opt/rocm/lib/llvm/bin/llvm-cxxfilt | cut -c1-90); echo "$n | $(echo $l | cut -d' ' -f2-)"; done
+ | while read l; do n=$(echo $l | cut -d' ' -f1 | c++filt | cut -c1-90); echo "$n | $(echo $l | cut -d' ' -f2-)"; done

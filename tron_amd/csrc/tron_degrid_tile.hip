@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(kDgThreads) degrid_tile_kernel(const DegridPar
             int rlo = 0, len = 0;
             float2 cs = make_float2(0.f, 0.f);
             if (pe < p.npe && pe < round0 + kDgMaxSpokes) {
-                cs = p.trig[pe];
+                cs = p.trig[(size_t)k * p.trig_img_stride + pe];
                 const float ax = (float)n * cs.y / (float)p.nro, ay = (float)n * cs.x / (float)p.nro;   // d/d(ro)
                 const float ox = half - 0.5f * (float)n * cs.y, oy = half - 0.5f * (float)n * cs.x;     // value at ro = 0
                 const float ix = safe_rcp(ax), iy = safe_rcp(ay);

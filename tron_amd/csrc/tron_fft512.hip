@@ -54,6 +54,17 @@ __device__ __forceinline__ void dft8_inv(float2 v[8])
     v[3] = cadd(E3, T3); v[7] = csub(E3, T3);
 }
 
+// Orders one wave's LDS exchange: the stores before it are visible to every lane's loads after it.  Lanes of a wave
+// exchange data through LDS here with no workgroup barrier; under the HIP memory model that needs a wavefront-scope
+// release/acquire pair (no instruction on gfx950 beyond the s_waitcnt the compiler emits anyway: LDS operations of one
+// wave execute in order) plus a wave barrier that keeps the compiler from moving accesses across it.
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // 512-point inverse DFT of one line held as v[q] = x[64*q + lane]; returns v[j2] = X[lane + 64*j2].
 // tw[k] = exp(+2*pi*i*k/512).  xch: this wave's private LDS exchange region.
 __device__ __forceinline__ void fft512_inv(float2 v[8], float2 *xch, const float2 *__restrict__ tw, const int lane)
@@ -64,22 +75,26 @@ __device__ __forceinline__ void fft512_inv(float2 v[8], float2 *xch, const float
     for (int k1 = 1; k1 < 8; ++k1) v[k1] = cmul(v[k1], tw[(lane * k1) & 511]);
 #pragma unroll
     for (int k1 = 0; k1 < 8; ++k1) xch[k1 * kPA + lane] = v[k1];
+    wave_lds_fence();
     // stage B: thread (k1 = lane>>3, m2 = lane&7): DFT over m1, twiddle w64^(m2*j1)
     {
         const int k1 = lane >> 3, m2 = lane & 7;
 #pragma unroll
         for (int m1 = 0; m1 < 8; ++m1) v[m1] = xch[k1 * kPA + m1 * 8 + m2];
+        wave_lds_fence();                                                  // stage B's stores reuse the region at another pitch
         dft8_inv(v);
 #pragma unroll
         for (int j1 = 1; j1 < 8; ++j1) v[j1] = cmul(v[j1], tw[(8 * m2 * j1) & 511]);
 #pragma unroll
         for (int j1 = 0; j1 < 8; ++j1) xch[j1 * kPB + lane] = v[j1];      // B[j1][k1*8 + m2]
     }
+    wave_lds_fence();
     // stage C: thread (k1 = lane&7, j1 = lane>>3): DFT over m2 -> X[k1 + 8*j1 + 64*j2]
     {
         const int k1 = lane & 7, j1 = lane >> 3;
 #pragma unroll
         for (int m2 = 0; m2 < 8; ++m2) v[m2] = xch[j1 * kPB + k1 * 8 + m2];
+        wave_lds_fence();                                                  // the next line's stage A stores come after these loads
         dft8_inv(v);
     }
 }

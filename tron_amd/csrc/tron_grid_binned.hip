@@ -10,14 +10,18 @@
 //
 // One workgroup = 4 waves = one 32x32 tile; each thread owns 2x2 points.  Per batch of <= NREC records:
 //   A  stage   lanes run along the spoke: coalesced k-space read, DCF, 2x(2CW) weights once per
-//              sample; the sample's base cell gets a packed per-wave counter bumped with ONE
-//              integer LDS atomic (ds_add_rtn_u32: 6.6 cycles per wave instruction on MI355X,
-//              vs 194 for ds_add_f32), which returns the sample's rank in its (wave, cell) bucket;
-//   B  scan    exclusive prefix sum over the (32+2CW-1)^2 cells -> CSR row starts;
-//   C  place   record ids are written to their sorted slots: cell start + earlier waves' counts + rank
+//              sample.  The sample is entered into every BAND that can see it -- band b = the two point
+//              rows 2b, 2b+1 (one row of 2x2 blocks), which see the 2CW+1 cell rows 2b-CW .. 2b+CW, so a
+//              sample sits in CW+1 bands at most -- by bumping a packed per-wave counter of its
+//              (band, cell column) bin with an integer LDS atomic (ds_add_rtn_u32: 6.6 cycles per wave
+//              instruction on MI355X, vs 194 for ds_add_f32), which returns its rank in that bin;
+//   B  scan    exclusive prefix sum over the 16 x (32+2CW) bins -> CSR starts;
+//   C  place   packed entries are written to their sorted slots: bin start + earlier waves' counts + rank
 //              (deterministic: each wave issues its atomics in program order);
-//   D  apply   a thread reads, for each of the 2CW+1 cell rows its 2x2 points can see, ONE contiguous
-//              id range, and accumulates weight pair x weight pair x sample for all coils in registers.
+//   D  apply   within a band the entries are ordered by cell column, so the samples a thread's 2x2 points can
+//              see are ONE contiguous range [start(b, 2bx), start(b, 2bx+2CW+1)): a plain loop, no row
+//              bookkeeping; per visit the entry, 2+2 weights and the coils' samples are read with a single
+//              LDS round trip and accumulated (weight pair x weight pair x sample) in registers.
 // No floating-point atomics anywhere; the output is written once, coil-planar, in FFT-native order.
 #include <stdlib.h>
 
@@ -35,17 +39,23 @@ struct BinCfg {
     static constexpr int NWP = NW + 2;                       // weights padded with a zero each side
     static constexpr int NCELL = kBinTile + 2 * CW - 1;      // base cells per dimension that can touch the tile
     static constexpr int CELLW = NCELL + 1;                  // + sentinel column
-    static constexpr int NCELLS = NCELL * CELLW;
-    static constexpr int CPT = (NCELLS + kBinThreads - 1) / kBinThreads;   // cells per thread in the scan
+    static constexpr int NB = kBinTile / 2;                  // bands (rows of 2x2 blocks)
+    static constexpr int RB = CW + 1;                        // bands one sample can belong to
+    static constexpr int NCELLS = NB * CELLW;                // (band, cell column) bins
+    static constexpr int CPT = (NCELLS + 1 + kBinThreads - 1) / kBinThreads;   // bins per thread in the scan
     // records per batch, sized so a workgroup stays near 48 KiB of LDS
-    static constexpr int REC_BYTES = 2 * NWP * 4 + CPB * 8 + 4 + 4 + 1;
+    static constexpr int REC_BYTES = 2 * NWP * 4 + CPB * 8 + 4 + RB * 5;
 #ifndef TRON_BIN_REC_KB
 #define TRON_BIN_REC_KB 36
 #endif
     static constexpr int NREC_RAW = (TRON_BIN_REC_KB * 1024) / REC_BYTES;
     static constexpr int NREC = NREC_RAW >= 512 ? 512 : (NREC_RAW / 64) * 64;
+    static constexpr int NSORT = NREC * RB;                  // sorted entries per batch (one per record and band)
     static constexpr int SLOT = 64;                          // longest spoke segment through tile + halo
 };
+
+// packed sorted entry: record id | cell column << 9 | cell row << 15 | |r| << 21 | (r == 0) << 31
+constexpr int kBinMaxRadius = 1023;                          // 10 bits of |r|: grids up to 2048^2
 
 template <int CPB, int CW>
 struct BinLds {
@@ -53,16 +63,38 @@ struct BinLds {
     int sp_pe[kBinMaxSpokes];
     int sp_seg[kBinMaxSpokes];            // rlo (low 16, signed) | len << 16
     int sp_start[kBinMaxSpokes + 1];      // exclusive scan of len
-    unsigned hist[C::NCELLS];             // 4 x 8-bit per-wave counters per cell
-    unsigned short start[C::NCELLS + 1];
-    unsigned sorted[C::NREC];             // per sorted slot: record id | fxrel<<10 | |r|<<16 | (r==0)<<30
+    unsigned hist[C::NCELLS];             // 4 x 8-bit per-wave counters per (band, cell column) bin
+    unsigned short start[C::NCELLS + 2];
+    unsigned sorted[C::NSORT];            // packed entries in (band, column) order
     unsigned key[C::NREC];
-    unsigned char rank[C::NREC];
+    unsigned char rank[C::NREC * C::RB];
     int wcnt[8];
     float wx[C::NREC * C::NWP];
     float wy[C::NREC * C::NWP];
     float2 d[C::NREC * CPB];
 };
+
+// Stores the two horizontally adjacent points (X0, Y), (X0+1, Y) of coil c, slice z: v = (re0, im0, re1, im1).
+__device__ __forceinline__ void store_point_pair(const GridParams &p, int z, int c, int X0, int Y, const float4 v)
+{
+    const int n = p.nxos, h = n / 2;
+    if (Y + h >= n) return;
+    const int row = p.out_shift ? (Y < 0 ? Y + n : Y) : Y + h;     // both fftshifts of src/tron.cu:631 folded in
+    const int colA = p.out_shift ? (X0 < 0 ? X0 + n : X0) : X0 + h;
+    // one 16-byte store for the two columns needs an even first column; then X0 is even too (n is), so X0 != -1 and
+    // the pair does not straddle the periodic wrap.  n/2 odd (e.g. nxos 18, 150) makes every X0 odd: scalar stores.
+    const bool pair = (X0 + 1 + h < n) && p.out_p == 1 && (colA & 1) == 0;
+    float2 *o = p.udata + (size_t)z * p.out_z + ((size_t)row * n + colA) * p.out_p + (size_t)c * p.out_c;
+    if (pair && (n & 1) == 0) {
+        *reinterpret_cast<float4 *>(o) = v;
+    } else {
+        if (X0 + h < n) o[0] = make_float2(v.x, v.y);
+        if (X0 + 1 + h < n) {
+            const int colB = p.out_shift ? (X0 + 1 < 0 ? X0 + 1 + n : X0 + 1) : X0 + 1 + h;
+            p.udata[(size_t)z * p.out_z + ((size_t)row * n + colB) * p.out_p + (size_t)c * p.out_c] = make_float2(v.z, v.w);
+        }
+    }
+}
 
 #ifndef TRON_BIN_WAVES
 #define TRON_BIN_WAVES 3
@@ -79,7 +111,12 @@ grid_binned_kernel(const GridParams p)
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int z = blockIdx.x % p.nslices;
-    const int tile = p.tile_order[blockIdx.x / p.nslices];
+    // tile id | part << 16 | parts << 20 | slot << 24: a heavy tile (the k-space centre: every spoke crosses it) may be
+    // dealt to `parts` workgroups over disjoint spoke ranges; grid_reduce_parts_kernel adds their tiles in part order
+    const int entry = p.tile_order[blockIdx.x / p.nslices];
+    const int tile = entry & 0xffff;
+    const int part = (entry >> 16) & 15, nparts = max((entry >> 20) & 15, 1), slot = (entry >> 24) & 255;
+    const int pe_lo = (int)(((long long)part * p.npe) / nparts), pe_hi = (int)(((long long)(part + 1) * p.npe) / nparts);
     const int c0 = p.coil0 + blockIdx.y * CPB;
     const int ncb = min(CPB, p.nchan - c0);
     const int n = p.nxos;
@@ -135,15 +172,15 @@ grid_binned_kernel(const GridParams p)
     const float by_lo = (float)y0 - p.W - eps, by_hi = (float)(y0 + kBinTile - 1) + p.W + eps;
     const int cx0 = x0 - CW, cy0 = y0 - CW;                     // base cell (0,0) of the histogram
 
-    for (int round0 = 0; round0 < p.npe && p.debug < 4; round0 += kBinMaxSpokes) {
+    for (int round0 = pe_lo; round0 < pe_hi && p.debug < 4; round0 += kBinMaxSpokes) {
         // ---- clip: one thread per spoke, accepted spokes compacted in acquisition order ---------
         if (tid == 0) L.sp_start[0] = 0;
         int nacc = 0;                                           // accepted so far in this round (uniform)
-        for (int chunk0 = round0; chunk0 < min(p.npe, round0 + kBinMaxSpokes); chunk0 += kBinThreads) {
+        for (int chunk0 = round0; chunk0 < min(pe_hi, round0 + kBinMaxSpokes); chunk0 += kBinThreads) {
             const int pe = chunk0 + tid;
             bool accept = false;
             int rlo = 0, len = 0;
-            if (pe < p.npe && pe < round0 + kBinMaxSpokes) {
+            if (pe < pe_hi && pe < round0 + kBinMaxSpokes) {
                 const float2 cs = trig[pe];
                 const float ic = safe_rcp(cs.x), is = safe_rcp(cs.y);
                 const float xa = bx_lo * ic, xb = bx_hi * ic;
@@ -340,10 +377,18 @@ grid_binned_kernel(const GridParams p)
                                      | ((unsigned)wave << 26) | (valid ? 1u << 28 : 0u) | (r == 0 ? 1u << 29 : 0u);
                 L.key[rec] = key;
                 if (valid) {
-                    const unsigned old = atomicAdd(&L.hist[fyrel * C::CELLW + fxrel], 1u << (8 * wave));
-                    const unsigned rk = (old >> (8 * wave)) & 0xffu;
-                    if (rk == 0xffu) atomicOr(p.errflag, 4u);
-                    L.rank[rec] = (unsigned char)rk;
+                    // bands whose 2CW+1 cell rows contain this row: 2b <= fyrel <= 2b + 2CW
+                    const int b_hi = min(fyrel >> 1, C::NB - 1), b_lo = max((fyrel - 2 * CW + 1) >> 1, 0);
+#pragma unroll
+                    for (int t = 0; t < C::RB; ++t) {
+                        const int b = b_lo + t;
+                        if (b <= b_hi) {
+                            const unsigned old = atomicAdd(&L.hist[b * C::CELLW + fxrel], 1u << (8 * wave));
+                            const unsigned rk = (old >> (8 * wave)) & 0xffu;
+                            if (rk == 0xffu) atomicOr(p.errflag, 4u);
+                            L.rank[rec * C::RB + t] = (unsigned char)rk;
+                        }
+                    }
                 }
             }
             // next batch: bounds now, samples in flight while this batch is scanned / placed / applied
@@ -381,84 +426,80 @@ grid_binned_kernel(const GridParams p)
 #pragma unroll
                 for (int k = 0; k < C::CPT; ++k) {
                     const int c = tid * C::CPT + k;
-                    if (c <= C::NCELLS) L.start[c] = (unsigned short)run;
+                    if (c <= C::NCELLS) L.start[c] = (unsigned short)run;   // start[NCELLS] = number of entries
                     run += cnt[k];
                 }
             }
             __syncthreads();
 
-            // ---- C. place record ids in cell order ---------------------------------------------
+            // ---- C. place one packed entry per (record, band) in (band, column) order -------------------------
             for (int rec = tid; rec < nrec; rec += kBinThreads) {
                 const unsigned key = L.key[rec];
                 if (key & (1u << 28)) {
-                    const int cell = (int)((key >> 6) & 63) * C::CELLW + (int)(key & 63);
-                    const unsigned hv = L.hist[cell];
+                    const int fxrel = (int)(key & 63), fyrel = (int)((key >> 6) & 63);
                     const int w = (key >> 26) & 3;
-                    const unsigned below = hv & ((1u << (8 * w)) - 1u);
-                    const int wb = (int)((below & 0xff) + ((below >> 8) & 0xff) + ((below >> 16) & 0xff));
-                    const int pos = L.start[cell] + wb + L.rank[rec];
-                    if (pos >= C::NREC) { atomicOr(p.errflag, 8u); continue; }
-                    // everything the apply loop needs besides the weights: id, cell column, |r|, r == 0
-                    L.sorted[pos] = (unsigned)rec | ((key & 63u) << 10) | (((key >> 12) & 0x3fffu) << 16) | (((key >> 29) & 1u) << 30);
+                    // everything the apply loop needs besides the weights: id, cell column and row, |r|, r == 0
+                    const unsigned ent = (unsigned)rec | ((unsigned)fxrel << 9) | ((unsigned)fyrel << 15)
+                                         | (((key >> 12) & 0x3ffu) << 21) | (((key >> 29) & 1u) << 31);
+                    const int b_hi = min(fyrel >> 1, C::NB - 1), b_lo = max((fyrel - 2 * CW + 1) >> 1, 0);
+#pragma unroll
+                    for (int t = 0; t < C::RB; ++t) {
+                        const int b = b_lo + t;
+                        if (b <= b_hi) {
+                            const int cell = b * C::CELLW + fxrel;
+                            const unsigned hv = L.hist[cell];
+                            const unsigned below = hv & ((1u << (8 * w)) - 1u);
+                            const int wb = (int)((below & 0xff) + ((below >> 8) & 0xff) + ((below >> 16) & 0xff));
+                            const int pos = L.start[cell] + wb + L.rank[rec * C::RB + t];
+                            if (pos >= C::NSORT) { atomicOr(p.errflag, 8u); continue; }
+                            L.sorted[pos] = ent;
+                        }
+                    }
                 }
             }
             __syncthreads();
 
-            // ---- D. apply: each thread walks the 2CW+1 cell rows its 2x2 points can see as ONE loop
-            //         (row ranges concatenated), so a wave runs max-over-lanes(total), not sum of row maxima
+            // ---- D. apply: ONE contiguous range of this thread's band holds every sample its 2x2 points can see
             if (p.debug < 1) {
-                constexpr int NR = 2 * CW + 1;
-                int delta[NR], cum[NR + 1];
-                cum[0] = 0;
-#pragma unroll
-                for (int dy = 0; dy < NR; ++dy) {
-                    const int rowbase = (my + dy) * C::CELLW + mx;
-                    const int kbeg = L.start[rowbase];
-                    const int kend = L.start[rowbase + 2 * CW + 1];
-                    delta[dy] = kbeg - cum[dy];                        // k = i + delta[row]
-                    cum[dy + 1] = cum[dy] + (kend - kbeg);
-                }
-                const int total = cum[NR];
-                // software pipeline: the sorted entry of visit i+1 is fetched while visit i is processed
-                int row_next = 0, dl_next = delta[0];
-#pragma unroll
-                for (int dy = 1; dy < NR; ++dy)
-                    if (0 >= cum[dy]) { row_next = dy; dl_next = delta[dy]; }
-                unsigned ent_next = total > 0 ? L.sorted[dl_next] : 0u;
-                for (int i = 0; i < total; ++i) {
+                const int bin0 = (my >> 1) * C::CELLW + mx;
+                int k = L.start[bin0];
+                const int kend = L.start[bin0 + 2 * CW + 1];
+                unsigned ent_next = k < kend ? L.sorted[k] : 0u;
+                while (k < kend) {
                     const unsigned ent = ent_next;
-                    const int row = row_next;
-                    {
-                        const int i1 = i + 1;
-                        row_next = 0; dl_next = delta[0];
-#pragma unroll
-                        for (int dy = 1; dy < NR; ++dy)
-                            if (i1 >= cum[dy]) { row_next = dy; dl_next = delta[dy]; }
-                        if (i1 < total) ent_next = L.sorted[i1 + dl_next];
-                    }
-                    const int id = (int)(ent & 1023u);
-                    const int jp = 2 * CW - row;                       // padded wy index for row Y0 (Y0+1 uses jp+1)
-                    const int ip = mx + 2 * CW - (int)((ent >> 10) & 63u);   // padded wx index for column X0
+                    ++k;
+                    if (k < kend) ent_next = L.sorted[k];                      // next visit's entry rides with this visit's reads
+                    const int id = (int)(ent & 511u);
+                    const int ip = mx + 2 * CW - (int)((ent >> 9) & 63u);      // padded wx index for column X0
+                    const int jp = my + 2 * CW - (int)((ent >> 15) & 63u);     // padded wy index for row Y0
                     const float *wxr = L.wx + id * C::NWP + ip;
                     const float *wyr = L.wy + id * C::NWP + jp;
                     const float wxa = wxr[0], wxb = wxr[1];
                     const float wya = wyr[0], wyb = wyr[1];
-                    const int ar = (int)((ent >> 16) & 0x3fffu);
+                    float4 dd[CPB / 2 > 0 ? CPB / 2 : 1];
+                    float2 d1[CPB % 2 ? CPB : 1];
+                    if (CPB % 2 == 0) {
+                        const float4 *d4 = reinterpret_cast<const float4 *>(L.d) + id;
+#pragma unroll
+                        for (int c = 0; c < CPB / 2; ++c) dd[c] = d4[c * C::NREC];
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < CPB; ++c) d1[c] = L.d[c * C::NREC + id];
+                    }
+                    // all LDS reads of the visit are in flight before the first use: one round trip per visit
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int ar = (int)((ent >> 21) & 0x3ffu);
                     float wq[4];
                     wq[0] = wxa * wya; wq[1] = wxb * wya; wq[2] = wxa * wyb; wq[3] = wxb * wyb;   // src/tron.cu:516
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
                         if ((unsigned)(ar - Rlo[q]) > (unsigned)(Rhi[q] - Rlo[q])) wq[q] = 0.f;    // src/tron.cu:512,521
-                    if (has_centre && ((ent >> 30) & 1u)) {
+                    if (has_centre && (ent >> 31)) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
                             if (Rlo[q] == 0) wq[q] += wq[q];                                      // r = 0 sits in both loops
                     }
                     if (CPB % 2 == 0) {
-                        const float4 *d4 = reinterpret_cast<const float4 *>(L.d) + id;
-                        float4 dd[CPB / 2 > 0 ? CPB / 2 : 1];
-#pragma unroll
-                        for (int c = 0; c < CPB / 2; ++c) dd[c] = d4[c * C::NREC];
 #pragma unroll
                         for (int c = 0; c < CPB / 2; ++c) {
                             const float4 d = dd[c];
@@ -473,7 +514,7 @@ grid_binned_kernel(const GridParams p)
                     } else {
 #pragma unroll
                         for (int c = 0; c < CPB; ++c) {
-                            const float2 d = L.d[c * C::NREC + id];
+                            const float2 d = d1[c];
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
                                 acc[q][c].x = fmaf(d.x, wq[q], acc[q][c].x);
@@ -489,16 +530,23 @@ grid_binned_kernel(const GridParams p)
         }
     }
 
+    if (nparts > 1) {
+        // partial tile of this spoke range, tile-local [coil][row][col], already scaled; summed by grid_reduce_parts_kernel
+        float2 *part_base = p.partial + ((((size_t)z * p.nsplit_slots + slot) * p.max_parts + part) * p.nchan) * (kBinTile * kBinTile);
 #pragma unroll
-    for (int qy = 0; qy < 2; ++qy) {
-        const int Y = Y0 + qy;
-        if (Y + h >= n) continue;
-        const int row = p.out_shift ? (Y < 0 ? Y + n : Y) : Y + h;     // both fftshifts of src/tron.cu:631 folded in
-        const int colA = p.out_shift ? (X0 < 0 ? X0 + n : X0) : X0 + h;
-        // one 16-byte store for the two columns needs an even first column; then X0 is even too (n is), so X0 != -1 and
-        // the pair does not straddle the periodic wrap.  n/2 odd (e.g. nxos 18, 150) makes every X0 odd: scalar stores.
-        const bool pair = (X0 + 1 + h < n) && p.out_p == 1 && (colA & 1) == 0;
-        float2 *out = p.udata + (size_t)z * p.out_z + ((size_t)row * n + colA) * p.out_p;
+        for (int qy = 0; qy < 2; ++qy)
+#pragma unroll
+            for (int c = 0; c < CPB; ++c)
+                if (c < ncb) {
+                    float4 v;
+                    v.x = acc[2 * qy][c].x * p.scale; v.y = acc[2 * qy][c].y * p.scale;
+                    v.z = acc[2 * qy + 1][c].x * p.scale; v.w = acc[2 * qy + 1][c].y * p.scale;
+                    *reinterpret_cast<float4 *>(part_base + (size_t)(c0 + c) * (kBinTile * kBinTile) + (my + qy) * kBinTile + mx) = v;
+                }
+        return;
+    }
+#pragma unroll
+    for (int qy = 0; qy < 2; ++qy)
 #pragma unroll
         for (int c = 0; c < CPB; ++c)
             if (c < ncb) {
@@ -507,17 +555,33 @@ grid_binned_kernel(const GridParams p)
                 v.y = acc[2 * qy][c].y * p.scale;
                 v.z = acc[2 * qy + 1][c].x * p.scale;
                 v.w = acc[2 * qy + 1][c].y * p.scale;
-                float2 *o = out + (size_t)(c0 + c) * p.out_c;
-                if (pair && (n & 1) == 0) {
-                    *reinterpret_cast<float4 *>(o) = v;
-                } else {
-                    if (X0 + h < n) o[0] = make_float2(v.x, v.y);
-                    if (X0 + 1 + h < n) {
-                        const int colB = p.out_shift ? (X0 + 1 < 0 ? X0 + 1 + n : X0 + 1) : X0 + 1 + h;
-                        p.udata[(size_t)z * p.out_z + ((size_t)row * n + colB) * p.out_p + (size_t)(c0 + c) * p.out_c] = make_float2(v.z, v.w);
-                    }
-                }
+                store_point_pair(p, z, c0 + c, X0, Y0 + qy, v);
             }
+}
+
+// Adds the partial tiles of a split tile in part order (fixed order: results do not depend on scheduling) and stores
+// the sum exactly as an unsplit workgroup would.  grid = (split slots x slices, nchan), block = 256.
+__global__ void __launch_bounds__(kBinThreads)
+grid_reduce_parts_kernel(const GridParams p)
+{
+    const int z = blockIdx.x % p.nslices;
+    const int slot = blockIdx.x / p.nslices;
+    const int entry = p.split_slots[slot];                      // tile id | parts << 20
+    const int tile = entry & 0xffff, nparts = (entry >> 20) & 15;
+    const int c = p.coil0 + blockIdx.y;
+    const int n = p.nxos, h = n / 2;
+    const int x0 = (tile % p.tiles_per_row) * kBinTile - h, y0 = (tile / p.tiles_per_row) * kBinTile - h;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int mx = 2 * (lane & 15), my = 8 * wave + 2 * (lane >> 4);
+    const float2 *base = p.partial + (((size_t)z * p.nsplit_slots + slot) * p.max_parts * p.nchan + c) * (kBinTile * kBinTile);
+#pragma unroll
+    for (int qy = 0; qy < 2; ++qy) {
+        float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int g = 0; g < nparts; ++g) {
+            const float4 v = *reinterpret_cast<const float4 *>(base + (size_t)g * p.nchan * (kBinTile * kBinTile) + (my + qy) * kBinTile + mx);
+            sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+        }
+        store_point_pair(p, z, c, x0 + mx, y0 + my + qy, sum);
     }
 }
 
@@ -529,7 +593,8 @@ static hipError_t launch_binned_cpb(const GridParams &p, int half_in, hipStream_
     q.tiles_per_row = tpr;
     q.ntiles = tpr * tpr;
     const int chunks = (p.nchan - p.coil0 + CPB - 1) / CPB;
-    dim3 grid((unsigned)((size_t)q.ntiles * q.nslices), (unsigned)chunks);
+    const int entries = p.tile_entries > 0 ? p.tile_entries : q.ntiles;
+    dim3 grid((unsigned)((size_t)entries * q.nslices), (unsigned)chunks);
     const size_t lds = sizeof(BinLds<CPB, CW>);
     if (lds > 64 * 1024) {   // above the default dynamic-LDS limit: raise it once per instantiation
         static hipError_t once = [] {
@@ -545,6 +610,9 @@ static hipError_t launch_binned_cpb(const GridParams &p, int half_in, hipStream_
         hipLaunchKernelGGL((grid_binned_kernel<CPB, CW, true>), grid, dim3(kBinThreads), lds, s, q);
     else
         hipLaunchKernelGGL((grid_binned_kernel<CPB, CW, false>), grid, dim3(kBinThreads), lds, s, q);
+    if (q.nsplit_slots > 0)
+        hipLaunchKernelGGL(grid_reduce_parts_kernel, dim3((unsigned)((size_t)q.nsplit_slots * q.nslices), (unsigned)(p.nchan - p.coil0)),
+                           dim3(kBinThreads), 0, s, q);
     return hipGetLastError();
 }
 
@@ -566,6 +634,7 @@ static hipError_t launch_binned_cw(const GridParams &p, int half_in, hipStream_t
 // p.tile_order must list the 32x32 tiles (see build_tile_order(nxos, 32, ...)).
 hipError_t launch_grid_binned(const GridParams &p, int half_in, hipStream_t s)
 {
+    if (p.nxos / 2 - 1 > kBinMaxRadius) return hipErrorInvalidValue;   // |r| has 10 bits in a sorted entry
     const int cw = (int)ceilf(p.W);
     switch (cw) {
         case 1: return launch_binned_cw<1>(p, half_in, s);

@@ -235,6 +235,38 @@ void build_tile_order(int nxos, int tile, std::vector<int> &order)
     for (size_t i = 0; i < t.size(); ++i) order[i] = t[i].id;
 }
 
+// Tile list of the binned gridding kernel for SMALL launches: a tile expected to hold more than `target` sample records
+// per image is dealt to several workgroups over disjoint spoke ranges (entry = tile | part << 16 | parts << 20 | slot << 24),
+// so that its serial chain no longer bounds the launch.  Expected records of a tile = integral of the radial sampling
+// density npe / (pi r) over tile + halo.  slots[s] = tile | parts << 20 of split tile s.
+void build_split_tile_order(int nxos, int tile, int npe, float W, int target, int max_parts,
+                            std::vector<int> &order, std::vector<int> &slots)
+{
+    std::vector<int> plain;
+    build_tile_order(nxos, tile, plain);
+    const int tpr = (nxos + tile - 1) / tile;
+    const int halo = (int)ceilf(W);
+    order.clear();
+    slots.clear();
+    for (int id : plain) {
+        const int x0 = (id % tpr) * tile - nxos / 2, y0 = (id / tpr) * tile - nxos / 2;
+        double dens = 0.0;
+        for (int y = y0 - halo; y < y0 + tile + halo; ++y)
+            for (int x = x0 - halo; x < x0 + tile + halo; ++x)
+                dens += 1.0 / std::max(0.5, sqrt((double)x * x + (double)y * y));
+        const double est = npe / M_PI * dens;
+        int parts = (int)(est / target + 0.5);
+        parts = std::max(1, std::min(std::min(parts, max_parts), std::max(1, npe)));
+        if (parts > 1 && slots.size() < 255) {
+            const int slot = (int)slots.size();
+            slots.push_back(id | (parts << 20));
+            for (int g = 0; g < parts; ++g) order.push_back(id | (g << 16) | (parts << 20) | (slot << 24));
+        } else {
+            order.push_back(id);
+        }
+    }
+}
+
 }  // namespace tron
 
 using namespace tron;
@@ -248,6 +280,7 @@ extern "C" void tron_config_default(tron_config *cfg)
     cfg->blocks = 4096;           // src/tron.cu:59
     cfg->threads = 128;           // src/tron.cu:58
     cfg->kb_mode = TRON_KB_FAST;
+    cfg->pin_host = 1;            // the reference pins its output (cudaMallocHost, src/tron.cu:967)
 }
 
 // main()'s dimension logic.  Adjoint: src/tron.cu:905-935; forward: :936-961; the int <- float
@@ -289,7 +322,6 @@ extern "C" int tron_derive_dims(const tron_config *cfg, const uint64_t in_dims[5
         d->out_dims[2] = d->nx;
         d->out_dims[3] = d->ny;
         d->out_dims[4] = d->nz;
-        d->out_bytes = (uint64_t)1 * d->nt * d->nx * d->ny * d->nz * sizeof(tron_float2);
     } else {
         d->nx = (int)in_dims[2];
         d->ny = (int)in_dims[3];
@@ -310,10 +342,24 @@ extern "C" int tron_derive_dims(const tron_config *cfg, const uint64_t in_dims[5
         d->out_dims[2] = d->nro;
         d->out_dims[3] = d->npe1;
         d->out_dims[4] = d->npe2;
-        d->out_bytes = (uint64_t)d->nc * d->nt * d->nro * d->npe1 * d->npe2 * sizeof(tron_float2);
     }
     d->prof_slide = prof_slide;
-    d->in_elems = in_dims[0] * in_dims[1] * in_dims[2] * in_dims[3] * in_dims[4];
+    // h_outdatasize (src/tron.cu:934,960) and the input element count, with checked products: five dims of up to
+    // 2^31-1 each wrap 64 bits, and a wrapped count would pass every later size check (crafted .ra header)
+    {
+        const uint64_t lead = cfg->adjoint ? 1 : (uint64_t)d->nc;
+        uint64_t ob = sizeof(tron_float2), ie = 1;
+        const uint64_t of[5] = {lead, (uint64_t)d->out_dims[1], (uint64_t)d->out_dims[2], (uint64_t)d->out_dims[3], (uint64_t)d->out_dims[4]};
+        bool bad = false;
+        for (int i = 0; i < 5; ++i) {
+            bad = bad || __builtin_mul_overflow(ob, of[i], &ob);
+            bad = bad || __builtin_mul_overflow(ie, in_dims[i], &ie);
+        }
+        if (bad || ie > (UINT64_MAX >> 4) || ob > (UINT64_MAX >> 1))
+            return tron::fail(TRON_ERR_INVALID, "tron_derive_dims: dimensions overflow the addressable size");
+        d->out_bytes = ob;
+        d->in_elems = ie;
+    }
     if (!(d->nc % 2 == 0 || d->nc == 1))                              // assert at src/tron.cu:963
         return tron::fail(TRON_ERR_INVALID, "only one or an even number of coils is supported (nc=%d), as in the reference", d->nc);
     if (d->nx <= 0 || d->nxos <= 0 || d->nro <= 0 || d->npe1work <= 0 || d->nz <= 0)

@@ -34,6 +34,12 @@ struct GridParams {
     int skip_outside;        // binned kernel: tiles wholly beyond radius nxos/2-1+W (always zero, src/tron.cu:498-502) are not stored;
                              // only set when the consumer (launch_fft512_adjoint) does not read them either
     int debug;               // TRON_DEBUG_SKIP: 1 = skip the gather phase, 2 = skip staging too (timing experiments only)
+    // binned kernel, split tiles (small launches: the k-space-centre tiles are dealt to several workgroups each)
+    int tile_entries;        // entries of tile_order (0: ntiles plain tile ids)
+    int nsplit_slots;        // split tiles per slice (0: none); slot s is tile split_slots[s] & 0xffff with (>> 20) & 15 parts
+    int max_parts;
+    const int *split_slots;
+    float2 *partial;         // [slice][slot][part][coil][32 x 32] partial tiles
 };
 
 struct PostParams {           // crop + deapodise + (optional) root-sum-of-squares, adjoint tail
@@ -54,6 +60,7 @@ struct DegridParams {
     const float2 *udata;      // Cartesian input
     float2 *nudata;           // [image][nrep*(ro + nro*pe) + c]
     const float2 *trig;       // (cos, sin) per spoke
+    int trig_img_stride;      // table entries between consecutive images (0: same angles every image)
     const int *tile_order;    // degrid_tile_kernel: 32x32 tiles, centre first (nullptr: raster order)
     long long in_z, in_c;     // input strides per image and per coil
     int in_p, in_shift;       // pixel stride; 1: input is the raw FFT output (second fftshift folded into indexing)
@@ -78,6 +85,15 @@ hipError_t warm_kernels();       // force-load the code object of tron_kernels.h
 hipError_t warm_grid_binned();   // ... and of tron_grid_binned.hip
 hipError_t warm_fft512();        // ... and of tron_fft512.hip
 hipError_t warm_degrid_tile();   // ... and of tron_degrid_tile.hip
+hipError_t warm_cgnr();          // ... and of tron_cgnr.hip
+// CGNR vector kernels (tron_cgnr.hip), batched over slices; per-slice scalars live on the device
+hipError_t launch_cg_scale_norm2(float2 *x, size_t n, int nslices, float scale, double *partial, hipStream_t s);
+hipError_t launch_cg_wnorm2(const float2 *v, size_t n, int nslices, int nchan, int nro, float a, float b, double *partial, hipStream_t s);
+hipError_t launch_cg_finish(const double *partial, double *num, float *coef, int mode, int nslices, hipStream_t s);
+hipError_t launch_cg_axpy(float2 *y, const float2 *x, const float *coef, float sign, size_t n, int nslices, hipStream_t s);
+hipError_t launch_cg_xpby(float2 *pt, const float2 *zt, const float *coef, size_t n, int nslices, hipStream_t s);
+hipError_t launch_sos(float2 *out, const float2 *coil, size_t npix, int nchan, int nslices, hipStream_t s);
+constexpr int kCgPartials = 64;  // = kCgBlocks
 // tiled degridding (tron_degrid_tile.hip), W <= 3
 hipError_t launch_degrid_tile(const DegridParams &p, int kb_mode, hipStream_t s);
 // fused pruned inverse FFT + crop + deapodise + SoS for nxos = 512, nx = 256 (tron_fft512.hip)

@@ -425,7 +425,7 @@ __global__ void __launch_bounds__(256) degrid_kernel(const DegridParams p)
     for (int t = 0; t < kKbPolyTerms; ++t) kb.poly[t] = p.kb_poly[t];
     const float W = p.W;
     const float R = (float)ro / (float)p.nro - 0.5f;                  // src/tron.cu:554
-    const float2 cs = p.trig[pe];
+    const float2 cs = p.trig[(size_t)k * p.trig_img_stride + pe];
     float X = cs.y, Y = cs.x;                                         // X = sin, Y = cos (src/tron.cu:559)
     X = (float)n * R * X + (float)((n + 1) / 2);                      // src/tron.cu:560-561
     Y = (float)n * R * Y + (float)((n + 1) / 2);

@@ -18,6 +18,7 @@
 #include <unistd.h>
 
 #include <thread>
+#include <vector>
 
 #include "../../include/rawarray.h"
 #include "../../include/tron_hip.h"
@@ -31,10 +32,10 @@ static void usage()
           "  -a                 adjoint operation (gridding); default is forward (degridding)\n"
           "  -B blocks          accepted for compatibility, ignored\n"
           "  -d prof_slide      phase encodes to slide between slices (helical / sliding window)\n"
-          "  -g n               GPU device to use (default: 0)\n"
+          "  -g n               GPU device to use (default: 0); `-g all` or `-g 0,1,..`: shard the slices over several GPUs\n"
           "  -G                 golden angle radial\n"
           "  -h                 show this help\n"
-          "  -i niter           CGNR iterations (not supported; must be 0)\n"
+          "  -i niter           CGNR iterations (adjoint only; 0 = plain gridding)\n"
           "  -k width           half-width of the gridding kernel (default 2)\n"
           "  -o gridos          grid oversampling factor (default 2)\n"
           "  -r nro             number of readout points (taken from the input file)\n"
@@ -49,6 +50,8 @@ int main(int argc, char *argv[])
 {
     tron_config cfg;
     tron_config_default(&cfg);
+    bool multi_gpu = false;              // -g all | -g 0,1,... | TRON_GPUS=n: one worker thread + plan per device
+    std::vector<int> gpu_list;
     int c;
     opterr = 0;
     while ((c = getopt(argc, argv, "3aB:d:g:Ghi:k:o:r:s:T:u:v")) != -1) {   // src/tron.cu:822
@@ -57,7 +60,21 @@ int main(int argc, char *argv[])
             case 'a': cfg.adjoint = 1; break;
             case 'B': cfg.blocks = atoi(optarg); break;
             case 'd': cfg.prof_slide = atoi(optarg); break;
-            case 'g': cfg.device = atoi(optarg); break;
+            case 'g':                                                          // src/tron.cu:838: cudaSetDevice(n); here also
+                if (strcmp(optarg, "all") == 0) {                              // "all" or a list "0,1,2": one worker per device
+                    multi_gpu = true;
+                } else if (strchr(optarg, ',')) {
+                    multi_gpu = true;
+                    for (const char *q = optarg; *q;) {
+                        gpu_list.push_back(atoi(q));
+                        const char *c = strchr(q, ',');
+                        if (!c) break;
+                        q = c + 1;
+                    }
+                } else {
+                    cfg.device = atoi(optarg);
+                }
+                break;
             case 'G': cfg.golden_angle = 1; break;
             case 'h': usage(); return 1;                                       // src/tron.cu:843-845
             case 'i': cfg.niter = atoi(optarg); break;
@@ -78,6 +95,13 @@ int main(int argc, char *argv[])
     const char *infile = argv[optind];
     const char *outfile = optind + 1 < argc ? argv[optind + 1] : "img_tron.ra";   // src/tron.cu:877
     if (const char *kb = getenv("TRON_KB_MODE")) cfg.kb_mode = strcmp(kb, "exact") == 0 ? TRON_KB_EXACT : TRON_KB_FAST;
+    if (const char *cc = getenv("TRON_CGNR_CONSISTENT")) cfg.cgnr_consistent = atoi(cc) != 0;
+    if (const char *ng = getenv("TRON_GPUS")) {
+        if (atoi(ng) > 1 && gpu_list.empty()) {
+            multi_gpu = true;
+            for (int g = 0; g < atoi(ng); ++g) gpu_list.push_back(g);
+        }
+    }
 
 #define VPRINT(...) do { if (cfg.verbose) printf(__VA_ARGS__); } while (0)
 
@@ -111,6 +135,8 @@ int main(int argc, char *argv[])
         ra_free(&hdr);
         return 1;
     }
+    uint64_t hdr_dims[5];
+    memcpy(hdr_dims, hdr.dims, sizeof(hdr_dims));
     ra_free(&hdr);
 
     struct timespec t0, t1, tp;
@@ -136,7 +162,9 @@ int main(int argc, char *argv[])
     out.dims = static_cast<uint64_t *>(malloc(5 * sizeof(uint64_t)));
     out.data = static_cast<uint8_t *>(calloc(dims.out_bytes ? dims.out_bytes : 1, 1));
     tron_plan *plan = nullptr;
-    int rc = (out.dims && out.data) ? tron_plan_create(&plan, &cfg, &dims) : TRON_ERR_NOMEM;
+    int rc = TRON_OK;
+    if (!(out.dims && out.data)) rc = TRON_ERR_NOMEM;
+    else if (!multi_gpu) rc = tron_plan_create(&plan, &cfg, &dims);        // multi-GPU: every worker creates its own plan
     clock_gettime(CLOCK_MONOTONIC, &tp);
     reader.join();
     if (!out.dims || !out.data) {
@@ -147,6 +175,18 @@ int main(int argc, char *argv[])
         tron_plan_destroy(plan);
         ra_free(&out);
         return 1;
+    }
+    {   // the file was opened a second time by the reader thread: it must still be the array the header promised
+        bool same = in.ndims == 5 && in.eltype == RA_TYPE_COMPLEX && in.elbyte == (cfg.input_half ? 4u : 8u)
+                    && in.size / (cfg.input_half ? 4 : 8) >= dims.in_elems;
+        for (int i = 0; same && i < 5; ++i) same = in.dims[i] == hdr_dims[i];
+        if (!same) {
+            fprintf(stderr, "tron: %s changed between reading its header and its payload\n", infile);
+            tron_plan_destroy(plan);
+            ra_free(&in);
+            ra_free(&out);
+            return 1;
+        }
     }
     memcpy(out.dims, dims.out_dims, 5 * sizeof(uint64_t));
     VPRINT("Read time: %.3f s (overlapped with) plan time: %.3f s\n", read_s, (tp.tv_sec - t0.tv_sec) + 1e-9 * (tp.tv_nsec - t0.tv_nsec));
@@ -159,7 +199,11 @@ int main(int argc, char *argv[])
     VPRINT("WARNING: Assuming square Cartesian dimensions for now.\n");
 
     VPRINT("Running reconstruction ...\n ");
-    if (rc == TRON_OK) rc = tron_recon_radial2d(plan, reinterpret_cast<tron_float2 *>(out.data), reinterpret_cast<const tron_float2 *>(in.data));
+    if (rc == TRON_OK && multi_gpu)
+        rc = tron_recon_radial2d_multi(&cfg, &dims, gpu_list.empty() ? nullptr : gpu_list.data(), (int)gpu_list.size(),
+                                       reinterpret_cast<tron_float2 *>(out.data), reinterpret_cast<const tron_float2 *>(in.data));
+    else if (rc == TRON_OK)
+        rc = tron_recon_radial2d(plan, reinterpret_cast<tron_float2 *>(out.data), reinterpret_cast<const tron_float2 *>(in.data));
     if (rc != TRON_OK) {
         fprintf(stderr, "tron: %s\n", tron_last_error());
         tron_plan_destroy(plan);

@@ -22,6 +22,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -88,6 +89,11 @@ struct tron_plan {
     int *d_tile_order = nullptr;
     int *d_tile_order32 = nullptr;   // 32x32 tiles of the binned (fast) gridding kernel
     bool binned = false;
+    // small launches of the binned kernel: heavy (k-space-centre) tiles dealt to several workgroups each
+    int *d_tile_order32_split = nullptr, *d_split_slots = nullptr;
+    int split_entries = 0, nsplit_slots = 0, max_parts = 0, split_below = 0;
+    float2 *d_partial = nullptr;
+    size_t partial_slices = 0;
     float *d_deapod = nullptr;
     unsigned int *d_errflag = nullptr;
     int ntiles = 0, tiles_per_row = 0;
@@ -102,6 +108,15 @@ struct tron_plan {
     size_t stage_in_bytes = 0;
     void *d_stage_out = nullptr;
     size_t stage_out_bytes = 0;
+    // CGNR (niter > 0): the forward operator's tables and the iteration's vectors, batched over the slices of a chunk
+    float *d_deapod_fwd = nullptr;   // 1/w, n = nxos, sigma = 1 (src/tron.cu:643)
+    float2 *d_trig_fwd = nullptr;    // linear angles in the degridding kernel's own convention (src/tron.cu:555); null: share d_trig
+    float2 *d_cg_r = nullptr, *d_cg_v = nullptr, *d_cg_zt = nullptr, *d_cg_pt = nullptr, *d_cg_x = nullptr;
+    double *d_cg_partial = nullptr, *d_cg_num = nullptr;
+    float *d_cg_coef = nullptr;
+    int cg_slices = 0;
+    hipStream_t stream_up = nullptr, stream_down = nullptr;   // host-buffer entry point: upload / download lanes
+    std::vector<hipEvent_t> ev_pipe;                          // its chunk events (created on demand, reused)
     float2 *d_trig_tmp = nullptr;  // stage-level gridding calls
     int chunk_cap = 0;             // slices the work buffers hold (1.5 x chunk for the adjoint)
     bool fft512 = false;           // fused pruned FFT path (nxos 512 -> nx 256)
@@ -109,6 +124,9 @@ struct tron_plan {
     float2 *d_fft_tmp = nullptr;   // chunk * nchan * 256 * 512
     std::map<std::pair<int, int>, FftPlan> fft;   // (batch, direction) -> plan
     // timing
+    int debug_skip = 0;            // environment knobs, read once at plan creation (never on the launch path)
+    bool degrid_simple = false, no_disc = false;
+    bool pin_host = false;         // hipHostRegister the caller's buffers in tron_recon_radial2d[_range]
     bool timing = false;
     bool sync_each = false;        // TRON_SYNC_EACH=1: synchronise after every launch and name the failing stage
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[STAGE_COUNT];
@@ -235,12 +253,13 @@ void fill_grid_consts(const tron_plan *p, GridParams &g)
     g.dcf_a = p->dcf_a;
     g.dcf_b = p->dcf_b;
     memcpy(g.kb_poly, p->kb_poly, sizeof(g.kb_poly));
-    if (const char *dbg = getenv("TRON_DEBUG_SKIP")) g.debug = atoi(dbg);
+    g.debug = p->debug_skip;
 }
 
 // Adjoint for slices [zfirst, zfirst+zcount).  d_in_z0 points at the first spoke of slice
 // zfirst's window; d_out at that slice's output.
-int adjoint_run(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, int zcount, int combine)
+// in_stride_spokes: spokes between the windows of consecutive slices in d_in_z0 (0 = prof_slide: views into the stream)
+int adjoint_run(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, int zcount, int combine, int in_stride_spokes = 0)
 {
     const tron_dims &d = p->d;
     const size_t n2 = (size_t)d.nxos * d.nxos;
@@ -268,10 +287,11 @@ int adjoint_run(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, int 
         GridParams g;
         memset(&g, 0, sizeof(g));
         fill_grid_consts(p, g);
-        g.nudata = static_cast<const unsigned char *>(d_in_z0) + (size_t)z0 * d.prof_slide * d.nro * p->nchan * elem;
+        const int in_stride = in_stride_spokes > 0 ? in_stride_spokes : d.prof_slide;
+        g.nudata = static_cast<const unsigned char *>(d_in_z0) + (size_t)z0 * in_stride * d.nro * p->nchan * elem;
         g.udata = grid_buf;
         g.trig = p->d_trig + (golden ? (size_t)(zfirst + z0) * d.prof_slide : 0);
-        g.in_slice_stride = (long long)d.prof_slide * d.nro * p->nchan;
+        g.in_slice_stride = (long long)in_stride * d.nro * p->nchan;
         g.trig_slice_stride = golden ? d.prof_slide : 0;
         g.nslices = cz;
         g.apply_dcf = 1;
@@ -280,12 +300,28 @@ int adjoint_run(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, int 
         g.out_p = 1;
         g.out_shift = 1;
         // the fused FFT never reads beyond the sampled disc, so the gridding kernel need not store zeros there
-        const int rzero = (p->fft512 && combine && !getenv("TRON_NO_DISC")) ? (int)floorf((float)(d.nxos / 2 - 1) + p->cfg.kernwidth) + 1 : 0;
+        const int rzero = (p->fft512 && combine && !p->no_disc) ? (int)floorf((float)(d.nxos / 2 - 1) + p->cfg.kernwidth) + 1 : 0;
         g.skip_outside = rzero > 0 ? 1 : 0;
         {
             StageTimer t(p, STAGE_GRID, st);
             if (p->binned) {
                 g.tile_order = p->d_tile_order32;
+                if (cz < p->split_below && p->nsplit_slots > 0) {
+                    // a launch this small would be bound by the centre tiles' serial chains: split them over spoke ranges
+                    if (p->partial_slices < (size_t)cz) {
+                        if (p->d_partial) { HIP_TRY(hipStreamSynchronize(st)); HIP_TRY(hipFree(p->d_partial)); p->d_partial = nullptr; }
+                        const size_t want = (size_t)std::min(p->split_below, std::max(cz, 8));
+                        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_partial),
+                                          want * p->nsplit_slots * p->max_parts * p->nchan * kBinnedTile * kBinnedTile * sizeof(float2)));
+                        p->partial_slices = want;
+                    }
+                    g.tile_order = p->d_tile_order32_split;
+                    g.tile_entries = p->split_entries;
+                    g.nsplit_slots = p->nsplit_slots;
+                    g.max_parts = p->max_parts;
+                    g.split_slots = p->d_split_slots;
+                    g.partial = p->d_partial;
+                }
                 HIP_TRY(launch_grid_binned(g, p->cfg.input_half, st));
             } else {
                 HIP_TRY(launch_grid(g, p->kb_mode, p->cfg.input_half, st));
@@ -332,22 +368,27 @@ int adjoint_run(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, int 
     return TRON_OK;
 }
 
-int forward_run(tron_plan *p, void *d_out, const void *d_in, int nimg)
+// trig / deapod default to the plan's own tables (forward plans); the CGNR path of an adjoint plan passes the forward
+// operator's tables and a per-image angle stride (every slice has its own golden angles)
+int forward_run(tron_plan *p, void *d_out, const void *d_in, int nimg, const float2 *trig = nullptr, int trig_img_stride = 0,
+                const float *deapod = nullptr)
 {
     const tron_dims &d = p->d;
     const size_t n2 = (size_t)d.nxos * d.nxos;
+    if (!trig) trig = p->d_trig;
+    if (!deapod) deapod = p->d_deapod;
     for (int k0 = 0; k0 < nimg; k0 += p->chunk) {
         const int ck = std::min(p->chunk, nimg - k0);
         const float2 *img = static_cast<const float2 *>(d_in) + (size_t)k0 * p->nchan * d.nx * d.nx;
         if (p->fft512) {
             // fused: pad + deapodise + shift + pruned forward FFT (tron_fft512.hip)
             StageTimer t(p, STAGE_FFT);
-            HIP_TRY(launch_fft512_forward(img, p->d_fft_tmp, p->d_grid, p->d_tw512, p->d_deapod, p->nchan, ck, p->stream));
+            HIP_TRY(launch_fft512_forward(img, p->d_fft_tmp, p->d_grid, p->d_tw512, deapod, p->nchan, ck, p->stream));
         } else {
             PreParams a;
             a.img = img;
             a.fft = p->d_grid;
-            a.inv_deapod = p->d_deapod;
+            a.inv_deapod = deapod;
             a.nx = d.nx;
             a.nxos = d.nxos;
             a.nchan = p->nchan;
@@ -363,14 +404,15 @@ int forward_run(tron_plan *p, void *d_out, const void *d_in, int nimg)
         memset(&g, 0, sizeof(g));
         g.udata = p->d_grid;
         g.nudata = static_cast<float2 *>(d_out) + (size_t)k0 * p->nchan * d.nro * d.npe1work;
-        g.trig = p->d_trig;
+        g.trig = trig + (size_t)k0 * trig_img_stride;
+        g.trig_img_stride = trig_img_stride;
         g.tile_order = p->d_tile_order32;
         g.in_z = (long long)p->nchan * n2;
         g.in_c = (long long)n2;
         g.in_p = 1;
         g.in_shift = 1;
         g.in_transposed = p->fft512 ? 1 : 0;      // launch_fft512_forward stores the grid transposed
-        if (const char *dbg = getenv("TRON_DEBUG_SKIP")) g.debug = atoi(dbg);
+        g.debug = p->debug_skip;
         g.n = d.nxos;
         g.nrep = p->nchan;
         g.nro = d.nro;
@@ -381,11 +423,79 @@ int forward_run(tron_plan *p, void *d_out, const void *d_in, int nimg)
         memcpy(g.kb_poly, p->kb_poly, sizeof(g.kb_poly));
         {
             StageTimer t(p, STAGE_DEGRID);
-            if (p->cfg.kernwidth <= 3.f && !getenv("TRON_DEGRID_SIMPLE"))
+            if (p->cfg.kernwidth <= 3.f && !p->degrid_simple)
                 HIP_TRY(launch_degrid_tile(g, p->kb_mode, p->stream));
             else
                 HIP_TRY(launch_degrid(g, p->kb_mode, p->stream));
         }
+    }
+    return TRON_OK;
+}
+
+// CGNR, src/tron.cu:665-720 as Knopp et al. 2007 Alg. 1 intends it (the reference marks its own version "NOT WORKING
+// CORRECTLY YET", :670; DESIGN.md lists the five repairs F1-F5), for slices [zfirst, zfirst+zcount) of a
+// device-resident spoke stream, all slices of a chunk advancing together.  d_out: combine ? SoS images [z][nx*ny]
+// : coil images [z][nchan*id + c].
+int cgnr_run(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, int zcount, int combine)
+{
+    const tron_dims &d = p->d;
+    if (p->cfg.input_half) return fail(TRON_ERR_UNSUPPORTED, "CGNR needs complex64 k-space (the residual lives in fp32)");
+    const size_t n = (size_t)p->nchan * d.nro * d.npe1work;          // data-space elements per slice
+    const size_t N = (size_t)p->nchan * d.nx * d.ny;                 // image-space elements per slice (F2)
+    const size_t spoke_bytes = (size_t)d.nro * p->nchan * sizeof(float2);
+    const int step = std::max(1, std::min(p->chunk, zcount));
+    if (p->cg_slices < step) {
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        for (void *q : {(void *)p->d_cg_r, (void *)p->d_cg_v, (void *)p->d_cg_zt, (void *)p->d_cg_pt, (void *)p->d_cg_x,
+                        (void *)p->d_cg_partial, (void *)p->d_cg_num, (void *)p->d_cg_coef})
+            if (q) HIP_TRY(hipFree(q));
+        p->d_cg_r = p->d_cg_v = p->d_cg_zt = p->d_cg_pt = p->d_cg_x = nullptr;
+        p->d_cg_partial = p->d_cg_num = nullptr; p->d_cg_coef = nullptr; p->cg_slices = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_cg_r), step * n * sizeof(float2)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_cg_v), step * n * sizeof(float2)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_cg_zt), step * N * sizeof(float2)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_cg_pt), step * N * sizeof(float2)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_cg_x), step * N * sizeof(float2)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_cg_partial), (size_t)step * kCgPartials * sizeof(double)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_cg_num), step * sizeof(double)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_cg_coef), step * sizeof(float)));
+        p->cg_slices = step;
+    }
+    const float unscale = (float)d.nxos * (float)d.npe1work;          // F3: the gridding kernel's 1/nxos/npe (src/tron.cu:532) divided out
+    const int golden = p->cfg.golden_angle;
+    hipStream_t st = p->stream;
+    int rc;
+    for (int z0 = 0; z0 < zcount; z0 += step) {
+        const int cz = std::min(step, zcount - z0);
+        const unsigned char *y = static_cast<const unsigned char *>(d_in_z0) + (size_t)z0 * d.prof_slide * spoke_bytes;
+        // r = y: the (overlapping) windows of the stream, one contiguous copy per slice (:685; F5)
+        HIP_TRY(hipMemcpy2DAsync(p->d_cg_r, n * sizeof(float2), y, (size_t)d.prof_slide * spoke_bytes, n * sizeof(float2), cz,
+                                 hipMemcpyDeviceToDevice, st));
+        // ztilde = A^H W r (:686), ptilde = ztilde (:687), x = 0 (:683)
+        if ((rc = adjoint_run(p, p->d_cg_zt, p->d_cg_r, zfirst + z0, cz, 0, d.npe1work))) return rc;
+        HIP_TRY(launch_cg_scale_norm2(p->d_cg_zt, N, cz, unscale, p->d_cg_partial, st));
+        HIP_TRY(launch_cg_finish(p->d_cg_partial, p->d_cg_num, p->d_cg_coef, 0, cz, st));
+        HIP_TRY(hipMemcpyAsync(p->d_cg_pt, p->d_cg_zt, cz * N * sizeof(float2), hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemsetAsync(p->d_cg_x, 0, cz * N * sizeof(float2), st));
+        // the forward operator's angles: the slice's own index range (F4); golden angles are shared with the adjoint's table
+        const float2 *trig = golden ? p->d_trig + (size_t)(zfirst + z0) * d.prof_slide : (p->d_trig_fwd ? p->d_trig_fwd : p->d_trig);
+        const int trig_stride = golden ? d.prof_slide : 0;
+        for (int t = 0; t < p->cfg.niter; ++t) {
+            if ((rc = forward_run(p, p->d_cg_v, p->d_cg_pt, cz, trig, trig_stride, p->d_deapod_fwd))) return rc;   // v = A ptilde (:691)
+            HIP_TRY(launch_cg_wnorm2(p->d_cg_v, n, cz, p->nchan, d.nro, p->dcf_a, p->dcf_b, p->d_cg_partial, st));  // <W v, v> (:693,696)
+            HIP_TRY(launch_cg_finish(p->d_cg_partial, p->d_cg_num, p->d_cg_coef, 1, cz, st));                       // alpha (:697; F1)
+            HIP_TRY(launch_cg_axpy(p->d_cg_x, p->d_cg_pt, p->d_cg_coef, 1.f, N, cz, st));                            // x += alpha ptilde (:699)
+            if (t == p->cfg.niter - 1) break;                                                                       // (:701)
+            HIP_TRY(launch_cg_axpy(p->d_cg_r, p->d_cg_v, p->d_cg_coef, -1.f, n, cz, st));                           // r -= alpha v (:703)
+            if ((rc = adjoint_run(p, p->d_cg_zt, p->d_cg_r, zfirst + z0, cz, 0, d.npe1work))) return rc;            // ztilde = A^H W r (:707)
+            HIP_TRY(launch_cg_scale_norm2(p->d_cg_zt, N, cz, unscale, p->d_cg_partial, st));
+            HIP_TRY(launch_cg_finish(p->d_cg_partial, p->d_cg_num, p->d_cg_coef, 2, cz, st));                       // beta (:709; F1)
+            HIP_TRY(launch_cg_xpby(p->d_cg_pt, p->d_cg_zt, p->d_cg_coef, N, cz, st));                               // ptilde = ztilde + beta ptilde (:710)
+        }
+        if (combine)
+            HIP_TRY(launch_sos(static_cast<float2 *>(d_out) + (size_t)z0 * d.nx * d.ny, p->d_cg_x, (size_t)d.nx * d.ny, p->nchan, cz, st));   // (:764)
+        else
+            HIP_TRY(hipMemcpyAsync(static_cast<float2 *>(d_out) + (size_t)z0 * N, p->d_cg_x, cz * N * sizeof(float2), hipMemcpyDeviceToDevice, st));   // (:713)
     }
     return TRON_OK;
 }
@@ -423,8 +533,8 @@ extern "C" int tron_plan_create(tron_plan **out, const tron_config *cfg, const t
     if (!out || !cfg || !dims) return fail(TRON_ERR_INVALID, "tron_plan_create: null argument");
     *out = nullptr;
     const tron_dims &d = *dims;
-    if (cfg->niter > 0)
-        return fail(TRON_ERR_UNSUPPORTED, "-i %d: the CGNR path is not implemented (the reference marks its own as not working, src/tron.cu:670)", cfg->niter);
+    if (cfg->niter < 0 || (cfg->niter > 0 && cfg->input_half))
+        return fail(TRON_ERR_UNSUPPORTED, "-i %d: CGNR needs niter >= 0 and complex64 k-space", cfg->niter);
     if (d.nt != 1)
         return fail(TRON_ERR_UNSUPPORTED, "nt=%d: only nt=1 is supported (the reference's FFT plans ignore nt, src/tron.cu:599-601)", d.nt);
     if (!(cfg->kernwidth > 0.f) || cfg->kernwidth > 4.f)
@@ -448,6 +558,7 @@ extern "C" int tron_plan_create(tron_plan **out, const tron_config *cfg, const t
     HIP_TRY(warm_grid_binned());
     HIP_TRY(warm_fft512());
     HIP_TRY(warm_degrid_tile());
+    HIP_TRY(warm_cgnr());
     HIP_TRY(hipDeviceSynchronize());
 
     tron_plan *p = new tron_plan();
@@ -500,11 +611,40 @@ extern "C" int tron_plan_create(tron_plan **out, const tron_config *cfg, const t
         p->tiles_per_row = (d.nxos + kTile - 1) / kTile;
         p->ntiles = (int)order.size();
         if ((rc = upload(&p->d_tile_order, order.data(), order.size() * sizeof(int)))) return bail(rc);
-        p->binned = p->kb_mode == TRON_KB_FAST && cfg->kernwidth <= 3.f;
+        p->binned = p->kb_mode == TRON_KB_FAST && cfg->kernwidth <= 3.f && d.nxos <= 2048;   // 10 bits of |r| in a sorted entry
         if (const char *gk = getenv("TRON_GRID_KERNEL")) p->binned = p->binned && strcmp(gk, "gather") != 0;
+        if (p->binned) {
+            std::vector<int> sorder, slots;
+            int target = 2500;                                            // records per workgroup and image
+            if (const char *e = getenv("TRON_SPLIT_TARGET")) target = std::max(64, atoi(e));
+            p->max_parts = 8;
+            build_split_tile_order(d.nxos, kBinnedTile, d.npe1work, cfg->kernwidth, target, p->max_parts, sorder, slots);
+            p->split_entries = (int)sorder.size();
+            p->nsplit_slots = (int)slots.size();
+            p->split_below = 64;                                          // launches of fewer slices use the split list
+            if (const char *e = getenv("TRON_SPLIT_BELOW")) p->split_below = atoi(e);
+            if (p->nsplit_slots > 0) {
+                if ((rc = upload(&p->d_tile_order32_split, sorder.data(), sorder.size() * sizeof(int)))) return bail(rc);
+                if ((rc = upload(&p->d_split_slots, slots.data(), slots.size() * sizeof(int)))) return bail(rc);
+            }
+        }
         std::vector<float> dea((size_t)d.nx * d.nx);
         build_deapod_table(d.nx, cfg->kernwidth, cfg->gridos, dea.data());        // src/tron.cu:635
         if ((rc = upload(&p->d_deapod, dea.data(), dea.size() * sizeof(float)))) return bail(rc);
+        if (cfg->niter > 0) {
+            // CGNR applies the forward operator too (src/tron.cu:691): its deapodisation table and, for linear angles,
+            // the degridding kernel's own angle convention (:555) unless cgnr_consistent asks for the gridding one (:509; Q5)
+            std::vector<float> deaf(n2);
+            build_deapod_table(d.nxos, cfg->kernwidth, 1.f, deaf.data());         // src/tron.cu:643
+            if ((rc = upload(&p->d_deapod_fwd, deaf.data(), deaf.size() * sizeof(float)))) return bail(rc);
+            if (!cfg->golden_angle && !cfg->cgnr_consistent) {
+                tron_config fc = *cfg;
+                fc.adjoint = 0;
+                std::vector<float> tf(2 * (size_t)d.npe1work);
+                build_trig_table(fc, d, tf.data(), (size_t)d.npe1work);
+                if ((rc = upload(&p->d_trig_fwd, tf.data(), tf.size() * sizeof(float)))) return bail(rc);
+            }
+        }
     } else {
         std::vector<float> dea(n2);
         build_deapod_table(d.nxos, cfg->kernwidth, 1.f, dea.data());             // src/tron.cu:643
@@ -568,6 +708,12 @@ extern "C" int tron_plan_create(tron_plan **out, const tron_config *cfg, const t
         printf("tronhip: fast Kaiser-Bessel polynomial max relative error %.2e\n", p->kb_poly_err);
     }
     if (const char *se = getenv("TRON_SYNC_EACH")) p->sync_each = atoi(se) != 0;
+    p->debug_skip = 0;
+    if (const char *dbg = getenv("TRON_DEBUG_SKIP")) p->debug_skip = atoi(dbg);
+    p->degrid_simple = getenv("TRON_DEGRID_SIMPLE") != nullptr;
+    p->no_disc = getenv("TRON_NO_DISC") != nullptr;
+    p->pin_host = cfg->pin_host != 0;
+    if (const char *ph = getenv("TRON_PIN_HOST")) p->pin_host = atoi(ph) != 0;
     *out = p;
     return TRON_OK;
 }
@@ -589,6 +735,13 @@ extern "C" int tron_plan_destroy(tron_plan *p)
     hipFree(p->d_band);
     hipFree(p->d_tile_order);
     hipFree(p->d_tile_order32);
+    hipFree(p->d_deapod_fwd);
+    hipFree(p->d_trig_fwd);
+    hipFree(p->d_cg_r); hipFree(p->d_cg_v); hipFree(p->d_cg_zt); hipFree(p->d_cg_pt); hipFree(p->d_cg_x);
+    hipFree(p->d_cg_partial); hipFree(p->d_cg_num); hipFree(p->d_cg_coef);
+    hipFree(p->d_tile_order32_split);
+    hipFree(p->d_split_slots);
+    hipFree(p->d_partial);
     hipFree(p->d_deapod);
     hipFree(p->d_errflag);
     hipFree(p->d_grid);
@@ -602,6 +755,9 @@ extern "C" int tron_plan_destroy(tron_plan *p)
         if (p->ev_g[i]) hipEventDestroy(p->ev_g[i]);
         if (p->ev_f[i]) hipEventDestroy(p->ev_f[i]);
     }
+    for (hipEvent_t e : p->ev_pipe) hipEventDestroy(e);
+    if (p->stream_up) hipStreamDestroy(p->stream_up);
+    if (p->stream_down) hipStreamDestroy(p->stream_down);
     if (p->stream2) hipStreamDestroy(p->stream2);
     if (p->stream) hipStreamDestroy(p->stream);
     delete p;
@@ -633,6 +789,21 @@ extern "C" int tron_nufft_adj_radial2d(tron_plan *p, void *d_out, const void *d_
     return adjoint_run(p, d_out, in, zfirst, zcount, combine);
 }
 
+extern "C" int tron_cgnr_radial2d(tron_plan *p, void *d_out, const void *d_in, int zfirst, int zcount, int combine)
+{
+    if (!p || !d_out || !d_in) return fail(TRON_ERR_INVALID, "tron_cgnr_radial2d: null argument");
+    if (!p->cfg.adjoint) return fail(TRON_ERR_INVALID, "plan was created for the forward direction");
+    if (p->cfg.niter <= 0) return fail(TRON_ERR_INVALID, "plan was created with niter = 0");
+    const tron_dims &d = p->d;
+    if (zfirst < 0 || zcount < 0 || zfirst + zcount > d.nz)
+        return fail(TRON_ERR_INVALID, "slice range [%d,%d) outside [0,%d)", zfirst, zfirst + zcount, d.nz);
+    if (zcount > 0 && (long long)(zfirst + zcount - 1) * d.prof_slide + d.npe1work > (long long)d.npe1 * d.npe2)
+        return fail(TRON_ERR_INVALID, "slice %d would read past the spoke stream", zfirst + zcount - 1);
+    HIP_TRY(hipSetDevice(p->cfg.device));
+    const unsigned char *in = static_cast<const unsigned char *>(d_in) + (size_t)zfirst * d.prof_slide * d.nro * p->nchan * sizeof(float2);
+    return cgnr_run(p, d_out, in, zfirst, zcount, combine);
+}
+
 extern "C" int tron_nufft_radial2d(tron_plan *p, void *d_out, const void *d_in, int nimg)
 {
     if (!p || !d_out || !d_in) return fail(TRON_ERR_INVALID, "tron_nufft_radial2d: null argument");
@@ -640,6 +811,82 @@ extern "C" int tron_nufft_radial2d(tron_plan *p, void *d_out, const void *d_in, 
     if (nimg < 0) return fail(TRON_ERR_INVALID, "nimg < 0");
     HIP_TRY(hipSetDevice(p->cfg.device));
     return forward_run(p, d_out, d_in, nimg);
+}
+
+// Adjoint of slices [zfirst, zfirst+zcount) from host memory: h_in_block points at the first spoke of slice zfirst's
+// window, h_out_block at that slice's image.
+static int adjoint_block(tron_plan *p, tron_float2 *h_out_block, const void *h_in_block, int zfirst, int zcount)
+{
+    const tron_dims &d = p->d;
+    const size_t elem = p->cfg.input_half ? 4 : 8;
+    int rc;
+    // Every spoke the range touches is uploaded ONCE; windows are views (src/tron.cu:738-748).  The range is cut
+    // into chunks of p->chunk slices and run as a three-lane pipeline -- upload(k+1) || kernels(k) || download(k-1)
+    // on three streams chained by events -- where the reference alternates two streams per slice and re-uploads
+    // every window (src/tron.cu:732-783).  Chunk k+1 uploads only the spokes chunk k did not.
+    size_t spoke_bytes = 0, nspokes = 0, in_bytes = 0, out_elems = 0, out_bytes = 0;
+    if (__builtin_mul_overflow((size_t)d.nro * elem, (size_t)p->nchan, &spoke_bytes) ||
+        __builtin_mul_overflow((size_t)(zcount - 1), (size_t)d.prof_slide, &nspokes) ||
+        __builtin_add_overflow(nspokes, (size_t)d.npe1work, &nspokes) ||
+        __builtin_mul_overflow(nspokes, spoke_bytes, &in_bytes) ||
+        __builtin_mul_overflow((size_t)zcount * d.nt, (size_t)d.nx * d.ny, &out_elems) ||
+        __builtin_mul_overflow(out_elems, sizeof(float2), &out_bytes))
+        return fail(TRON_ERR_INVALID, "slice range [%d,%d): staging size overflows", zfirst, zfirst + zcount);
+    if ((rc = ensure_buffer(&p->d_stage_in, &p->stage_in_bytes, in_bytes))) return rc;
+    if ((rc = ensure_buffer(&p->d_stage_out, &p->stage_out_bytes, out_bytes))) return rc;
+    if (!p->stream_up) HIP_TRY(hipStreamCreateWithFlags(&p->stream_up, hipStreamNonBlocking));
+    if (!p->stream_down) HIP_TRY(hipStreamCreateWithFlags(&p->stream_down, hipStreamNonBlocking));
+    const unsigned char *src = reinterpret_cast<const unsigned char *>(h_in_block);
+    tron_float2 *dst = h_out_block;
+    // Pinning the caller's buffers makes the copies truly asynchronous (and the two directions concurrent); it
+    // costs a page walk of the whole range, so it is opt-in (cfg.pin_host / TRON_PIN_HOST=1): pageable copies are
+    // staged by the runtime at the same PCIe rate and still overlap the kernels of the previous chunk.
+    bool pinned_in = false, pinned_out = false;
+    if (p->pin_host) {
+        pinned_in = hipHostRegister(const_cast<unsigned char *>(src), in_bytes, hipHostRegisterDefault) == hipSuccess;
+        pinned_out = hipHostRegister(dst, out_bytes, hipHostRegisterDefault) == hipSuccess;
+        (void)hipGetLastError();
+    }
+    const int step = std::max(1, std::min(p->chunk, zcount));
+    const int nchunks = (zcount + step - 1) / step;
+    while ((int)p->ev_pipe.size() < 2 * nchunks) {
+        hipEvent_t e = nullptr;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        p->ev_pipe.push_back(e);
+    }
+    const size_t img_elems = (size_t)d.nt * d.nx * d.ny;
+    size_t uploaded = 0;                                          // spokes of the range already on the device
+    rc = TRON_OK;
+    hipError_t he = hipSuccess;
+    for (int k = 0; k < nchunks && rc == TRON_OK && he == hipSuccess; ++k) {
+        const int z0 = k * step, cz = std::min(step, zcount - z0);
+        const size_t need = (size_t)(z0 + cz - 1) * d.prof_slide + d.npe1work;
+        if (need > uploaded) {
+            he = hipMemcpyAsync(static_cast<unsigned char *>(p->d_stage_in) + uploaded * spoke_bytes, src + uploaded * spoke_bytes,
+                                (need - uploaded) * spoke_bytes, hipMemcpyHostToDevice, p->stream_up);
+            uploaded = need;
+        }
+        if (he == hipSuccess) he = hipEventRecord(p->ev_pipe[2 * k], p->stream_up);
+        if (he == hipSuccess) he = hipStreamWaitEvent(p->stream, p->ev_pipe[2 * k], 0);
+        if (he != hipSuccess) break;
+        rc = (p->cfg.niter > 0 ? cgnr_run : [](tron_plan *pp, void *o, const void *i, int zf, int zc, int cb) { return adjoint_run(pp, o, i, zf, zc, cb); })
+                (p, static_cast<float2 *>(p->d_stage_out) + (size_t)z0 * img_elems,
+                 static_cast<const unsigned char *>(p->d_stage_in) + (size_t)z0 * d.prof_slide * spoke_bytes,
+                 zfirst + z0, cz, 1);                             // niter > 0: src/tron.cu:754-755; + coilcombinesos, :764
+        if (rc != TRON_OK) break;
+        he = hipEventRecord(p->ev_pipe[2 * k + 1], p->stream);
+        if (he == hipSuccess) he = hipStreamWaitEvent(p->stream_down, p->ev_pipe[2 * k + 1], 0);
+        if (he == hipSuccess)
+            he = hipMemcpyAsync(dst + (size_t)z0 * img_elems, static_cast<float2 *>(p->d_stage_out) + (size_t)z0 * img_elems,
+                                (size_t)cz * img_elems * sizeof(float2), hipMemcpyDeviceToHost, p->stream_down);
+    }
+    hipError_t s1 = hipStreamSynchronize(p->stream_up), s2 = hipStreamSynchronize(p->stream), s3 = hipStreamSynchronize(p->stream_down);
+    if (pinned_in) hipHostUnregister(const_cast<unsigned char *>(src));
+    if (pinned_out) hipHostUnregister(dst);
+    if (rc != TRON_OK) return rc;
+    for (hipError_t e : {he, s1, s2, s3})
+        if (e != hipSuccess) return fail(TRON_ERR_HIP, "host-buffer pipeline failed: %s", hipGetErrorString(e));
+    return tron_plan_sync(p);
 }
 
 extern "C" int tron_recon_radial2d_range(tron_plan *p, tron_float2 *h_out, const tron_float2 *h_in, int zfirst, int zcount)
@@ -657,19 +904,9 @@ extern "C" int tron_recon_radial2d_range(tron_plan *p, tron_float2 *h_out, const
         if (last > (long long)d.npe1 * d.npe2)
             return fail(TRON_ERR_INVALID, "slice %d would read spokes up to %lld but the input holds %lld (the reference reads out of bounds here)",
                         zfirst + zcount - 1, last, (long long)d.npe1 * d.npe2);
-        // one upload of every spoke the range touches; windows are views (src/tron.cu:738-748)
         const size_t spoke_bytes = (size_t)d.nro * p->nchan * elem;
-        const size_t first_spoke = (size_t)zfirst * d.prof_slide;
-        const size_t nspokes = (size_t)(zcount - 1) * d.prof_slide + d.npe1work;
-        if ((rc = ensure_buffer(&p->d_stage_in, &p->stage_in_bytes, nspokes * spoke_bytes))) return rc;
-        const size_t out_elems = (size_t)zcount * d.nt * d.nx * d.ny;
-        if ((rc = ensure_buffer(&p->d_stage_out, &p->stage_out_bytes, out_elems * sizeof(float2)))) return rc;
-        HIP_TRY(hipMemcpyAsync(p->d_stage_in, reinterpret_cast<const unsigned char *>(h_in) + first_spoke * spoke_bytes,
-                               nspokes * spoke_bytes, hipMemcpyHostToDevice, p->stream));
-        if ((rc = adjoint_run(p, p->d_stage_out, p->d_stage_in, zfirst, zcount, 1))) return rc;   // + coilcombinesos, src/tron.cu:764
-        HIP_TRY(hipMemcpyAsync(h_out + (size_t)d.nt * d.nx * d.ny * zfirst, p->d_stage_out, out_elems * sizeof(float2),
-                               hipMemcpyDeviceToHost, p->stream));                               // img_offset, src/tron.cu:740,768
-        return tron_plan_sync(p);
+        return adjoint_block(p, h_out + (size_t)d.nt * d.nx * d.ny * zfirst,                     // img_offset, src/tron.cu:740,768
+                             reinterpret_cast<const unsigned char *>(h_in) + (size_t)zfirst * d.prof_slide * spoke_bytes, zfirst, zcount);
     }
     // forward: every z reads h_in + nc*nt*nro*(z*prof_slide) (src/tron.cu:738-739,750) -- with the
     // default prof_slide that is slice 0 for every z -- and writes block z (src/tron.cu:776)
@@ -694,6 +931,76 @@ extern "C" int tron_recon_radial2d(tron_plan *p, tron_float2 *h_out, const tron_
 {
     if (!p) return fail(TRON_ERR_INVALID, "tron_recon_radial2d: null plan");
     return tron_recon_radial2d_range(p, h_out, h_in, 0, p->d.nz);
+}
+
+extern "C" int tron_recon_radial2d_block(tron_plan *p, tron_float2 *h_out_block, const void *h_in_block, int zfirst, int zcount)
+{
+    if (!p || !h_out_block || !h_in_block) return fail(TRON_ERR_INVALID, "tron_recon_radial2d_block: null argument");
+    if (!p->cfg.adjoint) return fail(TRON_ERR_UNSUPPORTED, "tron_recon_radial2d_block: defined for the adjoint (one forward run is one image)");
+    const tron_dims &d = p->d;
+    if (zfirst < 0 || zcount < 0 || zfirst + zcount > d.nz)
+        return fail(TRON_ERR_INVALID, "slice range [%d,%d) outside [0,%d)", zfirst, zfirst + zcount, d.nz);
+    if (zcount == 0) return TRON_OK;
+    if ((long long)(zfirst + zcount - 1) * d.prof_slide + d.npe1work > (long long)d.npe1 * d.npe2)
+        return fail(TRON_ERR_INVALID, "slice %d would read past the spoke stream", zfirst + zcount - 1);
+    HIP_TRY(hipSetDevice(p->cfg.device));
+    return adjoint_block(p, h_out_block, h_in_block, zfirst, zcount);
+}
+
+// One host worker thread and one plan per device, contiguous slice blocks written straight into the caller's output:
+// the reference's compiled-out MULTI_GPU round-robin (src/tron.cu:582-597,735-736) made contiguous; no inter-GPU traffic.
+extern "C" int tron_recon_radial2d_multi(const tron_config *cfg, const tron_dims *dims, const int *devices, int n_devices,
+                                         tron_float2 *h_out, const tron_float2 *h_in)
+{
+    if (!cfg || !dims || !h_out || !h_in) return fail(TRON_ERR_INVALID, "tron_recon_radial2d_multi: null argument");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (n_devices <= 0) n_devices = ndev;
+    if (n_devices < 1) return fail(TRON_ERR_HIP, "no HIP device");
+    std::vector<int> devs(n_devices);
+    for (int g = 0; g < n_devices; ++g) {
+        devs[g] = devices ? devices[g] : g;
+        if (devs[g] < 0 || devs[g] >= ndev) return fail(TRON_ERR_HIP, "device %d requested but %d HIP device(s) present", devs[g], ndev);
+    }
+    const int nz = dims->nz;
+    const int workers = (cfg->adjoint && nz > 1) ? std::min(n_devices, nz) : 1;   // a forward run is one image
+    std::vector<int> rcs(workers, TRON_OK);
+    std::vector<std::string> msgs(workers);
+    // the workers' slice blocks share spokes (windows overlap) and pages: pin both buffers ONCE, visible to every device
+    bool pinned_in = false, pinned_out = false;
+    const size_t in_bytes = (size_t)dims->in_elems * (cfg->input_half ? 4 : 8);
+    if (cfg->pin_host && workers > 1) {
+        HIP_TRY(hipSetDevice(devs[0]));
+        pinned_in = hipHostRegister(const_cast<tron_float2 *>(h_in), in_bytes, hipHostRegisterPortable) == hipSuccess;
+        pinned_out = hipHostRegister(h_out, (size_t)dims->out_bytes, hipHostRegisterPortable) == hipSuccess;
+        (void)hipGetLastError();
+    }
+    auto work = [&](int g) {
+        tron_config c = *cfg;
+        c.device = devs[g];
+        if (workers > 1) c.pin_host = 0;
+        tron_plan *plan = nullptr;
+        int rc = tron_plan_create(&plan, &c, dims);
+        if (rc == TRON_OK) {
+            const int z0 = (int)((long long)g * nz / workers), z1 = (int)((long long)(g + 1) * nz / workers);
+            rc = tron_recon_radial2d_range(plan, h_out, h_in, z0, z1 - z0);
+        }
+        if (rc != TRON_OK) msgs[g] = tron_last_error();          // the message lives in this worker's thread-local slot
+        tron_plan_destroy(plan);
+        rcs[g] = rc;
+    };
+    if (workers == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> th;
+        for (int g = 0; g < workers; ++g) th.emplace_back(work, g);
+        for (auto &t : th) t.join();
+    }
+    if (pinned_in) hipHostUnregister(const_cast<tron_float2 *>(h_in));
+    if (pinned_out) hipHostUnregister(h_out);
+    for (int g = 0; g < workers; ++g)
+        if (rcs[g] != TRON_OK) return fail(rcs[g], "device worker %d (HIP device %d): %s", g, devs[g], msgs[g].c_str());
+    return TRON_OK;
 }
 
 extern "C" int tron_precompensate(tron_plan *p, void *d_nudata)
@@ -765,7 +1072,7 @@ extern "C" int tron_degridradial2d(tron_plan *p, void *d_nudata, const void *d_u
     g.beta = p->beta;
     memcpy(g.kb_poly, p->kb_poly, sizeof(g.kb_poly));
     StageTimer t(p, STAGE_DEGRID);
-    if (p->cfg.kernwidth <= 3.f && !getenv("TRON_DEGRID_SIMPLE"))
+    if (p->cfg.kernwidth <= 3.f && !p->degrid_simple)
         HIP_TRY(launch_degrid_tile(g, p->kb_mode, p->stream));
     else
         HIP_TRY(launch_degrid(g, p->kb_mode, p->stream));

@@ -41,21 +41,35 @@ def spawn_ranks(argv, world: int, timeout=None):
     for r in range(world):
         procs.append(subprocess.Popen([sys.executable] + list(argv), env=rank_env(r, world, port),
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, code = "", 0
+    import threading
+    import time
+    out0_parts = []
+    reader = threading.Thread(target=lambda: out0_parts.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    code = 0
+    deadline = None if timeout is None else time.monotonic() + timeout
     try:
-        out0, _ = procs[0].communicate(timeout=timeout)
-        for p in procs:
-            rc = p.wait(timeout=timeout)
-            if rc != 0 and code == 0:
-                code = rc
-    except subprocess.TimeoutExpired:
-        code = 124
+        # a rank that dies before the rendezvous would leave the others waiting for it (gloo's own timeout is 30 min):
+        # watch all of them and end the run as soon as one fails
+        while True:
+            states = [p.poll() for p in procs]
+            bad = [rc for rc in states if rc not in (None, 0)]
+            if bad:
+                code = bad[0]
+                break
+            if all(rc == 0 for rc in states):
+                break
+            if deadline is not None and time.monotonic() > deadline:
+                code = 124
+                break
+            time.sleep(0.05)
     finally:
         for p in procs:          # exact PIDs we started, nothing else
             if p.poll() is None:
                 p.kill()
-                p.wait()
-    return code, out0
+            p.wait()
+    reader.join(timeout=10)
+    return code, (out0_parts[0] if out0_parts else "")
 
 
 class HostGroup:

@@ -33,6 +33,7 @@ class Config(ctypes.Structure):
         ("prof_slide", ctypes.c_int), ("skip_angles", ctypes.c_int), ("niter", ctypes.c_int),
         ("blocks", ctypes.c_int), ("threads", ctypes.c_int), ("device", ctypes.c_int),
         ("kb_mode", ctypes.c_int), ("input_half", ctypes.c_int), ("chunk_slices", ctypes.c_int),
+        ("pin_host", ctypes.c_int), ("cgnr_consistent", ctypes.c_int),
     ]
 
 
@@ -51,7 +52,7 @@ class Dims(ctypes.Structure):
 # every symbol include/tron_hip.h and include/rawarray.h declare
 EXPORTS = [
     "tron_config_default", "tron_derive_dims", "tron_plan_create", "tron_plan_destroy",
-    "tron_recon_radial2d", "tron_recon_radial2d_range", "tron_nufft_adj_radial2d", "tron_nufft_radial2d",
+    "tron_recon_radial2d", "tron_recon_radial2d_range", "tron_recon_radial2d_block", "tron_recon_radial2d_multi", "tron_nufft_adj_radial2d", "tron_cgnr_radial2d", "tron_nufft_radial2d",
     "tron_precompensate", "tron_gridradial2d", "tron_degridradial2d", "tron_plan_sync",
     "tron_plan_timing", "tron_plan_timing_get", "tron_plan_timing_reset",
     "tron_host_trig_table", "tron_host_band_table", "tron_host_deapod_table",
@@ -74,35 +75,47 @@ def load():
     L = ctypes.CDLL(LIB_PATH)
     i, f, p, sz = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
     pc, pd = ctypes.POINTER(Config), ctypes.POINTER(Dims)
-    L.tron_config_default.restype = None; L.tron_config_default.argtypes = [pc]
-    L.tron_derive_dims.restype = i; L.tron_derive_dims.argtypes = [pc, ctypes.POINTER(ctypes.c_uint64), pd]
-    L.tron_plan_create.restype = i; L.tron_plan_create.argtypes = [ctypes.POINTER(p), pc, pd]
-    L.tron_plan_destroy.restype = i; L.tron_plan_destroy.argtypes = [p]
-    L.tron_recon_radial2d.restype = i; L.tron_recon_radial2d.argtypes = [p, p, p]
-    L.tron_recon_radial2d_range.restype = i; L.tron_recon_radial2d_range.argtypes = [p, p, p, i, i]
-    L.tron_nufft_adj_radial2d.restype = i; L.tron_nufft_adj_radial2d.argtypes = [p, p, p, i, i, i]
-    L.tron_nufft_radial2d.restype = i; L.tron_nufft_radial2d.argtypes = [p, p, p, i]
-    L.tron_precompensate.restype = i; L.tron_precompensate.argtypes = [p, p]
-    L.tron_gridradial2d.restype = i; L.tron_gridradial2d.argtypes = [p, p, p, i]
-    L.tron_degridradial2d.restype = i; L.tron_degridradial2d.argtypes = [p, p, p]
-    L.tron_plan_sync.restype = i; L.tron_plan_sync.argtypes = [p]
-    L.tron_plan_timing.restype = i; L.tron_plan_timing.argtypes = [p, i]
-    L.tron_plan_timing_get.restype = i; L.tron_plan_timing_get.argtypes = [p, i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]
-    L.tron_plan_timing_reset.restype = i; L.tron_plan_timing_reset.argtypes = [p]
-    L.tron_host_trig_table.restype = i; L.tron_host_trig_table.argtypes = [pc, pd, p, sz]
-    L.tron_host_band_table.restype = i; L.tron_host_band_table.argtypes = [i, f, p]
-    L.tron_host_deapod_table.restype = i; L.tron_host_deapod_table.argtypes = [i, f, f, p]
-    L.tron_device_count.restype = i; L.tron_device_count.argtypes = [ctypes.POINTER(i)]
-    L.tron_device_malloc.restype = i; L.tron_device_malloc.argtypes = [ctypes.POINTER(p), sz]
-    L.tron_device_free.restype = i; L.tron_device_free.argtypes = [p]
-    L.tron_memcpy_h2d.restype = i; L.tron_memcpy_h2d.argtypes = [p, p, sz]
-    L.tron_memcpy_d2h.restype = i; L.tron_memcpy_d2h.argtypes = [p, p, sz]
-    L.tron_last_error.restype = ctypes.c_char_p; L.tron_last_error.argtypes = []
-    L.tron_version.restype = ctypes.c_char_p; L.tron_version.argtypes = []
-    L.ra_float_to_half_bits.restype = ctypes.c_uint16; L.ra_float_to_half_bits.argtypes = [ctypes.c_uint32]
-    L.ra_half_to_float_bits.restype = ctypes.c_uint32; L.ra_half_to_float_bits.argtypes = [ctypes.c_uint16]
-    L.ra_double_to_half_bits.restype = ctypes.c_uint16; L.ra_double_to_half_bits.argtypes = [ctypes.c_uint64]
-    L.ra_half_to_double_bits.restype = ctypes.c_uint64; L.ra_half_to_double_bits.argtypes = [ctypes.c_uint16]
+
+    def sig(name, restype, argtypes):
+        # a symbol missing from an OLDER build (tools/ab.sh A/B runs) is simply not bound; build() checks EXPORTS
+        try:
+            fn = getattr(L, name)
+        except AttributeError:
+            return
+        fn.restype, fn.argtypes = restype, argtypes
+
+    sig("tron_config_default", None, [pc])
+    sig("tron_derive_dims", i, [pc, ctypes.POINTER(ctypes.c_uint64), pd])
+    sig("tron_plan_create", i, [ctypes.POINTER(p), pc, pd])
+    sig("tron_plan_destroy", i, [p])
+    sig("tron_recon_radial2d", i, [p, p, p])
+    sig("tron_recon_radial2d_range", i, [p, p, p, i, i])
+    sig("tron_recon_radial2d_block", i, [p, p, p, i, i])
+    sig("tron_recon_radial2d_multi", i, [pc, pd, ctypes.POINTER(i), i, p, p])
+    sig("tron_nufft_adj_radial2d", i, [p, p, p, i, i, i])
+    sig("tron_cgnr_radial2d", i, [p, p, p, i, i, i])
+    sig("tron_nufft_radial2d", i, [p, p, p, i])
+    sig("tron_precompensate", i, [p, p])
+    sig("tron_gridradial2d", i, [p, p, p, i])
+    sig("tron_degridradial2d", i, [p, p, p])
+    sig("tron_plan_sync", i, [p])
+    sig("tron_plan_timing", i, [p, i])
+    sig("tron_plan_timing_get", i, [p, i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)])
+    sig("tron_plan_timing_reset", i, [p])
+    sig("tron_host_trig_table", i, [pc, pd, p, sz])
+    sig("tron_host_band_table", i, [i, f, p])
+    sig("tron_host_deapod_table", i, [i, f, f, p])
+    sig("tron_device_count", i, [ctypes.POINTER(i)])
+    sig("tron_device_malloc", i, [ctypes.POINTER(p), sz])
+    sig("tron_device_free", i, [p])
+    sig("tron_memcpy_h2d", i, [p, p, sz])
+    sig("tron_memcpy_d2h", i, [p, p, sz])
+    sig("tron_last_error", ctypes.c_char_p, [])
+    sig("tron_version", ctypes.c_char_p, [])
+    sig("ra_float_to_half_bits", ctypes.c_uint16, [ctypes.c_uint32])
+    sig("ra_half_to_float_bits", ctypes.c_uint32, [ctypes.c_uint16])
+    sig("ra_double_to_half_bits", ctypes.c_uint16, [ctypes.c_uint64])
+    sig("ra_half_to_double_bits", ctypes.c_uint64, [ctypes.c_uint16])
     _lib = L
     return L
 
@@ -204,12 +217,40 @@ class Plan:
             out = np.zeros(d.out_bytes // 8, np.complex64)
         if zcount is None:
             zcount = d.nz
+        # the C side can only validate against its own dims: a short or strided array would be read past its end
+        elem = 4 if self.cfg.input_half else 8
+        if not (isinstance(flat_in, np.ndarray) and (flat_in.flags.c_contiguous or flat_in.flags.f_contiguous)):
+            raise ValueError("Plan.recon: input must be a contiguous numpy array")
+        if flat_in.nbytes < d.in_elems * elem:
+            raise ValueError(f"Plan.recon: input holds {flat_in.nbytes} bytes, the plan's dims need {d.in_elems * elem}")
+        if self.cfg.input_half and flat_in.dtype != np.float16:
+            raise ValueError("Plan.recon: input_half plans take float16 (re, im) pairs")
+        if not self.cfg.input_half and flat_in.dtype not in (np.dtype(np.complex64), np.dtype(np.float32)):
+            raise ValueError(f"Plan.recon: expected complex64 input, got {flat_in.dtype}")
+        if not (out.flags.c_contiguous or out.flags.f_contiguous) or out.dtype != np.complex64 or out.nbytes < d.out_bytes:
+            raise ValueError(f"Plan.recon: output must be contiguous complex64 of at least {d.out_bytes} bytes")
         check(load().tron_recon_radial2d_range(self._h, out.ctypes.data_as(ctypes.c_void_p),
                                                flat_in.ctypes.data_as(ctypes.c_void_p), int(zfirst), int(zcount)))
         return out
 
+    def recon_block(self, block_in: np.ndarray, zfirst: int, zcount: int) -> np.ndarray:
+        """Adjoint of slices [zfirst, zfirst+zcount) from a buffer that holds ONLY their spokes (block_in[0] = spoke
+        zfirst*prof_slide of the stream); returns the zcount images (= tron_recon_radial2d_block)."""
+        d = self.dims
+        elem = 4 if self.cfg.input_half else 8
+        need = ((zcount - 1) * d.prof_slide + d.npe1work) * d.nro * d.nc * d.nt * elem if zcount > 0 else 0
+        if not (block_in.flags.c_contiguous or block_in.flags.f_contiguous) or block_in.nbytes < need:
+            raise ValueError(f"Plan.recon_block: input must be contiguous and hold {need} bytes, has {block_in.nbytes}")
+        out = np.zeros(zcount * d.nt * d.nx * d.ny, np.complex64)
+        check(load().tron_recon_radial2d_block(self._h, out.ctypes.data_as(ctypes.c_void_p),
+                                               block_in.ctypes.data_as(ctypes.c_void_p), int(zfirst), int(zcount)))
+        return out
+
     def adjoint_device(self, d_out, d_in, zfirst, zcount, combine=1):
         check(load().tron_nufft_adj_radial2d(self._h, d_out, d_in, int(zfirst), int(zcount), int(combine)))
+
+    def cgnr_device(self, d_out, d_in, zfirst, zcount, combine=1):
+        check(load().tron_cgnr_radial2d(self._h, d_out, d_in, int(zfirst), int(zcount), int(combine)))
 
     def forward_device(self, d_out, d_in, nimg):
         check(load().tron_nufft_radial2d(self._h, d_out, d_in, int(nimg)))
@@ -236,6 +277,23 @@ class Plan:
         ms, n = ctypes.c_double(0), ctypes.c_uint64(0)
         check(load().tron_plan_timing_get(self._h, int(stage), ctypes.byref(ms), ctypes.byref(n)))
         return ms.value, n.value
+
+
+def recon_multi(data: np.ndarray, adjoint: bool, devices=None, n_devices=0, **flags):
+    """``recon`` over several GPUs inside this process (= tron_recon_radial2d_multi): one worker thread + plan per device."""
+    data = np.asfortranarray(data, dtype=np.complex64)
+    flat = data.reshape(-1, order="F")
+    cfg = default_config(adjoint=int(adjoint), **flags)
+    dims = derive_dims(cfg, data.shape)
+    out = np.zeros(dims.out_bytes // 8, np.complex64)
+    devs = None
+    if devices is not None:
+        n_devices = len(devices)
+        devs = (ctypes.c_int * n_devices)(*[int(x) for x in devices])
+    check(load().tron_recon_radial2d_multi(ctypes.byref(cfg), ctypes.byref(dims), devs, int(n_devices),
+                                           out.ctypes.data_as(ctypes.c_void_p), flat.ctypes.data_as(ctypes.c_void_p)))
+    oshape = tuple(int(x) for x in dims.out_dims) if adjoint else (dims.nc,) + tuple(int(x) for x in dims.out_dims)[1:]
+    return out.reshape(oshape, order="F"), dims
 
 
 def recon(data: np.ndarray, adjoint: bool, **flags):
