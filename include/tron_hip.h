@@ -78,6 +78,9 @@ typedef struct tron_config {
     int   cgnr_consistent; /* CGNR with linear angles: 0 = each operator keeps the reference's own convention (grid
                               src/tron.cu:509, degrid :555 -- not a matched pair), 1 = the forward operator
                               inside the iteration uses the gridding convention.  Golden angle: no effect */
+    int   coil_combine;    /* adjoint: 0 = coilcombinesos, root-sum-of-squares (src/tron.cu:255-268,764; default);
+                              1 = coilcombinewalsh, adaptive combination (src/tron.cu:222-302; call site commented out at :766) */
+    int   walsh_patch;     /* coilcombinewalsh's npatch (src/tron.cu:272: "0 works, 1 good, 3 better", :766); default 1 */
 } tron_config;
 
 /* Everything main() derives from the input header and the flags (src/tron.cu:76-79,

@@ -67,6 +67,7 @@ def lib():
         L.oracle_nufft_radial2d.restype = None; L.oracle_nufft_radial2d.argtypes = [ctypes.POINTER(OracleParams), p, p]
         L.oracle_recon_radial2d.restype = i; L.oracle_recon_radial2d.argtypes = [ctypes.POINTER(OracleParams), p, p, i, i]
         L.oracle_recon_cgnr.restype = i; L.oracle_recon_cgnr.argtypes = [ctypes.POINTER(OracleParams), p, p, i, i, i, i]
+        L.oracle_recon_combine.restype = i; L.oracle_recon_combine.argtypes = [ctypes.POINTER(OracleParams), p, p, i, i, i, i]
         L.oracle_params_size.restype = ctypes.c_size_t
         assert L.oracle_params_size() == ctypes.sizeof(OracleParams)
         _lib = L
@@ -212,6 +213,21 @@ def recon(data, adjoint, zfirst=0, zcount=None, **flags):
     else:
         shape = (p.nc,) + tuple(int(d) for d in p.out_dims)[1:]
     return flat_out.reshape(shape, order="F"), p
+
+
+def recon_combine(data, mode=0, npatch=1, zfirst=0, zcount=None, **flags):
+    """``tron -a`` with the coil combination chosen: mode 0 = root-sum-of-squares per repetition (tron.cu:255-268 applied
+    to each of the nt repetitions), 1 = Walsh adaptive combine (tron.cu:222-302).  Handles nt > 1."""
+    data = np.asfortranarray(data, dtype=np.complex64)
+    p = make_params(data.shape, 1, **flags)
+    flat_in = data.reshape(-1, order="F")
+    flat_out = np.zeros(p.out_bytes // 8, np.complex64)
+    if zcount is None:
+        zcount = p.nz
+    rc = lib().oracle_recon_combine(ctypes.byref(p), _ptr(flat_out), _ptr(flat_in), int(zfirst), int(zcount), int(mode), int(npatch))
+    if rc != 0:
+        raise ValueError(f"oracle_recon_combine failed rc={rc}")
+    return flat_out.reshape(tuple(int(d) for d in p.out_dims), order="F"), p
 
 
 def recon_cgnr(data, niter, consistent=0, zfirst=0, zcount=None, **flags):

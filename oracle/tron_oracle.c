@@ -572,6 +572,116 @@ int oracle_recon_radial2d(const oracle_params *p, cfloat *h_out, const cfloat *h
     return rc;
 }
 
+/* ------------------------------------------------------------------ adaptive coil combination (tron.cu:222-302)
+ *
+ * coilcombinewalsh + powit, whose call site is commented out in the reference (:766, "0 works, 1 good, 3 better").
+ * Restated with float2math.h's operators (complex product :36-40, conj :52, division by a real as multiplication by
+ * 1.0f/s :24-28).  Deviations that make undefined behaviour defined: the covariance matrix has nchan*nchan entries and
+ * all of them are cleared (the reference sizes it MAXCHAN*MAXCHAN = 36 and clears NCHAN*NCHAN, tron.h:50-51, :272,282),
+ * and `nt` repetitions are combined one by one, coil c of repetition t being channel c + nc*t (the reference's kernel
+ * takes nt and never uses it). */
+static cfloat cmulf(cfloat a, cfloat b) { cfloat r = { a.x*b.x - a.y*b.y, a.x*b.y + a.y*b.x }; return r; }
+
+static void oracle_powit(cfloat *A, const int n, const int niters)            /* tron.cu:222-253 */
+{
+    cfloat *x = (cfloat*)malloc(sizeof(cfloat)*(size_t)n), *y = (cfloat*)malloc(sizeof(cfloat)*(size_t)n);
+    for (int k = 0; k < n; ++k) { x[k].x = 1.f; x[k].y = 0.f; }
+    for (int t = 0; t < niters; ++t) {
+        for (int j = 0; j < n; ++j) {
+            y[j].x = 0.f; y[j].y = 0.f;
+            for (int k = 0; k < n; ++k) { cfloat m = cmulf(A[j*n + k], x[k]); y[j].x += m.x; y[j].y += m.y; }
+        }
+        float norm_sq = 0.f;
+        for (int k = 0; k < n; ++k) norm_sq += y[k].x*y[k].x + y[k].y*y[k].y;
+        norm_sq = sqrtf(norm_sq);
+        for (int k = 0; k < n; ++k) { float inv = 1.0f / norm_sq; x[k].x = y[k].x * inv; x[k].y = y[k].y * inv; }
+    }
+    for (int j = 0; j < n; ++j) A[j] = x[j];      /* the eigenvalue the reference also stores (A[n]) is never read */
+    free(x); free(y);
+}
+
+/* coilimg: [nimg*nimg][nchan_total] with channel c + nc*t; img: [nimg*nimg][nt] (.ra dims [1, nt, nx, ny]) */
+void oracle_coilcombinewalsh(cfloat *img, const cfloat *coilimg, const int nimg, const int nc, const int nt, const int npatch)
+{
+    const int nchan = nc * nt;
+#ifdef _OPENMP
+#pragma omp parallel
+#endif
+    {
+        cfloat *A = (cfloat*)malloc(sizeof(cfloat)*(size_t)nc*nc);
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
+        for (int id = 0; id < nimg*nimg; ++id)
+            for (int t = 0; t < nt; ++t) {
+                const cfloat *ci = coilimg + (size_t)nc*t;
+                if (nc == 1) { img[(size_t)nt*id + t] = ci[(size_t)nchan*id]; continue; }
+                int x = id / nimg;
+                int y = id % nimg;
+                for (int k = 0; k < nc*nc; ++k) { A[k].x = 0.f; A[k].y = 0.f; }
+                int px0 = x - npatch > 0 ? x - npatch : 0, px1 = x + npatch < nimg - 1 ? x + npatch : nimg - 1;
+                int py0 = y - npatch > 0 ? y - npatch : 0, py1 = y + npatch < nimg - 1 ? y + npatch : nimg - 1;
+                for (int px = px0; px <= px1; ++px)
+                    for (int py = py0; py <= py1; ++py) {
+                        size_t offset = (size_t)nchan*((size_t)px*nimg + py);
+                        for (int c2 = 0; c2 < nc; ++c2)
+                            for (int c1 = 0; c1 < nc; ++c1) {
+                                cfloat b = { ci[offset+c2].x, -ci[offset+c2].y };
+                                cfloat m = cmulf(ci[offset+c1], b);
+                                A[c1*nc + c2].x += m.x; A[c1*nc + c2].y += m.y;
+                            }
+                    }
+                oracle_powit(A, nc, 5);
+                cfloat acc = { 0.f, 0.f };
+                for (int c = 0; c < nc; ++c) {
+                    cfloat a = { A[c].x, -A[c].y };
+                    cfloat m = cmulf(a, ci[(size_t)nchan*id + c]);
+                    acc.x += m.x; acc.y += m.y;
+                }
+                img[(size_t)nt*id + t] = acc;
+            }
+        free(A);
+    }
+}
+
+/* root-sum-of-squares per repetition: coilcombinesos (tron.cu:255-268) applied to the nc coils of repetition t */
+void oracle_coilcombinesos_nt(cfloat *img, const cfloat *coilimg, const int nimg, const int nc, const int nt)
+{
+    const int nchan = nc * nt;
+    for (int id = 0; id < nimg*nimg; ++id)
+        for (int t = 0; t < nt; ++t) {
+            if (nc > 1) {
+                float val = 0.f;
+                for (int c = 0; c < nc; ++c) { cfloat q = coilimg[(size_t)nchan*id + (size_t)nc*t + c]; val += q.x*q.x + q.y*q.y; }
+                img[(size_t)nt*id + t].x = sqrtf(val);
+                img[(size_t)nt*id + t].y = 0.f;
+            } else
+                img[(size_t)nt*id + t] = coilimg[(size_t)nchan*id + t];
+        }
+}
+
+/* recon_radial2d, adjoint, with the combination chosen: mode 0 = root-sum-of-squares per repetition, 1 = Walsh.
+   Output h_out[nt*nx*ny*z + nt*id + t] (.ra dims [1, nt, nx, ny, nz], first dim fastest). */
+int oracle_recon_combine(const oracle_params *p, cfloat *h_out, const cfloat *h_in, int zfirst, int zcount, int mode, int npatch)
+{
+    if (!p->adjoint) return -3;
+    const int nchan = p->nc * p->nt;
+    const size_t nbuf = (size_t)nchan*imax(p->nro*p->npe1work, p->nxos*p->nyos);
+    cfloat *d_u = (cfloat*)malloc(nbuf*sizeof(cfloat)), *d_v = (cfloat*)malloc(nbuf*sizeof(cfloat));
+    int rc = 0;
+    for (int z = zfirst; z < zfirst + zcount && z < p->nz; ++z) {
+        int peoffset = z*p->prof_slide;
+        if ((long long)peoffset + p->npe1work > (long long)p->npe1 * (p->npe2 > 0 ? p->npe2 : 1)) { rc = -2; break; }
+        memcpy(d_u, h_in + (size_t)nchan*p->nro*peoffset, (size_t)nchan*p->nro*p->npe1work*sizeof(cfloat));
+        oracle_nufft_adj_radial2d(p, d_v, d_u, peoffset);
+        cfloat *out = h_out + (size_t)p->nt*p->nx*p->ny*z;
+        if (mode == 1) oracle_coilcombinewalsh(out, d_v, p->nx, p->nc, p->nt, npatch);
+        else oracle_coilcombinesos_nt(out, d_v, p->nx, p->nc, p->nt);
+    }
+    free(d_u); free(d_v);
+    return rc;
+}
+
 /* ------------------------------------------------------------------ CGNR (tron.cu:658-720)
  *
  * The reference's tron_cgnr_radial2d carries the comment "NOT WORKING CORRECTLY YET" (:670).  This restates the

@@ -175,8 +175,12 @@ def test_device_resident_adjoint_uncombined(oracle):
 
 
 def test_errors_are_reported_not_fatal():
-    cfg = lib.default_config(adjoint=1, niter=3)
+    cfg = lib.default_config(adjoint=1, kernwidth=5.0)            # kernel widths beyond 4 are not implemented
     d = lib.derive_dims(cfg, (1, 1, 32, 10, 1))
+    with pytest.raises(lib.TronError) as e:
+        lib.Plan(cfg, d)
+    assert e.value.code == lib.TRON_ERR_UNSUPPORTED
+    cfg = lib.default_config(adjoint=1, niter=2, input_half=1)    # CGNR keeps its residual in fp32
     with pytest.raises(lib.TronError) as e:
         lib.Plan(cfg, d)
     assert e.value.code == lib.TRON_ERR_UNSUPPORTED

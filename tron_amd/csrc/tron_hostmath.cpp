@@ -280,6 +280,7 @@ extern "C" void tron_config_default(tron_config *cfg)
     cfg->blocks = 4096;           // src/tron.cu:59
     cfg->threads = 128;           // src/tron.cu:58
     cfg->kb_mode = TRON_KB_FAST;
+    cfg->walsh_patch = 1;         // src/tron.cu:766
     cfg->pin_host = 1;            // the reference pins its output (cudaMallocHost, src/tron.cu:967)
 }
 

@@ -92,7 +92,7 @@ hipError_t launch_cg_wnorm2(const float2 *v, size_t n, int nslices, int nchan, i
 hipError_t launch_cg_finish(const double *partial, double *num, float *coef, int mode, int nslices, hipStream_t s);
 hipError_t launch_cg_axpy(float2 *y, const float2 *x, const float *coef, float sign, size_t n, int nslices, hipStream_t s);
 hipError_t launch_cg_xpby(float2 *pt, const float2 *zt, const float *coef, size_t n, int nslices, hipStream_t s);
-hipError_t launch_sos(float2 *out, const float2 *coil, size_t npix, int nchan, int nslices, hipStream_t s);
+hipError_t launch_coil_combine(float2 *out, const float2 *coil, int nimg, int nc, int nt, int mode, int npatch, int nslices, hipStream_t s);
 constexpr int kCgPartials = 64;  // = kCgBlocks
 // tiled degridding (tron_degrid_tile.hip), W <= 3
 hipError_t launch_degrid_tile(const DegridParams &p, int kb_mode, hipStream_t s);

@@ -96,6 +96,8 @@ int main(int argc, char *argv[])
     const char *outfile = optind + 1 < argc ? argv[optind + 1] : "img_tron.ra";   // src/tron.cu:877
     if (const char *kb = getenv("TRON_KB_MODE")) cfg.kb_mode = strcmp(kb, "exact") == 0 ? TRON_KB_EXACT : TRON_KB_FAST;
     if (const char *cc = getenv("TRON_CGNR_CONSISTENT")) cfg.cgnr_consistent = atoi(cc) != 0;
+    if (const char *cb = getenv("TRON_COIL_COMBINE")) cfg.coil_combine = strcmp(cb, "walsh") == 0 ? 1 : 0;
+    if (const char *wp = getenv("TRON_WALSH_PATCH")) cfg.walsh_patch = atoi(wp);
     if (const char *ng = getenv("TRON_GPUS")) {
         if (atoi(ng) > 1 && gpu_list.empty()) {
             multi_gpu = true;

@@ -115,15 +115,19 @@ struct tron_plan {
     double *d_cg_partial = nullptr, *d_cg_num = nullptr;
     float *d_cg_coef = nullptr;
     int cg_slices = 0;
+    float2 *d_coil_tmp = nullptr;    // uncombined coil images of a batch (Walsh combination, nt > 1)
+    int coil_tmp_slices = 0;
     hipStream_t stream_up = nullptr, stream_down = nullptr;   // host-buffer entry point: upload / download lanes
     std::vector<hipEvent_t> ev_pipe;                          // its chunk events (created on demand, reused)
     float2 *d_trig_tmp = nullptr;  // stage-level gridding calls
-    int chunk_cap = 0;             // slices the work buffers hold (1.5 x chunk for the adjoint)
+    int chunk_cap = 0;             // most slices / images one batch may hold (1.5 x chunk for the adjoint)
+    int work_units = 0;            // slices / images the work buffers hold NOW (forward plans grow them on demand)
     bool fft512 = false;           // fused pruned FFT path (nxos 512 -> nx 256)
     float2 *d_tw512 = nullptr;     // exp(+2 pi i k / 512)
     float2 *d_fft_tmp = nullptr;   // chunk * nchan * 256 * 512
     std::map<std::pair<int, int>, FftPlan> fft;   // (batch, direction) -> plan
     // timing
+    bool poison = false;           // TRON_POISON_GRID (tests): NaN-fill the work grid
     int debug_skip = 0;            // environment knobs, read once at plan creation (never on the launch path)
     bool degrid_simple = false, no_disc = false;
     bool pin_host = false;         // hipHostRegister the caller's buffers in tron_recon_radial2d[_range]
@@ -258,8 +262,32 @@ void fill_grid_consts(const tron_plan *p, GridParams &g)
 
 // Adjoint for slices [zfirst, zfirst+zcount).  d_in_z0 points at the first spoke of slice
 // zfirst's window; d_out at that slice's output.
+// Work buffers (Cartesian grid, FFT intermediate) for `units` slices / images per batch.  Adjoint plans allocate their
+// full batch at creation; forward plans start empty and grow to what a call actually transforms (the host entry point
+// only ever asks for one image: no 1.5 GiB of work space for it).
+int ensure_work(tron_plan *p, int units)
+{
+    if (units <= p->work_units) return TRON_OK;
+    const tron_dims &d = p->d;
+    const size_t per_unit = (size_t)p->nchan * d.nxos * d.nxos * sizeof(float2);
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    if (p->stream2) HIP_TRY(hipStreamSynchronize(p->stream2));
+    for (float2 **b : {&p->d_grid, &p->d_grid2, &p->d_fft_tmp})
+        if (*b) { HIP_TRY(hipFree(*b)); *b = nullptr; }
+    p->work_units = 0;
+    if (hipMalloc(reinterpret_cast<void **>(&p->d_grid), (size_t)units * per_unit) != hipSuccess)
+        return fail(TRON_ERR_NOMEM, "cannot allocate %zu bytes of Cartesian work space", (size_t)units * per_unit);
+    if (p->poison) hipMemset(p->d_grid, 0xff, (size_t)units * per_unit);
+    if (p->fft512 && hipMalloc(reinterpret_cast<void **>(&p->d_fft_tmp), (size_t)units * p->nchan * 256 * 512 * sizeof(float2)) != hipSuccess)
+        return fail(TRON_ERR_NOMEM, "cannot allocate the FFT intermediate buffer");
+    if (p->dual && hipMalloc(reinterpret_cast<void **>(&p->d_grid2), (size_t)units * per_unit) != hipSuccess)
+        return fail(TRON_ERR_NOMEM, "cannot allocate the second Cartesian buffer");
+    p->work_units = units;
+    return TRON_OK;
+}
+
 // in_stride_spokes: spokes between the windows of consecutive slices in d_in_z0 (0 = prof_slide: views into the stream)
-int adjoint_run(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, int zcount, int combine, int in_stride_spokes = 0)
+int adjoint_run_raw(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, int zcount, int combine, int in_stride_spokes)
 {
     const tron_dims &d = p->d;
     const size_t n2 = (size_t)d.nxos * d.nxos;
@@ -275,6 +303,7 @@ int adjoint_run(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, int 
     if ((zcount + nbatch - 1) / nbatch > p->chunk_cap) nbatch = (zcount + p->chunk_cap - 1) / p->chunk_cap;
     const int even = (zcount + nbatch - 1) / nbatch;
     const int step = dual ? std::max(1, std::min(even, (zcount + 1) / 2)) : even;
+    if (int erc = ensure_work(p, std::min(step, std::max(zcount, 1)))) return erc;
     int lane_idx = 0;
     for (int z0 = 0; z0 < zcount; z0 += step, ++lane_idx) {
         const int cz = std::min(step, zcount - z0);
@@ -370,6 +399,44 @@ int adjoint_run(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, int 
 
 // trig / deapod default to the plan's own tables (forward plans); the CGNR path of an adjoint plan passes the forward
 // operator's tables and a per-image angle stride (every slice has its own golden angles)
+// coilcombinesos / coilcombinewalsh (src/tron.cu:764,766) of `cz` slices of coil images [z][nchan*id + c]
+int combine_coils(tron_plan *p, float2 *d_out, const float2 *d_coil, int cz)
+{
+    if (p->cfg.coil_combine == 1 && p->d.nc > 16)
+        return fail(TRON_ERR_UNSUPPORTED, "Walsh coil combination handles up to 16 coils (nc=%d)", p->d.nc);
+    HIP_TRY(launch_coil_combine(d_out, d_coil, p->d.nx, p->d.nc, p->d.nt, p->cfg.coil_combine == 1 ? 1 : 0,
+                                std::max(0, p->cfg.walsh_patch), cz, p->stream));
+    return TRON_OK;
+}
+
+// The adjoint with the plan's coil combination.  Root-sum-of-squares of one repetition is fused into the pipeline's
+// tail; Walsh's adaptive combination and nt > 1 (channel = coil + nc*repetition) run it uncombined into a scratch
+// buffer and combine from there.
+int adjoint_run(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, int zcount, int combine, int in_stride_spokes = 0)
+{
+    if (!combine || (p->d.nt == 1 && p->cfg.coil_combine != 1))
+        return adjoint_run_raw(p, d_out, d_in_z0, zfirst, zcount, combine, in_stride_spokes);
+    const tron_dims &d = p->d;
+    const size_t N = (size_t)p->nchan * d.nx * d.ny, elem = p->cfg.input_half ? 4 : 8;
+    const int step = std::max(1, std::min(p->chunk, zcount));
+    if (p->coil_tmp_slices < step) {
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        if (p->d_coil_tmp) HIP_TRY(hipFree(p->d_coil_tmp));
+        p->d_coil_tmp = nullptr; p->coil_tmp_slices = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_coil_tmp), step * N * sizeof(float2)));
+        p->coil_tmp_slices = step;
+    }
+    const int in_stride = in_stride_spokes > 0 ? in_stride_spokes : d.prof_slide;
+    for (int z0 = 0; z0 < zcount; z0 += step) {
+        const int cz = std::min(step, zcount - z0);
+        int rc = adjoint_run_raw(p, p->d_coil_tmp, static_cast<const unsigned char *>(d_in_z0) + (size_t)z0 * in_stride * d.nro * p->nchan * elem,
+                                 zfirst + z0, cz, 0, in_stride_spokes);
+        if (rc) return rc;
+        if ((rc = combine_coils(p, static_cast<float2 *>(d_out) + (size_t)z0 * d.nt * d.nx * d.ny, p->d_coil_tmp, cz))) return rc;
+    }
+    return TRON_OK;
+}
+
 int forward_run(tron_plan *p, void *d_out, const void *d_in, int nimg, const float2 *trig = nullptr, int trig_img_stride = 0,
                 const float *deapod = nullptr)
 {
@@ -377,6 +444,7 @@ int forward_run(tron_plan *p, void *d_out, const void *d_in, int nimg, const flo
     const size_t n2 = (size_t)d.nxos * d.nxos;
     if (!trig) trig = p->d_trig;
     if (!deapod) deapod = p->d_deapod;
+    if (int erc = ensure_work(p, std::max(1, std::min(p->chunk, nimg)))) return erc;
     for (int k0 = 0; k0 < nimg; k0 += p->chunk) {
         const int ck = std::min(p->chunk, nimg - k0);
         const float2 *img = static_cast<const float2 *>(d_in) + (size_t)k0 * p->nchan * d.nx * d.nx;
@@ -469,8 +537,9 @@ int cgnr_run(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, int zco
         const int cz = std::min(step, zcount - z0);
         const unsigned char *y = static_cast<const unsigned char *>(d_in_z0) + (size_t)z0 * d.prof_slide * spoke_bytes;
         // r = y: the (overlapping) windows of the stream, one contiguous copy per slice (:685; F5)
-        HIP_TRY(hipMemcpy2DAsync(p->d_cg_r, n * sizeof(float2), y, (size_t)d.prof_slide * spoke_bytes, n * sizeof(float2), cz,
-                                 hipMemcpyDeviceToDevice, st));
+        for (int z = 0; z < cz; ++z)
+            HIP_TRY(hipMemcpyAsync(p->d_cg_r + (size_t)z * n, y + (size_t)z * d.prof_slide * spoke_bytes, n * sizeof(float2),
+                                   hipMemcpyDeviceToDevice, st));
         // ztilde = A^H W r (:686), ptilde = ztilde (:687), x = 0 (:683)
         if ((rc = adjoint_run(p, p->d_cg_zt, p->d_cg_r, zfirst + z0, cz, 0, d.npe1work))) return rc;
         HIP_TRY(launch_cg_scale_norm2(p->d_cg_zt, N, cz, unscale, p->d_cg_partial, st));
@@ -492,9 +561,9 @@ int cgnr_run(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, int zco
             HIP_TRY(launch_cg_finish(p->d_cg_partial, p->d_cg_num, p->d_cg_coef, 2, cz, st));                       // beta (:709; F1)
             HIP_TRY(launch_cg_xpby(p->d_cg_pt, p->d_cg_zt, p->d_cg_coef, N, cz, st));                               // ptilde = ztilde + beta ptilde (:710)
         }
-        if (combine)
-            HIP_TRY(launch_sos(static_cast<float2 *>(d_out) + (size_t)z0 * d.nx * d.ny, p->d_cg_x, (size_t)d.nx * d.ny, p->nchan, cz, st));   // (:764)
-        else
+        if (combine) {
+            if ((rc = combine_coils(p, static_cast<float2 *>(d_out) + (size_t)z0 * d.nt * d.nx * d.ny, p->d_cg_x, cz))) return rc;        // (:764)
+        } else
             HIP_TRY(hipMemcpyAsync(static_cast<float2 *>(d_out) + (size_t)z0 * N, p->d_cg_x, cz * N * sizeof(float2), hipMemcpyDeviceToDevice, st));   // (:713)
     }
     return TRON_OK;
@@ -535,8 +604,8 @@ extern "C" int tron_plan_create(tron_plan **out, const tron_config *cfg, const t
     const tron_dims &d = *dims;
     if (cfg->niter < 0 || (cfg->niter > 0 && cfg->input_half))
         return fail(TRON_ERR_UNSUPPORTED, "-i %d: CGNR needs niter >= 0 and complex64 k-space", cfg->niter);
-    if (d.nt != 1)
-        return fail(TRON_ERR_UNSUPPORTED, "nt=%d: only nt=1 is supported (the reference's FFT plans ignore nt, src/tron.cu:599-601)", d.nt);
+    if (d.nt < 1 || d.nc < 1 || (long long)d.nc * d.nt > 4096)
+        return fail(TRON_ERR_INVALID, "nc=%d nt=%d: channel count outside [1, 4096]", d.nc, d.nt);
     if (!(cfg->kernwidth > 0.f) || cfg->kernwidth > 4.f)
         return fail(TRON_ERR_UNSUPPORTED, "kernel width %g outside (0, 4]", cfg->kernwidth);
     if (d.nxos < 2 || d.nxos > 16384 || d.nxos != d.nyos || d.nx != d.ny)
@@ -552,6 +621,7 @@ extern "C" int tron_plan_create(tron_plan **out, const tron_config *cfg, const t
     if (cfg->device < 0 || cfg->device >= ndev)
         return fail(TRON_ERR_HIP, "device %d requested but %d HIP device(s) present", cfg->device, ndev);
     HIP_TRY(hipSetDevice(cfg->device));
+    (void)hipGetLastError();       // a stale error of an earlier, failed call must not be reported by this one
     std::call_once(g_fft_once, [] { rocfft_setup(); });
     // make every code object resident before anything is queued on a non-blocking stream
     HIP_TRY(warm_kernels());
@@ -611,7 +681,7 @@ extern "C" int tron_plan_create(tron_plan **out, const tron_config *cfg, const t
         p->tiles_per_row = (d.nxos + kTile - 1) / kTile;
         p->ntiles = (int)order.size();
         if ((rc = upload(&p->d_tile_order, order.data(), order.size() * sizeof(int)))) return bail(rc);
-        p->binned = p->kb_mode == TRON_KB_FAST && cfg->kernwidth <= 3.f && d.nxos <= 2048;   // 10 bits of |r| in a sorted entry
+        p->binned = p->kb_mode == TRON_KB_FAST && cfg->kernwidth <= 3.f;
         if (const char *gk = getenv("TRON_GRID_KERNEL")) p->binned = p->binned && strcmp(gk, "gather") != 0;
         if (p->binned) {
             std::vector<int> sorder, slots;
@@ -652,10 +722,7 @@ extern "C" int tron_plan_create(tron_plan **out, const tron_config *cfg, const t
     }
     unsigned int zero = 0;
     if ((rc = upload(&p->d_errflag, &zero, sizeof(zero)))) return bail(rc);
-    if (hipMalloc(reinterpret_cast<void **>(&p->d_grid), (size_t)p->chunk_cap * per_unit) != hipSuccess)
-        return bail(fail(TRON_ERR_NOMEM, "cannot allocate %zu bytes of Cartesian work space", (size_t)p->chunk_cap * per_unit));
-    if (getenv("TRON_POISON_GRID"))      // tests: NaN-fill the work grid so a read of a never-written point shows up
-        hipMemset(p->d_grid, 0xff, (size_t)p->chunk_cap * per_unit);
+    p->poison = getenv("TRON_POISON_GRID") != nullptr;   // tests: NaN-fill the work grid so a read of a never-written point shows up
     if (d.nxos == 512 && d.nx == 256) {
         p->fft512 = true;
         if (const char *ff = getenv("TRON_FFT")) p->fft512 = strcmp(ff, "rocfft") != 0;
@@ -667,8 +734,6 @@ extern "C" int tron_plan_create(tron_plan **out, const tron_config *cfg, const t
             tw[2 * k + 1] = (float)sin(2.0 * M_PI * k / 512.0);
         }
         if ((rc = upload(&p->d_tw512, tw.data(), tw.size() * sizeof(float)))) return bail(rc);
-        if (hipMalloc(reinterpret_cast<void **>(&p->d_fft_tmp), (size_t)p->chunk_cap * p->nchan * 256 * 512 * sizeof(float2)) != hipSuccess)
-            return bail(fail(TRON_ERR_NOMEM, "cannot allocate the FFT intermediate buffer"));
         // off by default: measured +2 % (the gridding kernel already fills every CU's LDS, so the FFT
         // lane only gets the tail); TRON_DUAL_STREAM=1 turns it on
         p->dual = false;
@@ -697,9 +762,13 @@ extern "C" int tron_plan_create(tron_plan **out, const tron_config *cfg, const t
                 if (hipEventCreateWithFlags(&p->ev_g[i], hipEventDisableTiming) != hipSuccess ||
                     hipEventCreateWithFlags(&p->ev_f[i], hipEventDisableTiming) != hipSuccess)
                     return bail(fail(TRON_ERR_HIP, "cannot create pipeline events"));
-            if (hipMalloc(reinterpret_cast<void **>(&p->d_grid2), (size_t)p->chunk_cap * per_unit) != hipSuccess)
-                return bail(fail(TRON_ERR_NOMEM, "cannot allocate the second Cartesian buffer"));
         }
+    }
+    // adjoint: the whole batch now (an out-of-memory plan fails here, not mid-run); forward: on first use, sized by the call
+    if (cfg->adjoint && (rc = ensure_work(p, p->chunk_cap))) return bail(rc);
+    if (!p->fft512) {   // rocFFT plans for the batch sizes this plan will certainly see: no plan creation (and device
+        FftPlan *f = nullptr;       // synchronisation) in the middle of the first pipeline
+        if ((rc = get_fft(p, (cfg->adjoint ? std::min(p->chunk, std::max(d.nz, 1)) : 1) * p->nchan, cfg->adjoint ? 1 : 0, &f))) return bail(rc);
     }
     if (cfg->verbose) {
         printf("tronhip: device %d, %s, nchan %d, grid %d^2 -> image %d^2, %d spokes/image, chunk %d, KB %s\n",
@@ -735,6 +804,7 @@ extern "C" int tron_plan_destroy(tron_plan *p)
     hipFree(p->d_band);
     hipFree(p->d_tile_order);
     hipFree(p->d_tile_order32);
+    hipFree(p->d_coil_tmp);
     hipFree(p->d_deapod_fwd);
     hipFree(p->d_trig_fwd);
     hipFree(p->d_cg_r); hipFree(p->d_cg_v); hipFree(p->d_cg_zt); hipFree(p->d_cg_pt); hipFree(p->d_cg_x);

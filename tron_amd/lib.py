@@ -34,6 +34,7 @@ class Config(ctypes.Structure):
         ("blocks", ctypes.c_int), ("threads", ctypes.c_int), ("device", ctypes.c_int),
         ("kb_mode", ctypes.c_int), ("input_half", ctypes.c_int), ("chunk_slices", ctypes.c_int),
         ("pin_host", ctypes.c_int), ("cgnr_consistent", ctypes.c_int),
+        ("coil_combine", ctypes.c_int), ("walsh_patch", ctypes.c_int),
     ]
 
 

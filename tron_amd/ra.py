@@ -93,6 +93,26 @@ def read(path, with_header: bool = False):
     return (arr, h) if with_header else arr
 
 
+def read_spokes(path, first_spoke: int, nspokes: int):
+    """Reads only spokes [first_spoke, first_spoke+nspokes) of a 5-D k-space file [nc, nt, nro, npe1, npe2] (a spoke =
+    nc*nt*nro consecutive elements): one seek + one read of exactly those bytes.  Returns (flat array, header,
+    bytes_read); complex64 files give complex64, complex-half files float16 (re, im) pairs."""
+    with open(path, "rb") as f:
+        h = _read_header(f)
+        if h.ndims != 5 or h.eltype != RA_TYPE_COMPLEX or h.elbyte not in (4, 8):
+            raise ValueError("read_spokes wants a 5-D complex64 / complex-half k-space file")
+        spoke_bytes = h.dims[0] * h.dims[1] * h.dims[2] * h.elbyte
+        total = h.dims[3] * h.dims[4]
+        if first_spoke < 0 or nspokes < 0 or first_spoke + nspokes > total:
+            raise ValueError(f"spokes [{first_spoke}, {first_spoke + nspokes}) outside the file's {total}")
+        f.seek(h.nbytes_header + first_spoke * spoke_bytes)
+        payload = f.read(nspokes * spoke_bytes)
+        if len(payload) != nspokes * spoke_bytes:
+            raise ValueError(f"Read {len(payload)} B instead of {nspokes * spoke_bytes} B.")
+    arr = np.frombuffer(payload, dtype=np.complex64 if h.elbyte == 8 else np.float16)
+    return arr, h, len(payload)
+
+
 def _classify(arr: np.ndarray):
     k = arr.dtype.kind
     if k == "c":

@@ -44,7 +44,46 @@ def hip_compute(cfg, dims):
     def run(flat_in, zfirst, zcount, out):
         plan.recon(flat_in, zfirst=zfirst, zcount=zcount, out=out)
     run.close = plan.close
+    run.plan = plan
     return run
+
+
+def gather_blocks(block, zc: int, slice_elems: int, nz: int, rank: int, world: int, group=None):
+    """Host-side gather of per-rank image blocks (rank r holds slices partition(nz, world, r)) on rank 0; returns the
+    assembled flat output there, None elsewhere.  The only cross-rank traffic of a sharded run."""
+    if world == 1:
+        return np.ascontiguousarray(block[: nz * slice_elems])
+    import torch
+    import torch.distributed as dist
+    maxc = max(partition(nz, world, r)[1] for r in range(world))
+    padded = np.zeros(maxc * slice_elems, np.complex64)
+    padded[: zc * slice_elems] = block[: zc * slice_elems]
+    t = torch.from_numpy(padded.view(np.float32))
+    if rank == 0:
+        parts = [torch.empty_like(t) for _ in range(world)]
+        dist.gather(t, parts, dst=0, group=group)
+        out = np.zeros(nz * slice_elems, np.complex64)
+        for r, part in enumerate(parts):
+            rz0, rzc = partition(nz, world, r)
+            out[rz0 * slice_elems: (rz0 + rzc) * slice_elems] = part.numpy().view(np.complex64)[: rzc * slice_elems]
+        return out
+    dist.gather(t, None, dst=0, group=group)
+    return None
+
+
+def recon_file_sharded(infile, cfg, rank: int, world: int, compute_block, group=None):
+    """One rank's share of `tron -a` on a .ra file: reads ONLY the spokes its slice block touches (spoke_range),
+    reconstructs them with ``compute_block(block_in, zfirst, zcount) -> zcount images`` and gathers on rank 0.
+    Returns (flat output or None, dims, bytes this rank read from the file)."""
+    from . import lib, ra
+    hdr = ra.read_header(infile)
+    dims = lib.derive_dims(cfg, hdr.dims)
+    z0, zc = partition(dims.nz, world, rank)
+    s0, ns = spoke_range(dims.prof_slide, dims.npe1work, z0, zc)
+    block_in, _, nbytes = ra.read_spokes(infile, s0, ns)
+    slice_elems = dims.nt * dims.nx * dims.ny
+    block_out = compute_block(block_in, z0, zc, dims) if zc > 0 else np.zeros(0, np.complex64)
+    return gather_blocks(block_out, zc, slice_elems, dims.nz, rank, world, group), dims, nbytes
 
 
 def recon_sharded(flat_in: np.ndarray, out_elems: int, slice_elems: int, nz: int, compute,
@@ -104,15 +143,22 @@ def main(argv=None):
         print("usage: python -m tron_amd.shard [tron flags] <infile.ra> [outfile.ra]", file=sys.stderr)
         return 1
     infile, outfile = args[0], (args[1] if len(args) > 1 else "img_tron.ra")
-    data = ra.read(infile)
     if not kw.get("adjoint"):
         raise SystemExit("sharding is defined for the adjoint (-a): forward runs have one image")
+    hdr = ra.read_header(infile)
+    if hdr.eltype == ra.RA_TYPE_COMPLEX and hdr.elbyte == 4:
+        kw["input_half"] = 1
     cfg = lib.default_config(**kw)
-    dims = lib.derive_dims(cfg, data.shape)
-    flat = np.asfortranarray(data, dtype=np.complex64).reshape(-1, order="F")
-    compute = hip_compute(cfg, dims)
-    out = recon_sharded(flat, dims.out_bytes // 8, dims.nt * dims.nx * dims.ny, dims.nz, compute, rank, world)
-    compute.close()
+    plans = {}
+
+    def compute_block(block_in, z0, zc, dims):
+        # the plan is made from the FULL file's dims (global slice and angle indices); the rank holds only its own spokes
+        plan = plans.setdefault("p", lib.Plan(cfg, dims))
+        return plan.recon_block(block_in, z0, zc)                   # = tron_recon_radial2d_block
+
+    out, dims, _ = recon_file_sharded(infile, cfg, rank, world, compute_block)
+    if "p" in plans:
+        plans["p"].close()
     if rank == 0:
         ra.write(outfile, out.reshape(tuple(int(x) for x in dims.out_dims), order="F"))
     if world > 1:
