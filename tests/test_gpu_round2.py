@@ -124,5 +124,6 @@ def test_walsh_adaptive_coil_combine(oracle, nc, npatch):
     assert got.shape == want.shape
     assert rel_l2(got, want) <= 1e-5
     sos, _ = lib.recon(data, adjoint=True, golden_angle=1)
-    assert not np.allclose(np.abs(got), np.abs(sos))                  # it is a different combination ...
+    if npatch > 0:                                                     # (a one-pixel patch has a rank-1 covariance: |walsh| = SoS)
+        assert not np.allclose(np.abs(got), np.abs(sos))              # it is a different combination ...
     assert np.corrcoef(np.abs(got).ravel(), np.abs(sos).ravel())[0, 1] > 0.5      # ... of the same coil images

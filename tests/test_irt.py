@@ -83,3 +83,21 @@ def test_irt_constants_match_survey_probe():
     assert abs(sn[0].real - 0.99917) < 1e-5 and abs(sn[127].real - 0.61511) < 1e-5
     T = irt.nufft_T(256, 4, 512, alpha, beta)
     assert np.allclose(np.diag(T), [10.054, 25.238, 25.238, 10.054], atol=1e-3)
+
+
+def test_cpp_irt_comparator_matches_the_numpy_restatement():
+    """oracle/irt_nufft.cpp (the C++/OpenMP comparator bench.py times as cpu_baseline) against oracle/irt_nufft.py, which
+    the tests above check against the NUFFT's definition: nufft_init + nufft_adj, several coils, with density weights."""
+    from oracle import irt_cpp
+    rng = np.random.default_rng(11)
+    N, M = 32, 64 * 24
+    om = 2 * np.pi * (rng.random((M, 2)) - 0.5)
+    om[:5] = [[0.0, 0.0], [np.pi - 1e-9, 0.3], [-np.pi, -np.pi], [1e-12, -1e-12], [2.0, -3.0]]     # grid edges / wrap
+    X = rng.standard_normal((3, M)) + 1j * rng.standard_normal((3, M))
+    w = rng.random(M)
+    st = irt.Nufft(om, (N, N), (4, 4), (2 * N, 2 * N), (N // 2, N // 2))
+    want = np.stack([st.adjoint(X[c] * w) for c in range(3)])
+    got = irt_cpp.adjoint(om, X, N, dcf=w, threads=2)
+    assert np.linalg.norm(got - want) / np.linalg.norm(want) < 1e-12
+    r = irt_cpp.bench_golden(32, 64, 20, 2, 3, 2)          # the timed loop runs and produces finite images
+    assert r["wall_s"] > 0 and np.isfinite(r["checksum"]) and r["checksum"] > 0
