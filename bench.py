@@ -179,6 +179,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-irt", action="store_true", help="skip the contrib/irt comparator (cpu_baseline is then the oracle port)")
     ap.add_argument("--forward", action="store_true",
                     help="measure the forward (degridding) direction instead: --slices images of 256^2 -> 512 x 512 golden-angle spokes")
+    ap.add_argument("--linear", action="store_true",
+                    help="secondary line: linear-angle spokes (no -G): every slice shares one trajectory, so with few coils several "
+                         "slices share one pass of the gridding kernel")
     ap.add_argument("--no-check", action="store_true")
     return ap.parse_args(argv)
 
@@ -268,7 +271,8 @@ def main():
     else:
         zfirst, nz = 0, args.slices
         total_slices = world * nz
-    cfg = lib.default_config(adjoint=1, golden_angle=1, data_undersamp=undersamp, prof_slide=NPE, device=local_rank,
+    golden = 0 if args.linear else 1
+    cfg = lib.default_config(adjoint=1, golden_angle=golden, data_undersamp=undersamp, prof_slide=NPE, device=local_rank,
                              kb_mode=lib.KB_FAST if args.kb == "fast" else lib.KB_EXACT, chunk_slices=args.chunk,
                              input_half=1 if args.half else 0, skip_angles=zfirst * NPE)    # global angle index of this rank's first spoke
     dims = lib.derive_dims(cfg, (nc, 1, NRO, NPE * nz, 1))
@@ -360,7 +364,7 @@ def main():
             for z in sorted({0, nz - 1}):
                 lo = 2 * nc * NRO * NPE * z
                 host = kspace[lo: lo + 2 * nc * NRO * NPE].float().cpu().numpy().view(np.complex64).reshape((nc, 1, NRO, NPE, 1), order="F")
-                want, _ = pyoracle.recon(host, adjoint=1, golden=1, data_undersamp=undersamp, prof_slide=NPE, skip_angles=(zfirst + z) * NPE)
+                want, _ = pyoracle.recon(host, adjoint=1, golden=golden, data_undersamp=undersamp, prof_slide=NPE, skip_angles=(zfirst + z) * NPE)
                 got = images[2 * NX * NX * z: 2 * NX * NX * (z + 1)].cpu().numpy().view(np.complex64)
                 err = max(err, float(np.linalg.norm(got - want.reshape(-1, order="F")) / np.linalg.norm(want)))
             if not err <= 1e-5:
@@ -390,8 +394,8 @@ def main():
             "value": round(value, 1), "unit": "slices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32" if not args.half else "f32 (k-space stored as f16)", "data": "synthetic",
-            "config": {"workload": f"adjoint gridding recon: {per_gpu} x {nc} coils, 512 readout x {NPE} golden-angle spokes "
-                                   f"-> 512^2 oversampled grid -> 256^2 image (tron -a -G -u {undersamp:.4f} -d {NPE})",
+            "config": {"workload": f"adjoint gridding recon: {per_gpu} x {nc} coils, 512 readout x {NPE} {'golden' if golden else 'linear'}-angle spokes "
+                                   f"-> 512^2 oversampled grid -> 256^2 image (tron -a {'-G ' if golden else ''}-u {undersamp:.4f} -d {NPE})",
                        "coils": nc, "slices_per_gpu": nz, "kb_mode": args.kb,
                        "parallelism": f"slices sharded over {world} GPU(s), one process each, no collective on the data path (gloo barrier only)",
                        **({"ranks_share_one_gpu": True} if share and ndev < world else {})},

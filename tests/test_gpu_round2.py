@@ -127,3 +127,23 @@ def test_walsh_adaptive_coil_combine(oracle, nc, npatch):
     if npatch > 0:                                                     # (a one-pixel patch has a rank-1 covariance: |walsh| = SoS)
         assert not np.allclose(np.abs(got), np.abs(sos))              # it is a different combination ...
     assert np.corrcoef(np.abs(got).ravel(), np.abs(sos).ravel())[0, 1] > 0.5      # ... of the same coil images
+
+
+@pytest.mark.parametrize("nc,nro,npe1,flags", [
+    (1, 64, 150, dict(data_undersamp=0.5, prof_slide=17)),      # 7 slices: one full group of 8 missing one
+    (2, 64, 150, dict(data_undersamp=0.5, prof_slide=11)),      # 11 slices in groups of 4
+    (4, 32, 80, dict(data_undersamp=1.0, prof_slide=16)),       # 4 slices in groups of 2
+    (1, 512, 60 * 9, dict(data_undersamp=60 / 512 + 1e-6, prof_slide=60)),   # metric grid size (fused FFT tail), 9 slices
+])
+def test_linear_angle_slices_share_one_gridding_pass(oracle, monkeypatch, nc, nro, npe1, flags):
+    """Linear angles (no -G): the spoke angle depends on pe only (src/tron.cu:509), so every slice has the same
+    trajectory and up to 8/nc slices ride in the coil dimension of ONE pass of the binned kernel.  Same arithmetic per
+    channel as the one-slice-per-pass launch: identical bits; and the oracle within 1e-5."""
+    data = synth.kspace(nc, nro, npe1, seed=1601 + nc)
+    got, dims = lib.recon(data, adjoint=True, golden_angle=0, **flags)
+    assert dims.nz > 2
+    monkeypatch.setenv("TRON_SLICES_PER_PASS", "0")
+    one, _ = lib.recon(data, adjoint=True, golden_angle=0, **flags)
+    assert np.array_equal(got, one)
+    want, _ = oracle.recon(data, adjoint=1, golden=0, **flags)
+    assert rel_l2(got, want) <= 1e-5

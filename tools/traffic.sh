@@ -16,6 +16,7 @@ for f in glob.glob(out + '/*/*/*_counter_collection.csv'):
         k = r['Kernel_Name'].split('(')[0].split('::')[-1]
         agg[k][r['Counter_Name']] += float(r['Counter_Value']); n[(k, r['Counter_Name'])].add(r['Dispatch_Id'])
 res = {"source_hash": kernel_source_hash(), "command": os.environ["CMD"],
+       "coil_slices_per_launch": int(os.environ.get("COIL_SLICES_PER_LAUNCH", "512")),   # gridbench 8 coils x 64-slice launches
        "units": "KiB summed over dispatches; gfx950: FETCH_SIZE counts half the bytes of 16-B/lane streaming reads (MI355X_MICROARCH.md, HBM)",
        "kernels": {}}
 for k, v in agg.items():

@@ -107,8 +107,13 @@ grid_binned_kernel(const GridParams p)
     const int tile = entry & 0xffff;
     const int part = (entry >> 16) & 15, nparts = max((entry >> 20) & 15, 1), slot = (entry >> 24) & 255;
     const int pe_lo = (int)(((long long)part * p.npe) / nparts), pe_hi = (int)(((long long)(part + 1) * p.npe) / nparts);
-    const int c0 = p.coil0 + blockIdx.y * CPB;
-    const int ncb = min(CPB, p.nchan - c0);
+    // vslices > 1 (linear angles: every slice has the SAME trajectory, src/tron.cu:509 depends on pe only): `vslices`
+    // consecutive slices ride in the coil dimension -- register channel c = slice (c / nchan) of the group, coil c % nchan
+    // -- so clipping, weights and the sort are paid once per group instead of once per slice
+    const int vs = p.vslices > 1 ? p.vslices : 1;
+    const int zbase = z * vs;
+    const int c0 = vs > 1 ? 0 : p.coil0 + blockIdx.y * CPB;
+    const int ncb = vs > 1 ? min(CPB, (p.nslices_total - zbase) * p.nchan) : min(CPB, p.nchan - c0);
     const int n = p.nxos;
     const int h = n / 2;
     const int rmax = n / 2 - 1;
@@ -154,7 +159,7 @@ grid_binned_kernel(const GridParams p)
         for (int c = 0; c < CPB; ++c) acc[q][c] = make_float2(0.f, 0.f);
 
     const unsigned char *in_bytes = reinterpret_cast<const unsigned char *>(p.nudata)
-        + (size_t)z * (size_t)p.in_slice_stride * (HALF ? sizeof(__half2) : sizeof(float2));
+        + (size_t)zbase * (size_t)p.in_slice_stride * (HALF ? sizeof(__half2) : sizeof(float2));
     const float2 *trig = p.trig + (size_t)z * p.trig_slice_stride;
 
     const float eps = 0.01f;
@@ -261,7 +266,13 @@ grid_binned_kernel(const GridParams p)
                     pf_r[j] = r;
                     const int ro = (p.nro == n ? r : (r * p.nro) / n) + p.nro / 2;   // src/tron.cu:517,519 (truncating division)
                     const size_t sbase = ((size_t)p.nro * pe + ro) * p.nchan + c0;
-                    if (!HALF && CPB % 2 == 0 && (ncb & 1) == 0 && (p.nchan & 1) == 0 && (c0 & 1) == 0) {
+                    if (vs > 1) {
+                        // channel c = (slice c / nchan of the group, coil c % nchan): one load per channel, each coalesced along the spoke
+#pragma unroll
+                        for (int c = 0; c < CPB; ++c)
+                            pf_d[j][c] = c < ncb ? load_sample<HALF>(in_bytes, (size_t)(c / p.nchan) * (size_t)p.in_slice_stride + sbase + (c % p.nchan))
+                                                 : make_float2(0.f, 0.f);
+                    } else if (!HALF && CPB % 2 == 0 && (ncb & 1) == 0 && (p.nchan & 1) == 0 && (c0 & 1) == 0) {
                         // the coils of one sample are contiguous: 16-byte loads (coils beyond ncb are zero padding)
                         const float4 *src4 = reinterpret_cast<const float4 *>(reinterpret_cast<const float2 *>(in_bytes) + sbase);
 #pragma unroll
@@ -293,6 +304,10 @@ grid_binned_kernel(const GridParams p)
             }
         };
 
+#ifdef TRON_BIN_LATE_CLEAR
+        for (int c = tid; c < C::NCELLS; c += kBinThreads) L.hist[c] = 0u;      // first batch of the round (ordered by the barriers below)
+        __syncthreads();
+#endif
         int sp0 = 0, sp1 = 0;
         if (nacc > 0 && p.debug < 3) {
             sp1 = batch_end(0);
@@ -302,8 +317,10 @@ grid_binned_kernel(const GridParams p)
             const int rec_base = L.sp_start[sp0];
             const int nrec = L.sp_start[sp1] - rec_base;
 
+#ifndef TRON_BIN_LATE_CLEAR
             for (int c = tid; c < C::NCELLS; c += kBinThreads) L.hist[c] = 0u;
             __syncthreads();
+#endif
 
             // ---- A. stage + count: records are dealt out flat, 64 consecutive records per wave pass ----
 #pragma unroll
@@ -431,6 +448,10 @@ grid_binned_kernel(const GridParams p)
             }
             __syncthreads();
 
+#ifdef TRON_BIN_LATE_CLEAR
+            // the counters are not read again in this batch: clear them for the next one here (one barrier less per batch)
+            for (int c = tid; c < C::NCELLS; c += kBinThreads) L.hist[c] = 0u;
+#endif
             // ---- D. apply: each thread walks the 2CW+1 cell rows its 2x2 points can see as ONE loop
             //         (row ranges concatenated), so a wave runs max-over-lanes(total), not sum of row maxima
             if (p.debug < 1) {
@@ -470,6 +491,16 @@ grid_binned_kernel(const GridParams p)
                     const float *wyr = L.wy + id * C::NWP + jp;
                     const float wxa = wxr[0], wxb = wxr[1];
                     const float wya = wyr[0], wyb = wyr[1];
+#ifdef TRON_BIN_EARLY_D
+                    float4 dd[CPB / 2 > 0 ? CPB / 2 : 1];
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (CPB % 2 == 0) {
+                        const float4 *d4e = reinterpret_cast<const float4 *>(L.d) + id;
+#pragma unroll
+                        for (int c = 0; c < CPB / 2; ++c) dd[c] = d4e[c * C::NREC];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#endif
                     const int ar = (int)((ent >> 16) & 0x3fffu);
                     float wq[4];
                     wq[0] = wxa * wya; wq[1] = wxb * wya; wq[2] = wxa * wyb; wq[3] = wxb * wyb;   // src/tron.cu:516
@@ -482,10 +513,12 @@ grid_binned_kernel(const GridParams p)
                             if (Rlo[q] == 0) wq[q] += wq[q];                                      // r = 0 sits in both loops
                     }
                     if (CPB % 2 == 0) {
+#ifndef TRON_BIN_EARLY_D
                         const float4 *d4 = reinterpret_cast<const float4 *>(L.d) + id;
                         float4 dd[CPB / 2 > 0 ? CPB / 2 : 1];
 #pragma unroll
                         for (int c = 0; c < CPB / 2; ++c) dd[c] = d4[c * C::NREC];
+#endif
 #pragma unroll
                         for (int c = 0; c < CPB / 2; ++c) {
                             const float4 d = dd[c];
@@ -541,7 +574,8 @@ grid_binned_kernel(const GridParams p)
                 v.y = acc[2 * qy][c].y * p.scale;
                 v.z = acc[2 * qy + 1][c].x * p.scale;
                 v.w = acc[2 * qy + 1][c].y * p.scale;
-                store_point_pair(p, z, c0 + c, X0, Y0 + qy, v);
+                if (vs > 1) store_point_pair(p, zbase + c / p.nchan, c % p.nchan, X0, Y0 + qy, v);
+                else store_point_pair(p, z, c0 + c, X0, Y0 + qy, v);
             }
 }
 
@@ -578,7 +612,7 @@ static hipError_t launch_binned_cpb(const GridParams &p, int half_in, hipStream_
     GridParams q = p;
     q.tiles_per_row = tpr;
     q.ntiles = tpr * tpr;
-    const int chunks = (p.nchan - p.coil0 + CPB - 1) / CPB;
+    const int chunks = p.vslices > 1 ? 1 : (p.nchan - p.coil0 + CPB - 1) / CPB;
     const int entries = p.tile_entries > 0 ? p.tile_entries : q.ntiles;
     dim3 grid((unsigned)((size_t)entries * q.nslices), (unsigned)chunks);
     const size_t lds = sizeof(BinLds<CPB, CW>);
@@ -605,6 +639,13 @@ static hipError_t launch_binned_cpb(const GridParams &p, int half_in, hipStream_
 template <int CW>
 static hipError_t launch_binned_cw(const GridParams &p, int half_in, hipStream_t s)
 {
+    if (p.vslices > 1) {                       // slices in the coil dimension: vslices * nchan channels per pass
+        const int nv = p.vslices * p.nchan;
+        if (nv > 8 || p.nsplit_slots > 0 || p.coil0 != 0 || p.trig_slice_stride != 0) return hipErrorInvalidValue;
+        if (nv > 4) return launch_binned_cpb<8, CW>(p, half_in, s);
+        if (nv > 2) return launch_binned_cpb<4, CW>(p, half_in, s);
+        return launch_binned_cpb<2, CW>(p, half_in, s);
+    }
     const int nc = p.nchan - p.coil0;
     static const int force = getenv("TRON_GRID_CPB") ? atoi(getenv("TRON_GRID_CPB")) : 0;   // tuning knob
     if (force == 8) return launch_binned_cpb<8, CW>(p, half_in, s);

@@ -40,6 +40,8 @@ struct GridParams {
     int max_parts;
     const int *split_slots;
     float2 *partial;         // [slice][slot][part][coil][32 x 32] partial tiles
+    // binned kernel, linear angles: `vslices` consecutive slices share one pass (nslices = groups, nslices_total = slices)
+    int vslices, nslices_total;
 };
 
 struct PostParams {           // crop + deapodise + (optional) root-sum-of-squares, adjoint tail

@@ -127,6 +127,7 @@ struct tron_plan {
     float2 *d_fft_tmp = nullptr;   // chunk * nchan * 256 * 512
     std::map<std::pair<int, int>, FftPlan> fft;   // (batch, direction) -> plan
     // timing
+    bool slices_per_pass = true;   // TRON_SLICES_PER_PASS=0 turns the linear-angle slice grouping off (A/B, tests)
     bool poison = false;           // TRON_POISON_GRID (tests): NaN-fill the work grid
     int debug_skip = 0;            // environment knobs, read once at plan creation (never on the launch path)
     bool degrid_simple = false, no_disc = false;
@@ -335,7 +336,14 @@ int adjoint_run_raw(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, 
             StageTimer t(p, STAGE_GRID, st);
             if (p->binned) {
                 g.tile_order = p->d_tile_order32;
-                if (cz < p->split_below && p->nsplit_slots > 0) {
+                // linear angles: every slice has the same trajectory (src/tron.cu:509 depends on pe only), so with few coils
+                // several slices share one pass of the kernel (clipping, weights and the sort paid once per group)
+                const int vs = (!golden && cz > 1 && p->nchan <= 4 && p->slices_per_pass) ? std::max(1, 8 / p->nchan) : 1;
+                if (vs > 1) {
+                    g.vslices = vs;
+                    g.nslices_total = cz;
+                    g.nslices = (cz + vs - 1) / vs;
+                } else if (cz < p->split_below && p->nsplit_slots > 0) {
                     // a launch this small would be bound by the centre tiles' serial chains: split them over spoke ranges
                     if (p->partial_slices < (size_t)cz) {
                         if (p->d_partial) { HIP_TRY(hipStreamSynchronize(st)); HIP_TRY(hipFree(p->d_partial)); p->d_partial = nullptr; }
@@ -780,6 +788,7 @@ extern "C" int tron_plan_create(tron_plan **out, const tron_config *cfg, const t
     p->debug_skip = 0;
     if (const char *dbg = getenv("TRON_DEBUG_SKIP")) p->debug_skip = atoi(dbg);
     p->degrid_simple = getenv("TRON_DEGRID_SIMPLE") != nullptr;
+    if (const char *sp = getenv("TRON_SLICES_PER_PASS")) p->slices_per_pass = atoi(sp) != 0;
     p->no_disc = getenv("TRON_NO_DISC") != nullptr;
     p->pin_host = cfg->pin_host != 0;
     if (const char *ph = getenv("TRON_PIN_HOST")) p->pin_host = atoi(ph) != 0;
