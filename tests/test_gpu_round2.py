@@ -137,13 +137,14 @@ def test_walsh_adaptive_coil_combine(oracle, nc, npatch):
 ])
 def test_linear_angle_slices_share_one_gridding_pass(oracle, monkeypatch, nc, nro, npe1, flags):
     """Linear angles (no -G): the spoke angle depends on pe only (src/tron.cu:509), so every slice has the same
-    trajectory and up to 8/nc slices ride in the coil dimension of ONE pass of the binned kernel.  Same arithmetic per
-    channel as the one-slice-per-pass launch: identical bits; and the oracle within 1e-5."""
+    trajectory and up to 8/nc slices ride in the coil dimension of ONE pass of the binned kernel.  Same terms per
+    channel as the one-slice-per-pass launch (record batches differ, so sums agree to fp32 summation order); the oracle
+    within 1e-5."""
     data = synth.kspace(nc, nro, npe1, seed=1601 + nc)
     got, dims = lib.recon(data, adjoint=True, golden_angle=0, **flags)
     assert dims.nz > 2
     monkeypatch.setenv("TRON_SLICES_PER_PASS", "0")
     one, _ = lib.recon(data, adjoint=True, golden_angle=0, **flags)
-    assert np.array_equal(got, one)
+    assert rel_l2(got, one) <= 2e-6
     want, _ = oracle.recon(data, adjoint=1, golden=0, **flags)
     assert rel_l2(got, want) <= 1e-5

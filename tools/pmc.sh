@@ -5,8 +5,11 @@ i=0
 for pass in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_THREAD_CYCLES_VALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_ANY"; do
   i=$((i+1)); rocprofv3 --pmc $pass --kernel-trace -d $out/p$i --output-format csv -- python3 $R/"$@" > $out/p$i.log 2>&1
 done
-python3 - <<PY
-import csv,glob,collections
+python3 - <<PY | tee $out/summary.txt
+import csv,glob,collections,sys
+sys.path.insert(0,'$R')
+from tron_amd.buildinfo import kernel_source_hash
+print('kernel sources', kernel_source_hash(), '| command: $*')
 agg=collections.defaultdict(lambda: collections.defaultdict(float)); dur=collections.defaultdict(float); calls=collections.Counter()
 for f in glob.glob('$out/p*/*/*_counter_collection.csv'):
     seen=set()

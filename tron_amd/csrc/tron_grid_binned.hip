@@ -37,12 +37,17 @@ struct BinCfg {
     static constexpr int CELLW = NCELL + 1;                  // + sentinel column
     static constexpr int NCELLS = NCELL * CELLW;
     static constexpr int CPT = (NCELLS + kBinThreads - 1) / kBinThreads;   // cells per thread in the scan
-    // records per batch, sized so a workgroup stays near 48 KiB of LDS
+    // records per batch.  8 coils need 167 VGPRs = 3 waves per SIMD, so three 48 KiB workgroups per CU and the largest
+    // batches that allows; with fewer coils the kernel fits 4 waves per SIMD and a FOURTH workgroup per CU (<= 40 KiB)
+    // beats larger batches (measured on one box, gridding us per coil-slice, 36 KiB of records -> this:
+    // 4 coils 3.51 -> 3.13, 2 coils 5.96 -> 5.45, 1 coil 11.1 -> 9.9; 8 coils at 24/28 KiB: 2.28 -> 2.45)
     static constexpr int REC_BYTES = 2 * NWP * 4 + CPB * 8 + 4 + 4 + 1;
-#ifndef TRON_BIN_REC_KB
-#define TRON_BIN_REC_KB 36
+#ifdef TRON_BIN_REC_KB
+    static constexpr int REC_KB = TRON_BIN_REC_KB;
+#else
+    static constexpr int REC_KB = CPB >= 8 ? 36 : (CPB >= 2 ? 24 : 28);
 #endif
-    static constexpr int NREC_RAW = (TRON_BIN_REC_KB * 1024) / REC_BYTES;
+    static constexpr int NREC_RAW = (REC_KB * 1024) / REC_BYTES;
     static constexpr int NREC = NREC_RAW >= 512 ? 512 : (NREC_RAW / 64) * 64;
     static constexpr int SLOT = 64;                          // longest spoke segment through tile + halo
 };
