@@ -4,6 +4,8 @@
                                            compiled unmodified into oracle/_ref) from seeded arrays
   half_vectors.npz                         float32/float64 bit patterns and the half bits the REFERENCE's
                                            src/float16.cu returns for them; all 65536 half->float results
+  cgnr_*.ra / walsh_*.ra / nt_*.ra         (round 2) the same for CGNR (src/tron.cu:665-720 as restated in oracle/), the Walsh
+                                           coil combination (:222-302) and nt > 1 -- written by `make_golden.py round2`
   adj_*.ra / fwd_*.ra                      seeded inputs and the outputs of the CPU oracle (oracle/), i.e.
                                            regression vectors for the grid/degrid path.  The reference holds
                                            no golden vectors for this path and src/tron.cu cannot be built here
@@ -34,7 +36,26 @@ def ref_write(path, arr, eltype, elbyte):
     assert R.ra_write(ctypes.byref(a), path.encode()) == 0
 
 
+def round2():
+    """Fixtures of the round-2 features; the round-1 files are left untouched."""
+    img = synth.image(2, 16, seed=911)
+    kdata, p = pyoracle.recon(img, 0, golden=1)                      # consistent k-space: CGNR has something to converge to
+    kdata = np.asfortranarray(kdata.reshape((2, 1, p.nro, p.npe1work, 1), order="F"))
+    cases = {
+        "cgnr3_ga_nc2": (kdata, lambda d: pyoracle.recon_cgnr(d, 3, golden=1)[0]),
+        "walsh_ga_nc4": (synth.kspace(4, 32, 30, seed=912), lambda d: pyoracle.recon_combine(d, 1, 1, golden=1)[0]),
+        "nt2_ga_nc2": (synth.kspace(2, 32, 44, seed=913, nt=2), lambda d: pyoracle.recon_combine(d, 0, golden=1, data_undersamp=0.5, prof_slide=14)[0]),
+    }
+    for name, (data, fn) in cases.items():
+        out = fn(data)
+        ra.write(os.path.join(HERE, name + "_in.ra"), data)
+        ra.write(os.path.join(HERE, name + "_out.ra"), out)
+        print(name, data.shape, "->", out.shape)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "round2":
+        return round2()
     assert pyoracle.have_ref(), "build oracle/_ref first (make -C oracle)"
     R = pyoracle.ref()
     ref_write(os.path.join(HERE, "ref_written_c64.ra"), synth.kspace(2, 8, 5, seed=901), 4, 8)

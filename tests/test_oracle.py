@@ -176,3 +176,50 @@ def test_adjoint_is_a_nufft(oracle):
     # r = 0 is visited twice by the reference near the centre (Q2): allow for it loosely
     err = rel_l2(img * nxos * nxos / (nxos * nxos), exact)
     assert err < 0.05, err
+
+
+# ----------------------------------------------------------------------------- round 2: CGNR, Walsh, nt > 1 (properties)
+
+def test_cgnr_restatement_properties(oracle):
+    """The oracle's CGNR (src/tron.cu:665-720 as Knopp et al. 2007 Alg. 1 intends it): zero iterations are the plain
+    adjoint (:754-757) and the density-weighted residual of A x_k falls with every iteration on consistent data."""
+    img = synth.image(2, 16, seed=41)
+    data, p = oracle.recon(img, adjoint=0, golden=1)
+    data = np.asfortranarray(data.reshape((2, 1, p.nro, p.npe1work, 1), order="F"))
+    adj, _ = oracle.recon(data, adjoint=1, golden=1)
+    assert np.array_equal(oracle.recon_cgnr(data, 0, golden=1)[0], adj)
+    nro, npe = p.nro, p.npe1work
+    w = (2.0 - 2.0 / npe) / nro * np.abs(np.arange(nro) - nro // 2) + 1.0 / npe          # src/tron.cu:408-412
+    import ctypes
+    L = oracle.lib()
+    pp = oracle.make_params(data.shape, 1, golden=1)
+    res = []
+    for k in (1, 2, 4, 8):
+        x = np.zeros(2 * 16 * 16, np.complex64)                 # coil images [nchan*id + c] (before the root-sum-of-squares)
+        L.oracle_cgnr_radial2d.restype = None
+        L.oracle_cgnr_radial2d.argtypes = [ctypes.POINTER(oracle.OracleParams), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        flat = np.asfortranarray(data).reshape(-1, order="F")
+        L.oracle_cgnr_radial2d(ctypes.byref(pp), x.ctypes.data, flat.ctypes.data, 0, k, 0)
+        xi = np.transpose(x.reshape(16, 16, 2), (2, 1, 0)).reshape((2, 1, 16, 16, 1), order="F")
+        y, _ = oracle.recon(xi, adjoint=0, golden=1)
+        r = (y.reshape(data.shape, order="F") - data)[:, 0, :, :, 0]
+        res.append(float(np.sqrt(np.sum(w[None, :, None] * np.abs(r) ** 2))))
+    assert all(b < a for a, b in zip(res, res[1:])), res
+
+
+def test_walsh_and_repetition_restatements(oracle):
+    """coilcombinewalsh (src/tron.cu:270-302): with a one-pixel patch the coil covariance is rank one, its dominant
+    eigenvector is the normalised coil vector, so |walsh| = root-sum-of-squares; nt = T equals T separate nt = 1 runs."""
+    data = synth.kspace(4, 32, 30, seed=42)
+    sos, _ = oracle.recon(data, adjoint=1, golden=1)
+    w0, _ = oracle.recon_combine(data, 1, 0, golden=1)
+    assert rel_l2(np.abs(w0), np.abs(sos)) < 1e-5
+    w1, _ = oracle.recon_combine(data, 1, 1, golden=1)
+    assert rel_l2(np.abs(w1), np.abs(sos)) > 1e-3
+    assert np.array_equal(oracle.recon_combine(data, 0, golden=1)[0], sos)
+    d2 = synth.kspace(2, 32, 30, seed=43, nt=3)
+    out, p = oracle.recon_combine(d2, 0, golden=1)
+    assert out.shape == (1, 3, 16, 16, 1) and p.nt == 3
+    for t in range(3):
+        one, _ = oracle.recon(np.asfortranarray(d2[:, t:t + 1]), adjoint=1, golden=1)
+        assert np.array_equal(out[0, t], one[0, 0])

@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(kDgThreads) degrid_tile_kernel(const DegridPar
     const float by_lo = (float)ty0 - eps, by_hi = (float)(ty0 + kDgTile) + eps;
     float2 *dst = p.nudata + (size_t)k * p.nro * p.npe * p.nrep;
 
-    for (int round0 = 0; round0 < p.npe && p.debug < 2; round0 += kDgMaxSpokes) {
+    for (int round0 = 0; round0 < p.npe && TRON_DBG_LT(p, 2); round0 += kDgMaxSpokes) {
         // ---- clip: thread = spoke; X(ro) = n*(ro/nro - 1/2)*sin + half, Y likewise with cos ----------
         if (tid == 0) L.sp_start[0] = 0;
         int nacc = 0;
@@ -194,7 +194,7 @@ __global__ void __launch_bounds__(kDgThreads) degrid_tile_kernel(const DegridPar
         // ---- samples, dealt out flat over the 256 threads -------------------------------------------
         // (keeping the tile loads in flight across the first clip round was tried: the registers it pins cost more
         //  than the exposed latency, 2.78 -> 2.91 us per coil image)
-        for (int rec = tid; rec < nrec && p.debug < 1; rec += kDgThreads) {
+        for (int rec = tid; rec < nrec && TRON_DBG_LT(p, 1); rec += kDgThreads) {
             // spoke holding record `rec`: largest s with sp_start[s] <= rec
             int lo;
             if (mapped) {

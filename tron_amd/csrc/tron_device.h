@@ -9,6 +9,14 @@
 
 namespace tron {
 
+// Timing-bisection knob (TRON_DEBUG_SKIP, tools/bisect.sh): compiled in only with -DTRON_DEBUG_KNOBS
+// (tools/build_variants.sh debug:"-DTRON_DEBUG_KNOBS"); production kernels carry no debug branches.
+#ifdef TRON_DEBUG_KNOBS
+#define TRON_DBG_LT(p, n) ((p).debug < (n))
+#else
+#define TRON_DBG_LT(p, n) true
+#endif
+
 // ------------------------------------------------------------------------- Kaiser-Bessel
 
 // src/tron.cu:304-321, op for op: the coefficient literals are doubles, so both Horner chains
@@ -74,6 +82,18 @@ __device__ __forceinline__ v2f kb_weight_fast2(const v2f x, const KbCoef &k)
     if (!(fabsf(x.x) < k.W)) acc.x = 0.0f;
     if (!(fabsf(x.y) < k.W)) acc.y = 0.0f;
     return acc;
+}
+
+// streaming (non-temporal) 8-byte load / store: data that is touched once
+__device__ __forceinline__ float2 ld_nt(const float2 *p)
+{
+    const v2f v = __builtin_nontemporal_load(reinterpret_cast<const v2f *>(p));
+    return make_float2(v.x, v.y);
+}
+__device__ __forceinline__ void st_nt(float2 *p, const float2 a)
+{
+    const v2f v = {a.x, a.y};
+    __builtin_nontemporal_store(v, reinterpret_cast<v2f *>(p));
 }
 
 __device__ __forceinline__ float safe_rcp(float c)

@@ -81,7 +81,13 @@ __device__ __forceinline__ void store_point_pair(const GridParams &p, int z, int
     const bool pair = (X0 + 1 + h < n) && p.out_p == 1 && (colA & 1) == 0;
     float2 *o = p.udata + (size_t)z * p.out_z + ((size_t)row * n + colA) * p.out_p + (size_t)c * p.out_c;
     if (pair && (n & 1) == 0) {
+#ifdef TRON_BIN_NT_STORE
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const v4f t = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(t, reinterpret_cast<v4f *>(o));
+#else
         *reinterpret_cast<float4 *>(o) = v;
+#endif
     } else {
         if (X0 + h < n) o[0] = make_float2(v.x, v.y);
         if (X0 + 1 + h < n) {
@@ -172,7 +178,7 @@ grid_binned_kernel(const GridParams p)
     const float by_lo = (float)y0 - p.W - eps, by_hi = (float)(y0 + kBinTile - 1) + p.W + eps;
     const int cx0 = x0 - CW, cy0 = y0 - CW;                     // base cell (0,0) of the histogram
 
-    for (int round0 = pe_lo; round0 < pe_hi && p.debug < 4; round0 += kBinMaxSpokes) {
+    for (int round0 = pe_lo; round0 < pe_hi && TRON_DBG_LT(p, 4); round0 += kBinMaxSpokes) {
         // ---- clip: one thread per spoke, accepted spokes compacted in acquisition order ---------
         if (tid == 0) L.sp_start[0] = 0;
         int nacc = 0;                                           // accepted so far in this round (uniform)
@@ -314,11 +320,11 @@ grid_binned_kernel(const GridParams p)
         __syncthreads();
 #endif
         int sp0 = 0, sp1 = 0;
-        if (nacc > 0 && p.debug < 3) {
+        if (nacc > 0 && TRON_DBG_LT(p, 3)) {
             sp1 = batch_end(0);
-            if (p.debug < 2) prefetch(0, sp1);
+            if (TRON_DBG_LT(p, 2)) prefetch(0, sp1);
         }
-        while (sp0 < nacc && p.debug < 3) {
+        while (sp0 < nacc && TRON_DBG_LT(p, 3)) {
             const int rec_base = L.sp_start[sp0];
             const int nrec = L.sp_start[sp1] - rec_base;
 
@@ -331,7 +337,7 @@ grid_binned_kernel(const GridParams p)
 #pragma unroll
             for (int j = 0; j < RPT; ++j) {
                 const int rec = tid + j * kBinThreads;
-                if (rec >= nrec || p.debug >= 2) continue;
+                if (rec >= nrec || !TRON_DBG_LT(p, 2)) continue;
                 const int pe = pf_pe[j], r = pf_r[j];
                 const float2 cs = trig[pe];
                 const float kx = (float)r * cs.x;                     // src/tron.cu:514-515
@@ -400,7 +406,7 @@ grid_binned_kernel(const GridParams p)
             int nsp1 = nsp0;
             if (nsp0 < nacc) {
                 nsp1 = batch_end(nsp0);
-                if (p.debug < 2) prefetch(nsp0, nsp1);
+                if (TRON_DBG_LT(p, 2)) prefetch(nsp0, nsp1);
             }
             __syncthreads();
 
@@ -459,7 +465,7 @@ grid_binned_kernel(const GridParams p)
 #endif
             // ---- D. apply: each thread walks the 2CW+1 cell rows its 2x2 points can see as ONE loop
             //         (row ranges concatenated), so a wave runs max-over-lanes(total), not sum of row maxima
-            if (p.debug < 1) {
+            if (TRON_DBG_LT(p, 1)) {
                 constexpr int NR = 2 * CW + 1;
                 int delta[NR], cum[NR + 1];
                 cum[0] = 0;
