@@ -19,6 +19,16 @@ def test_random_shapes_fast_vs_exact_vs_oracle(oracle):
     assert worst <= 1e-5
 
 
+def test_random_shapes_round2_features_vs_oracle(oracle):
+    """CGNR, Walsh combination, nt > 1, chunked / pinned host pipeline on random shapes, against the oracle."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("tron_fuzz", os.path.join(root, "tests", "fuzz_shapes.py"))
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    worst, failures = fuzz.run2(48, 20261003, verbose=False)
+    assert not failures, failures
+
+
 def test_tiny_problem_sizes(oracle):
     """Readouts of 2..8 samples and images of 1..5 pixels: grids far smaller than one tile, single spokes."""
     import numpy as np

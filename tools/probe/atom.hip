@@ -20,6 +20,8 @@ __global__ void k(float* out, int iters)
         if (MODE == 4) acc += tile[idx];
         if (MODE == 5) tile[idx] = acc + it;
         if (MODE == 6) atomicMax(&ut[idx], (unsigned)it);
+        if (MODE == 7) atomicAdd(&((unsigned long long*)tile)[idx >> 1], (unsigned long long)(long long)(it - 1000));   // ds_add_u64
+        if (MODE == 8) { atomicAdd(&ut[idx], 1u); atomicAdd(&ut[(idx + 1056) % (64 * 33)], 2u); }                       // two ds_add_u32
     }
     __syncthreads();
     float s = acc;
@@ -42,5 +44,6 @@ int main()
     float* d; hipMalloc(&d, 4);
     run<0>("ds_add_f32", d); run<1>("ds_add_u32", d); run<2>("ds_add_rtn_u32", d);
     run<3>("read+add+write", d); run<4>("ds_read_b32", d); run<5>("ds_write_b32", d); run<6>("ds_max_u32", d);
+    run<7>("ds_add_u64", d); run<8>("2 x ds_add_u32", d);
     return 0;
 }
