@@ -172,30 +172,33 @@ __global__ void __launch_bounds__(256) fft512_rows_kernel(const Fft512Params p)
 }
 
 // grid = (256/16, nslices); block = 256.  Column FFTs + crop + deapodise + root-sum-of-squares.
-__global__ void __launch_bounds__(256) fft512_cols_post_kernel(const Fft512Params p)
+// SINGLE (one channel): the deapodised complex image passes through (src/tron.cu:265-266).  Otherwise only sum |.|^2 is
+// carried across the coils and the (positive) deapodisation factor is applied once at the end, sqrt(sum |v|^2) / w =
+// sqrt(sum |v / w|^2) up to fp32 rounding: 16 accumulators instead of 16 + 16 factors + 32 pass-through values per
+// thread took the kernel from 182 VGPRs (2 waves per SIMD) to 4 waves per SIMD.
+#ifndef TRON_FFT_COLS_WAVES
+#define TRON_FFT_COLS_WAVES 3
+#endif
+template <bool SINGLE>
+__global__ void __launch_bounds__(256, TRON_FFT_COLS_WAVES) fft512_cols_post_kernel(const Fft512Params p)
 {
     __shared__ float2 s_t[kFKeep * (kLinesPerWg + 1)];     // [kept row][col in block]; the exchange regions until then
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int z = blockIdx.y;
     const int col0 = blockIdx.x * kLinesPerWg;
     float2 *xch = s_t + wave * kXch;
-    float inv[4][4];
     float val[4][4];
-    float2 single[4][4];
+    float2 single[SINGLE ? 4 : 1][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
-            const int j2 = jj < 2 ? jj : jj + 4;
-            const int rowc = crop_index(lane + 64 * j2);
-            inv[j][jj] = p.inv_deapod[rowc * kFKeep + col0 + wave * 4 + j];   // src/tron.cu:398-400
             val[j][jj] = 0.f;
-            single[j][jj] = make_float2(0.f, 0.f);
+            if (SINGLE) single[j][jj] = make_float2(0.f, 0.f);
         }
     // software pipeline over the nchan x 4 lines of this wave: line i+1 is in flight while line i is transformed
     const float2 *base = p.in + (size_t)z * p.nchan * (size_t)kFKeep * kF + (size_t)(col0 + wave * 4) * kF;
     float2 nxt[8];
-#pragma unroll
     // the intermediate is written once by pass 1 and read once here: streaming (non-temporal) accesses on both sides took
     // the two passes from 1.160 to 1.104 us per coil-slice (same-box A/B; the loads 2.5 %, the stores 2.5 %);
     // non-temporal loads of the gridded data in pass 1 gained nothing
@@ -204,6 +207,7 @@ __global__ void __launch_bounds__(256) fft512_cols_post_kernel(const Fft512Param
 #else
 #define TRON_COLS_LD(ptr) (*(ptr))
 #endif
+#pragma unroll
     for (int q = 0; q < 8; ++q) nxt[q] = TRON_COLS_LD(&base[q * 64 + lane]);
     for (int c = 0; c < p.nchan; ++c) {
 #pragma unroll
@@ -223,10 +227,9 @@ __global__ void __launch_bounds__(256) fft512_cols_post_kernel(const Fft512Param
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
                 const int j2 = jj < 2 ? jj : jj + 4;
-                float2 u = v[j2];
-                u.x *= inv[j][jj]; u.y *= inv[j][jj];
-                val[j][jj] += u.x * u.x + u.y * u.y;                          // src/tron.cu:262
-                single[j][jj] = u;
+                const float2 u = v[j2];
+                if (SINGLE) single[j][jj] = u;
+                else val[j][jj] += u.x * u.x + u.y * u.y;                     // src/tron.cu:262 (the factor 1/w^2 is applied below)
             }
         }
     }
@@ -237,7 +240,9 @@ __global__ void __launch_bounds__(256) fft512_cols_post_kernel(const Fft512Param
         for (int jj = 0; jj < 4; ++jj) {
             const int j2 = jj < 2 ? jj : jj + 4;
             const int rowc = crop_index(lane + 64 * j2);
-            const float2 o = p.nchan > 1 ? make_float2(sqrtf(val[j][jj]), 0.f) : single[j][jj];   // src/tron.cu:259-266
+            const float inv = p.inv_deapod[rowc * kFKeep + col0 + wave * 4 + j];   // src/tron.cu:398-400
+            const float2 o = SINGLE ? make_float2(single[j][jj].x * inv, single[j][jj].y * inv)     // src/tron.cu:259-266
+                                    : make_float2(sqrtf(val[j][jj]) * inv, 0.f);
             s_t[rowc * (kLinesPerWg + 1) + wave * 4 + j] = o;
         }
     __syncthreads();
@@ -258,7 +263,10 @@ hipError_t launch_fft512_adjoint(const float2 *grid, float2 *tmp, float2 *out, c
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     p.in = tmp;
-    hipLaunchKernelGGL(fft512_cols_post_kernel, dim3(kFKeep / kLinesPerWg, nslices), dim3(256), 0, s, p);
+    if (nchan == 1)
+        hipLaunchKernelGGL(fft512_cols_post_kernel<true>, dim3(kFKeep / kLinesPerWg, nslices), dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL(fft512_cols_post_kernel<false>, dim3(kFKeep / kLinesPerWg, nslices), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 

@@ -27,7 +27,10 @@ namespace tron {
 
 constexpr int kBinTile = 32;
 constexpr int kBinThreads = 256;
-constexpr int kBinMaxSpokes = 512;   // accepted spokes kept per clip round
+#ifndef TRON_BIN_MAXSPOKES
+#define TRON_BIN_MAXSPOKES 512
+#endif
+constexpr int kBinMaxSpokes = TRON_BIN_MAXSPOKES;   // accepted spokes kept per clip round
 
 template <int CPB, int CW>
 struct BinCfg {
