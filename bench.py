@@ -360,8 +360,9 @@ def main():
             # the timed path produced real images: spot-check the first and the last slice of this rank against the oracle
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             from oracle import pyoracle
+            pyoracle.set_threads(max(1, (os.cpu_count() or 1) // world))      # torchrun exports OMP_NUM_THREADS=1
             err = 0.0
-            for z in sorted({0, nz - 1}):
+            for z in sorted({0, nz - 1} if world == 1 else {0}):
                 lo = 2 * nc * NRO * NPE * z
                 host = kspace[lo: lo + 2 * nc * NRO * NPE].float().cpu().numpy().view(np.complex64).reshape((nc, 1, NRO, NPE, 1), order="F")
                 want, _ = pyoracle.recon(host, adjoint=1, golden=golden, data_undersamp=undersamp, prof_slide=NPE, skip_angles=(zfirst + z) * NPE)

@@ -1,7 +1,8 @@
 /* Minimal C99 client of the C ABI (include/tron_hip.h, include/rawarray.h): what a TRON maintainer's
    main() does after getopt -- read a .ra file, run recon_radial2d's replacement, write a .ra file.
      gcc -std=c99 -Iinclude examples/recon_c_abi.c -Ltron_amd/lib -ltronhip -Wl,-rpath,$PWD/tron_amd/lib -o recon_c_abi
-     ./recon_c_abi -a in.ra out.ra        (adjoint, golden angle)      ./recon_c_abi in.ra out.ra   (forward) */
+     ./recon_c_abi -a in.ra out.ra        (adjoint, golden angle)      ./recon_c_abi in.ra out.ra   (forward)
+     ./recon_c_abi -a -i 3 in.ra out.ra   (CGNR, 3 iterations)         ./recon_c_abi -a -m in.ra out.ra   (every GPU of the node) */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -11,10 +12,16 @@
 
 int main(int argc, char **argv)
 {
-    int adjoint = 0, arg = 1;
-    if (argc > 1 && strcmp(argv[1], "-a") == 0) { adjoint = 1; arg = 2; }
+    int adjoint = 0, arg = 1, niter = 0, multi = 0;
+    while (arg < argc && argv[arg][0] == '-') {
+        if (strcmp(argv[arg], "-a") == 0) adjoint = 1;
+        else if (strcmp(argv[arg], "-m") == 0) multi = 1;          /* tron_recon_radial2d_multi: one worker + plan per GPU */
+        else if (strcmp(argv[arg], "-i") == 0 && arg + 1 < argc) niter = atoi(argv[++arg]);
+        else break;
+        ++arg;
+    }
     if (argc - arg < 2) {
-        fprintf(stderr, "usage: %s [-a] in.ra out.ra\n", argv[0]);
+        fprintf(stderr, "usage: %s [-a] [-i niter] [-m] in.ra out.ra\n", argv[0]);
         return 1;
     }
     ra_t in, out;
@@ -27,9 +34,10 @@ int main(int argc, char **argv)
     tron_config_default(&cfg);            /* the reference's defaults, src/tron.cu:58-87 */
     cfg.adjoint = adjoint;
     cfg.golden_angle = 1;
+    cfg.niter = niter;                    /* > 0: CGNR, src/tron.cu:754-755 */
     tron_dims dims;
     tron_plan *plan = NULL;
-    if (tron_derive_dims(&cfg, in.dims, &dims) != TRON_OK || tron_plan_create(&plan, &cfg, &dims) != TRON_OK) {
+    if (tron_derive_dims(&cfg, in.dims, &dims) != TRON_OK || (!multi && tron_plan_create(&plan, &cfg, &dims) != TRON_OK)) {
         fprintf(stderr, "%s\n", tron_last_error());
         return 1;
     }
@@ -41,7 +49,8 @@ int main(int argc, char **argv)
     out.dims = (uint64_t *)malloc(5 * sizeof(uint64_t));
     out.data = (uint8_t *)calloc(dims.out_bytes ? dims.out_bytes : 1, 1);
     memcpy(out.dims, dims.out_dims, 5 * sizeof(uint64_t));
-    if (tron_recon_radial2d(plan, (tron_float2 *)out.data, (const tron_float2 *)in.data) != TRON_OK) {
+    if ((multi ? tron_recon_radial2d_multi(&cfg, &dims, NULL, 0, (tron_float2 *)out.data, (const tron_float2 *)in.data)
+               : tron_recon_radial2d(plan, (tron_float2 *)out.data, (const tron_float2 *)in.data)) != TRON_OK) {
         fprintf(stderr, "%s\n", tron_last_error());
         return 1;
     }

@@ -74,6 +74,16 @@ def lib():
     return _lib
 
 
+def set_threads(n: int) -> None:
+    """OpenMP threads of the oracle's parallel loops from here on (launchers such as torchrun export OMP_NUM_THREADS=1,
+    which would make a metric-size check take minutes)."""
+    lib()
+    try:
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(max(1, int(n)))
+    except OSError:
+        pass
+
+
 def _c64(a):
     a = np.ascontiguousarray(a, dtype=np.complex64)
     return a

@@ -404,7 +404,14 @@ def test_c_client_matches_the_tron_binary(tmp_path):
     inp, o1, o2 = (str(tmp_path / n) for n in ("in.ra", "c.ra", "t.ra"))
     ra.write(inp, data)
     assert subprocess.run([exe, "-a", inp, o1]).returncode == 0
-    assert subprocess.run([os.path.join(root, "tron_amd", "bin", "tron"), "-a", "-G", inp, o2]).returncode == 0
+    tron = os.path.join(root, "tron_amd", "bin", "tron")
+    assert subprocess.run([tron, "-a", "-G", inp, o2]).returncode == 0
+    assert open(o1, "rb").read() == open(o2, "rb").read()
+    # the multi-GPU entry point (every visible device) and CGNR through the same client
+    assert subprocess.run([exe, "-a", "-m", inp, o1]).returncode == 0
+    assert open(o1, "rb").read() == open(o2, "rb").read()
+    assert subprocess.run([exe, "-a", "-i", "2", inp, o1]).returncode == 0
+    assert subprocess.run([tron, "-a", "-G", "-i", "2", inp, o2]).returncode == 0
     assert open(o1, "rb").read() == open(o2, "rb").read()
 
 
