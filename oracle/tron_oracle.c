@@ -527,10 +527,118 @@ void oracle_nufft_adj_radial2d(const oracle_params *p, cfloat *d_out, cfloat *d_
     oracle_deapod(d_out, p->nx, nchan, p->kernwidth, p->gridos);
 }
 
+/* ------------------------------------------------------------------ non-square forward transform
+ *
+ * "TODO: implement non-square images" (tron.cu:945): the reference derives nyos = ny*gridos (:944) and plans a
+ * nxos x nyos FFT (:599-602), but every kernel of tron_nufft_radial2d takes ONE size (:642-647), so an image with
+ * ny != nx is read as nx x nx -- undefined for ny < nx.  This is the definition the tests and the HIP path share:
+ * the square pipeline with every row-axis quantity taken from ny / nyos and every column-axis quantity from nx / nxos.
+ * Image, grid: [row][col] with `rows` rows of `cols` columns (the .ra's dims[3] = ny rows, dims[2] = nx columns); rows
+ * <-> the sine axis, columns <-> the cosine axis, as in the square case.  nro = gridos*nx stays (:945).
+ */
+static void pad_rect(cfloat *dst, int rdst, int cdst, const cfloat *src, int rsrc, int csrc, int nchan)      /* tron.cu:435-457 */
+{
+    const int wr = rdst > rsrc ? (rdst - rsrc) / 2 : 0, wc = cdst > csrc ? (cdst - csrc) / 2 : 0;
+    for (int id = 0; id < rdst*cdst; ++id) {
+        for (int c = 0; c < nchan; ++c) { dst[(size_t)nchan*id + c].x = 0.f; dst[(size_t)nchan*id + c].y = 0.f; }
+        int xdst = id / cdst, ydst = id % cdst;
+        if ((xdst - wr > 0) && (xdst - wr < rsrc) && (ydst - wc > 0) && (ydst - wc < csrc)) {      /* strict > 0: Q8 */
+            size_t srcid = (size_t)(xdst - wr)*csrc + (ydst - wc);
+            for (int c = 0; c < nchan; ++c) dst[(size_t)nchan*id + c] = src[(size_t)nchan*srcid + c];
+        }
+    }
+}
+
+float oracle_deapod_weight_rect(size_t id, int rows, int cols, float m, float sigma)                          /* tron.cu:393-400 */
+{
+    float x = id / (float)cols - (rows + 1) / 2;           /* fractional row coordinate: Q7 */
+    float y = (float)(id % cols) - (cols + 1) / 2;
+    return oracle_gridkernelhat(x * (1.f / rows / sigma), m, sigma) * oracle_gridkernelhat(y * (1.f / cols / sigma), m, sigma);
+}
+
+static void deapod_rect(cfloat *a, int rows, int cols, int nrep, float m, float sigma)
+{
+    for (size_t id = 0; id < (size_t)rows*cols; ++id) {
+        float wgt = oracle_deapod_weight_rect(id, rows, cols, m, sigma);
+        float inv = 1.0f / (wgt > 0.f ? wgt : 1.f);
+        for (int c = 0; c < nrep; ++c) { a[(size_t)nrep*id + c].x *= inv; a[(size_t)nrep*id + c].y *= inv; }
+    }
+}
+
+static void fftshift_rect(cfloat *dst, const cfloat *src, int rows, int cols, int nchan, int direction)      /* tron.cu:161-178 */
+{
+    int offr = direction == 0 ? rows/2 : rows - rows/2, offc = direction == 0 ? cols/2 : cols - cols/2;
+    for (int idsrc = 0; idsrc < rows*cols; ++idsrc) {
+        int xdst = (idsrc / cols + offr) % rows, ydst = (idsrc % cols + offc) % cols;
+        for (int c = 0; c < nchan; ++c) dst[((size_t)cols*xdst + ydst)*nchan + c] = src[(size_t)idsrc*nchan + c];
+    }
+}
+
+static void fft2_rect(cfloat *dst, const cfloat *src, int rows, int cols, int nchan, int sign)
+{
+    const int nmax = rows > cols ? rows : cols;
+    double *wrr = (double*)malloc(sizeof(double)*rows), *wir = (double*)malloc(sizeof(double)*rows);
+    double *wrc = (double*)malloc(sizeof(double)*cols), *wic = (double*)malloc(sizeof(double)*cols);
+    for (int k = 0; k < rows; ++k) { wrr[k] = cos(2*M_PI*k/rows); wir[k] = sin(2*M_PI*k/rows); }
+    for (int k = 0; k < cols; ++k) { wrc[k] = cos(2*M_PI*k/cols); wic[k] = sin(2*M_PI*k/cols); }
+    for (int c = 0; c < nchan; ++c) {
+        double *are = (double*)malloc(sizeof(double)*(size_t)rows*cols), *aim = (double*)malloc(sizeof(double)*(size_t)rows*cols);
+        double *lr = (double*)malloc(sizeof(double)*nmax), *li = (double*)malloc(sizeof(double)*nmax);
+        double *tr = (double*)malloc(sizeof(double)*nmax), *ti = (double*)malloc(sizeof(double)*nmax);
+        for (size_t i = 0; i < (size_t)rows*cols; ++i) { are[i] = src[i*nchan + c].x; aim[i] = src[i*nchan + c].y; }
+        for (int row = 0; row < rows; ++row) dft_line(are + (size_t)row*cols, aim + (size_t)row*cols, cols, sign, wrc, wic, tr, ti);
+        for (int col = 0; col < cols; ++col) {
+            for (int row = 0; row < rows; ++row) { lr[row] = are[(size_t)row*cols + col]; li[row] = aim[(size_t)row*cols + col]; }
+            dft_line(lr, li, rows, sign, wrr, wir, tr, ti);
+            for (int row = 0; row < rows; ++row) { are[(size_t)row*cols + col] = lr[row]; aim[(size_t)row*cols + col] = li[row]; }
+        }
+        for (size_t i = 0; i < (size_t)rows*cols; ++i) { dst[i*nchan + c].x = (float)are[i]; dst[i*nchan + c].y = (float)aim[i]; }
+        free(are); free(aim); free(lr); free(li); free(tr); free(ti);
+    }
+    free(wrr); free(wir); free(wrc); free(wic);
+}
+
+static void degrid_rect(cfloat *nudata, const cfloat *udata, int rows, int cols, int nrep, int nro, int npe, float W,      /* tron.cu:540-577 */
+                        float gridos, int skip_angles, int golden)
+{
+    for (int id = 0; id < nro*npe; ++id) {
+        for (int c = 0; c < nrep; ++c) { nudata[(size_t)nrep*id + c].x = 0.f; nudata[(size_t)nrep*id + c].y = 0.f; }
+        int pe = id / nro, ro = id % nro;
+        float R = (float)ro/(float)nro - 0.5f;
+        float T = oracle_degrid_angle(pe, npe, skip_angles, golden);
+        float X, Y;
+        sincosf(T, &X, &Y);
+        X = rows*R*X + (rows + 1)/2;                       /* row coordinate: the sine axis */
+        Y = cols*R*Y + (cols + 1)/2;                       /* column coordinate: the cosine axis */
+        for (int xu = ceilf(X-W); xu <= (X+W); ++xu) {
+            float wgtx = oracle_gridkernel(xu-X, W, gridos);
+            for (int yu = ceilf(Y-W); yu <= (Y+W); ++yu) {
+                float wgt = wgtx * oracle_gridkernel(yu-Y, W, gridos);
+                int i = ((xu % rows) + rows) % rows;       /* periodic wrap; the reference's (xu + n) % n for |xu| < n */
+                int j = ((yu % cols) + cols) % cols;
+                size_t offset = (size_t)nrep*((size_t)i*cols + j);
+                for (int c = 0; c < nrep; ++c) {
+                    nudata[(size_t)nrep*id + c].x += udata[offset + c].x * wgt;
+                    nudata[(size_t)nrep*id + c].y += udata[offset + c].y * wgt;
+                }
+            }
+        }
+    }
+}
+
 /* tron.cu:639-649 */
 void oracle_nufft_radial2d(const oracle_params *p, cfloat *d_out, cfloat *d_in)
 {
     const int nchan = p->nc * p->nt;
+    if (p->nx != p->ny) {                                  /* rows = ny / nyos, columns = nx / nxos */
+        pad_rect(d_out, p->nyos, p->nxos, d_in, p->ny, p->nx, nchan);
+        deapod_rect(d_out, p->nyos, p->nxos, nchan, p->kernwidth, 1.f);
+        fftshift_rect(d_in, d_out, p->nyos, p->nxos, nchan, 0);
+        fft2_rect(d_out, d_in, p->nyos, p->nxos, nchan, -1);
+        fftshift_rect(d_in, d_out, p->nyos, p->nxos, nchan, 1);
+        degrid_rect(d_out, d_in, p->nyos, p->nxos, nchan, p->nro, p->npe1work, p->kernwidth, p->gridos, p->skip_angles, p->golden_angle);
+        return;
+    }
     oracle_pad(d_out, p->nxos, d_in, p->nx, nchan);
     oracle_deapod(d_out, p->nxos, nchan, p->kernwidth, 1.f);
     oracle_fftshift(d_in, d_out, p->nxos, nchan, 0 /* FORWARD */);

@@ -148,3 +148,22 @@ def test_linear_angle_slices_share_one_gridding_pass(oracle, monkeypatch, nc, nr
     assert rel_l2(got, one) <= 2e-6
     want, _ = oracle.recon(data, adjoint=1, golden=0, **flags)
     assert rel_l2(got, want) <= 1e-5
+
+
+@pytest.mark.parametrize("kb", [lib.KB_FAST, lib.KB_EXACT])
+@pytest.mark.parametrize("nc,nx,ny,flags", [
+    (1, 16, 12, dict(golden_angle=1, data_undersamp=0.75)),
+    (2, 12, 20, dict(golden_angle=0)),
+    (2, 48, 32, dict(golden_angle=1, data_undersamp=0.5, kernwidth=2.5, gridos=1.5)),
+    (1, 256, 128, dict(golden_angle=1, data_undersamp=0.1)),          # 512 x 256 grid: the rocFFT path, not the fused 512^2 one
+])
+def test_forward_non_square_images(oracle, nc, nx, ny, flags, kb):
+    """The reference's "TODO: implement non-square images" (src/tron.cu:945), forward direction: rows (ny, sine axis) and
+    columns (nx, cosine axis) with their own grid sizes; the oracle's definition is checked against a DTFT on the CPU."""
+    img = synth.uniform_c64(nc * nx * ny, 1701).reshape((nc, 1, nx, ny, 1), order="F")
+    want, p = oracle.recon(img, adjoint=0, **{("golden" if k == "golden_angle" else k): v for k, v in flags.items()})
+    got, dims = lib.recon(img, adjoint=False, kb_mode=kb, **flags)
+    assert (dims.nx, dims.ny, dims.nxos, dims.nyos) == (p.nx, p.ny, p.nxos, p.nyos) and dims.nxos != dims.nyos
+    assert got.shape == want.shape
+    assert rel_l2(got, want) <= 1e-5
+    # a non-square ADJOINT cannot be asked for: nx = ny = nro/2 by construction (src/tron.cu:910-911)

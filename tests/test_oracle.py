@@ -223,3 +223,29 @@ def test_walsh_and_repetition_restatements(oracle):
     for t in range(3):
         one, _ = oracle.recon(np.asfortranarray(d2[:, t:t + 1]), adjoint=1, golden=1)
         assert np.array_equal(out[0, t], one[0, 0])
+
+
+@pytest.mark.parametrize("nx,ny", [(16, 16), (16, 12), (12, 20)])
+def test_forward_is_a_nufft_square_and_rectangular(oracle, nx, ny):
+    """The forward pipeline approximates the DTFT of the image at the radial sample positions, for square images (the
+    reference's case) and for the rectangular definition of the "TODO: implement non-square images" (src/tron.cu:945):
+    rows (ny, the sine axis) and columns (nx, the cosine axis) each with their own size.  Pins orientation, FFT sign,
+    shifts, the dropped row / column 0 (Q8) and that the rectangular code path is the square one generalised."""
+    img = synth.uniform_c64(nx * ny, 77).reshape((1, 1, nx, ny, 1), order="F")
+    out, p = oracle.recon(img, adjoint=0, golden=1, data_undersamp=0.75)
+    assert (p.nx, p.ny, p.nxos, p.nyos, p.nro) == (nx, ny, 2 * nx, 2 * ny, 2 * nx)
+    rows_cols = img[0, 0, :, :, 0].T                       # [row (ny), col (nx)]
+    r = np.arange(ny)[:, None] - ny // 2
+    c = np.arange(nx)[None, :] - nx // 2
+    keep = (np.arange(ny)[:, None] > 0) & (np.arange(nx)[None, :] > 0)      # pad drops image row 0 and column 0
+    exact = np.zeros((p.nro, p.npe1work), complex)
+    for pe in range(p.npe1work):
+        t = float(oracle.degrid_angle(pe, p.npe1work, 0, 1))
+        for ro in range(p.nro):
+            R = ro / p.nro - 0.5
+            ph = np.exp(-2j * np.pi * (R * np.sin(t) * r + R * np.cos(t) * c))
+            exact[ro, pe] = np.sum(rows_cols * ph * keep)
+    got = out[0, 0, :, :, 0].astype(complex)
+    scale = np.vdot(exact, got) / np.vdot(exact, exact)    # the un-normalised Kaiser-Bessel window leaves a constant factor
+    assert abs(scale.imag) < 0.02 * abs(scale.real)
+    assert rel_l2(got, scale * exact) < 0.05

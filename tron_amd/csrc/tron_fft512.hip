@@ -139,11 +139,7 @@ __global__ void __launch_bounds__(256) fft512_rows_kernel(const Fft512Params p)
         for (int q = 0; q < 8; ++q) {
             const int col = q * 64 + lane;
             const int X = col < kF / 2 ? col : col - kF;
-#ifdef TRON_FFT_NT_LOAD
-            v[q] = X * X <= lim ? ld_nt(&line[col]) : make_float2(0.f, 0.f);   // read once: do not keep it in L2 / MALL
-#else
             v[q] = X * X <= lim ? line[col] : make_float2(0.f, 0.f);
-#endif
         }
         fft512_inv(v, xch, p.tw, lane);
         // keep k = lane + 64*j2 for j2 in {0,1,6,7}

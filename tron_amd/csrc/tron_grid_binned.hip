@@ -84,13 +84,7 @@ __device__ __forceinline__ void store_point_pair(const GridParams &p, int z, int
     const bool pair = (X0 + 1 + h < n) && p.out_p == 1 && (colA & 1) == 0;
     float2 *o = p.udata + (size_t)z * p.out_z + ((size_t)row * n + colA) * p.out_p + (size_t)c * p.out_c;
     if (pair && (n & 1) == 0) {
-#ifdef TRON_BIN_NT_STORE
-        typedef float v4f __attribute__((ext_vector_type(4)));
-        const v4f t = {v.x, v.y, v.z, v.w};
-        __builtin_nontemporal_store(t, reinterpret_cast<v4f *>(o));
-#else
         *reinterpret_cast<float4 *>(o) = v;
-#endif
     } else {
         if (X0 + h < n) o[0] = make_float2(v.x, v.y);
         if (X0 + 1 + h < n) {
@@ -318,10 +312,6 @@ grid_binned_kernel(const GridParams p)
             }
         };
 
-#ifdef TRON_BIN_LATE_CLEAR
-        for (int c = tid; c < C::NCELLS; c += kBinThreads) L.hist[c] = 0u;      // first batch of the round (ordered by the barriers below)
-        __syncthreads();
-#endif
         int sp0 = 0, sp1 = 0;
         if (nacc > 0 && TRON_DBG_LT(p, 3)) {
             sp1 = batch_end(0);
@@ -331,10 +321,8 @@ grid_binned_kernel(const GridParams p)
             const int rec_base = L.sp_start[sp0];
             const int nrec = L.sp_start[sp1] - rec_base;
 
-#ifndef TRON_BIN_LATE_CLEAR
             for (int c = tid; c < C::NCELLS; c += kBinThreads) L.hist[c] = 0u;
             __syncthreads();
-#endif
 
             // ---- A. stage + count: records are dealt out flat, 64 consecutive records per wave pass ----
 #pragma unroll
@@ -462,10 +450,6 @@ grid_binned_kernel(const GridParams p)
             }
             __syncthreads();
 
-#ifdef TRON_BIN_LATE_CLEAR
-            // the counters are not read again in this batch: clear them for the next one here (one barrier less per batch)
-            for (int c = tid; c < C::NCELLS; c += kBinThreads) L.hist[c] = 0u;
-#endif
             // ---- D. apply: each thread walks the 2CW+1 cell rows its 2x2 points can see as ONE loop
             //         (row ranges concatenated), so a wave runs max-over-lanes(total), not sum of row maxima
             if (TRON_DBG_LT(p, 1)) {
@@ -505,16 +489,6 @@ grid_binned_kernel(const GridParams p)
                     const float *wyr = L.wy + id * C::NWP + jp;
                     const float wxa = wxr[0], wxb = wxr[1];
                     const float wya = wyr[0], wyb = wyr[1];
-#ifdef TRON_BIN_EARLY_D
-                    float4 dd[CPB / 2 > 0 ? CPB / 2 : 1];
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (CPB % 2 == 0) {
-                        const float4 *d4e = reinterpret_cast<const float4 *>(L.d) + id;
-#pragma unroll
-                        for (int c = 0; c < CPB / 2; ++c) dd[c] = d4e[c * C::NREC];
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#endif
                     const int ar = (int)((ent >> 16) & 0x3fffu);
                     float wq[4];
                     wq[0] = wxa * wya; wq[1] = wxb * wya; wq[2] = wxa * wyb; wq[3] = wxb * wyb;   // src/tron.cu:516
@@ -527,12 +501,10 @@ grid_binned_kernel(const GridParams p)
                             if (Rlo[q] == 0) wq[q] += wq[q];                                      // r = 0 sits in both loops
                     }
                     if (CPB % 2 == 0) {
-#ifndef TRON_BIN_EARLY_D
                         const float4 *d4 = reinterpret_cast<const float4 *>(L.d) + id;
                         float4 dd[CPB / 2 > 0 ? CPB / 2 : 1];
 #pragma unroll
                         for (int c = 0; c < CPB / 2; ++c) dd[c] = d4[c * C::NREC];
-#endif
 #pragma unroll
                         for (int c = 0; c < CPB / 2; ++c) {
                             const float4 d = dd[c];

@@ -20,6 +20,7 @@ void build_trig_table(const tron_config &cfg, const tron_dims &d, float *cos_sin
 void build_trig_table_window(int npe, int skip, int golden, float *cos_sin);
 void build_band_table(int nxos, float kernwidth, uint32_t *band);
 void build_deapod_table(int n, float kernwidth, float sigma, float *inv_weight);
+void build_deapod_table_rect(int rows, int cols, float kernwidth, float sigma, float *inv_weight);
 void build_tile_order(int nxos, int tile, std::vector<int> &order);
 void build_split_tile_order(int nxos, int tile, int npe, float W, int target, int max_parts,
                             std::vector<int> &order, std::vector<int> &slots);

@@ -136,6 +136,18 @@ void build_deapod_table(int n, float kernwidth, float sigma, float *inv_weight)
     }
 }
 
+// The same for a non-square grid (forward plans only; "TODO: implement non-square images", src/tron.cu:945): rows and
+// columns each scaled by their own size, the fractional coordinate of :395 kept on the row axis.
+void build_deapod_table_rect(int rows, int cols, float kernwidth, float sigma, float *inv_weight)
+{
+    for (size_t id = 0; id < (size_t)rows * cols; ++id) {
+        float x = id / float(cols) - (rows + 1) / 2;
+        float y = float(id % cols) - (cols + 1) / 2;
+        float wgt = kb_hat(x * (1.f / rows / sigma), kernwidth) * kb_hat(y * (1.f / cols / sigma), kernwidth);
+        inv_weight[id] = 1.0f / (wgt > 0.f ? wgt : 1.f);
+    }
+}
+
 // Density compensation constants, src/tron.cu:408-409
 void dcf_constants(int nro, int npe1work, float *a, float *b)
 {

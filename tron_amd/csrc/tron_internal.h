@@ -56,6 +56,7 @@ struct PreParams {            // pad + deapodise + shift, forward head
     float2 *fft;              // [image][coil][nxos][nxos] FFT-native order
     const float *inv_deapod;  // nxos*nxos
     int nx, nxos, nchan, nimg;
+    int ny, nyos;             // rows of a non-square image / grid (0: square)
 };
 
 struct DegridParams {
@@ -69,6 +70,7 @@ struct DegridParams {
     int in_transposed;        // degrid_tile_kernel: input planes are stored [col][row] (fused forward FFT)
     int debug;                // TRON_DEBUG_SKIP (timing bisection): 1 = no sample loop, 2 = tile load only
     int n, nrep, nro, npe, nimg;
+    int nrows;                // simple kernel only: rows of a non-square grid (0: n); n is then the column count
     float W, beta;
     float kb_poly[kKbPolyTerms];
 };

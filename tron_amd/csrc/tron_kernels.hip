@@ -359,26 +359,29 @@ __global__ void __launch_bounds__(256) pre_kernel(const PreParams p)
 {
     const int id = blockIdx.x * blockDim.x + threadIdx.x;
     const int k = blockIdx.y;
-    const int n = p.nxos;
-    if (id >= n * n) return;
-    const int w = n > p.nx ? (n - p.nx) / 2 : 0;                      // src/tron.cu:439
-    const int xdst = id / n, ydst = id % n;
-    const bool in = (xdst - w > 0) && (xdst - w < p.nx) && (ydst - w > 0) && (ydst - w < p.nx);   // src/tron.cu:449-450
+    // rows <-> the sine axis (ny / nyos), columns <-> the cosine axis (nx / nxos); square unless the plan is a non-square
+    // forward one ("TODO: implement non-square images", src/tron.cu:945)
+    const int ncol = p.nxos, nrow = p.nyos > 0 ? p.nyos : p.nxos;
+    const int icol = p.nx, irow = p.ny > 0 ? p.ny : p.nx;
+    if (id >= nrow * ncol) return;
+    const int wr = nrow > irow ? (nrow - irow) / 2 : 0, wc = ncol > icol ? (ncol - icol) / 2 : 0;   // src/tron.cu:439
+    const int xdst = id / ncol, ydst = id % ncol;
+    const bool in = (xdst - wr > 0) && (xdst - wr < irow) && (ydst - wc > 0) && (ydst - wc < icol);   // src/tron.cu:449-450
     const float inv = p.inv_deapod[id];
-    const int sr = (xdst + n / 2) % n, sc = (ydst + n / 2) % n;       // src/tron.cu:164-172
-    const float2 *src = p.img + (size_t)k * p.nchan * p.nx * p.nx;
-    float2 *dst = p.fft + ((size_t)k * p.nchan) * n * n + (size_t)sr * n + sc;
+    const int sr = (xdst + nrow / 2) % nrow, sc = (ydst + ncol / 2) % ncol;       // src/tron.cu:164-172
+    const float2 *src = p.img + (size_t)k * p.nchan * icol * irow;
+    float2 *dst = p.fft + ((size_t)k * p.nchan) * nrow * ncol + (size_t)sr * ncol + sc;
     for (int c = 0; c < p.nchan; ++c) {
         float2 v = make_float2(0.f, 0.f);
-        if (in) v = src[((size_t)(xdst - w) * p.nx + (ydst - w)) * p.nchan + c];
+        if (in) v = src[((size_t)(xdst - wr) * icol + (ydst - wc)) * p.nchan + c];
         v.x *= inv; v.y *= inv;
-        dst[(size_t)c * n * n] = v;
+        dst[(size_t)c * nrow * ncol] = v;
     }
 }
 
 hipError_t launch_pre(const PreParams &p, hipStream_t s)
 {
-    dim3 grid((p.nxos * p.nxos + 255) / 256, p.nimg);
+    dim3 grid((p.nxos * (p.nyos > 0 ? p.nyos : p.nxos) + 255) / 256, p.nimg);
     hipLaunchKernelGGL(pre_kernel, grid, dim3(256), 0, s, p);
     return hipGetLastError();
 }
@@ -426,8 +429,9 @@ __global__ void __launch_bounds__(256) degrid_kernel(const DegridParams p)
     const float W = p.W;
     const float R = (float)ro / (float)p.nro - 0.5f;                  // src/tron.cu:554
     const float2 cs = p.trig[(size_t)k * p.trig_img_stride + pe];
+    const int nr = p.nrows > 0 ? p.nrows : n;                         // rows of a non-square grid (columns: n)
     float X = cs.y, Y = cs.x;                                         // X = sin, Y = cos (src/tron.cu:559)
-    X = (float)n * R * X + (float)((n + 1) / 2);                      // src/tron.cu:560-561
+    X = (float)nr * R * X + (float)((nr + 1) / 2);                    // src/tron.cu:560-561
     Y = (float)n * R * Y + (float)((n + 1) / 2);
     const float2 *src = p.udata + (size_t)k * p.in_z;
     float2 *dst = p.nudata + ((size_t)k * p.nro * p.npe + id) * p.nrep;
@@ -439,10 +443,10 @@ __global__ void __launch_bounds__(256) degrid_kernel(const DegridParams p)
             const float wgtx = kb_weight<KB>((float)xu - X, kb);
             for (int yu = (int)ceilf(Y - W); (float)yu <= (Y + W); ++yu) {
                 const float wgt = wgtx * kb_weight<KB>((float)yu - Y, kb);
-                int i = (xu + n) % n;                                 // src/tron.cu:569-570
-                int j = (yu + n) % n;
-                if (p.in_shift) { i = (i + n / 2) % n; j = (j + n / 2) % n; }   // fftshift(INVERSE) of :646 folded in
-                const float2 *u = src + (p.in_transposed ? (size_t)j * n + i : (size_t)i * n + j) * p.in_p;
+                int i = (xu % nr + nr) % nr;                          // src/tron.cu:569-570 ((xu + n) % n for |xu| < n)
+                int j = (yu % n + n) % n;
+                if (p.in_shift) { i = (i + nr / 2) % nr; j = (j + n / 2) % n; }   // fftshift(INVERSE) of :646 folded in
+                const float2 *u = src + (p.in_transposed ? (size_t)j * nr + i : (size_t)i * n + j) * p.in_p;
 #pragma unroll
                 for (int c = 0; c < CPB; ++c)
                     if (c0 + c < p.nrep) {

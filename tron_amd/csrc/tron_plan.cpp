@@ -189,7 +189,7 @@ int get_fft(tron_plan *p, int batch, int inverse, FftPlan **out)
     auto it = p->fft.find(key);
     if (it == p->fft.end()) {
         FftPlan f;
-        const size_t lengths[2] = {(size_t)p->d.nxos, (size_t)p->d.nxos};
+        const size_t lengths[2] = {(size_t)p->d.nxos, (size_t)p->d.nyos};      // fastest (columns) first; square except non-square forward plans
         // cufftPlan2d / cufftPlanMany of src/tron.cu:205-220: unnormalised C2C; CUFFT_INVERSE (+i)
         // for the adjoint (:632), CUFFT_FORWARD (-i) for the forward transform (:645)
         FFT_TRY(rocfft_plan_create(&f.plan, rocfft_placement_inplace,
@@ -270,7 +270,7 @@ int ensure_work(tron_plan *p, int units)
 {
     if (units <= p->work_units) return TRON_OK;
     const tron_dims &d = p->d;
-    const size_t per_unit = (size_t)p->nchan * d.nxos * d.nxos * sizeof(float2);
+    const size_t per_unit = (size_t)p->nchan * d.nxos * d.nyos * sizeof(float2);
     HIP_TRY(hipStreamSynchronize(p->stream));
     if (p->stream2) HIP_TRY(hipStreamSynchronize(p->stream2));
     for (float2 **b : {&p->d_grid, &p->d_grid2, &p->d_fft_tmp})
@@ -449,13 +449,14 @@ int forward_run(tron_plan *p, void *d_out, const void *d_in, int nimg, const flo
                 const float *deapod = nullptr)
 {
     const tron_dims &d = p->d;
-    const size_t n2 = (size_t)d.nxos * d.nxos;
+    const size_t n2 = (size_t)d.nxos * d.nyos;
+    const bool square = d.nx == d.ny;
     if (!trig) trig = p->d_trig;
     if (!deapod) deapod = p->d_deapod;
     if (int erc = ensure_work(p, std::max(1, std::min(p->chunk, nimg)))) return erc;
     for (int k0 = 0; k0 < nimg; k0 += p->chunk) {
         const int ck = std::min(p->chunk, nimg - k0);
-        const float2 *img = static_cast<const float2 *>(d_in) + (size_t)k0 * p->nchan * d.nx * d.nx;
+        const float2 *img = static_cast<const float2 *>(d_in) + (size_t)k0 * p->nchan * d.nx * d.ny;
         if (p->fft512) {
             // fused: pad + deapodise + shift + pruned forward FFT (tron_fft512.hip)
             StageTimer t(p, STAGE_FFT);
@@ -469,6 +470,8 @@ int forward_run(tron_plan *p, void *d_out, const void *d_in, int nimg, const flo
             a.nxos = d.nxos;
             a.nchan = p->nchan;
             a.nimg = ck;
+            a.ny = square ? 0 : d.ny;
+            a.nyos = square ? 0 : d.nyos;
             {
                 StageTimer t(p, STAGE_PRE);
                 HIP_TRY(launch_pre(a, p->stream));
@@ -490,6 +493,7 @@ int forward_run(tron_plan *p, void *d_out, const void *d_in, int nimg, const flo
         g.in_transposed = p->fft512 ? 1 : 0;      // launch_fft512_forward stores the grid transposed
         g.debug = p->debug_skip;
         g.n = d.nxos;
+        g.nrows = square ? 0 : d.nyos;
         g.nrep = p->nchan;
         g.nro = d.nro;
         g.npe = d.npe1work;
@@ -499,10 +503,10 @@ int forward_run(tron_plan *p, void *d_out, const void *d_in, int nimg, const flo
         memcpy(g.kb_poly, p->kb_poly, sizeof(g.kb_poly));
         {
             StageTimer t(p, STAGE_DEGRID);
-            if (p->cfg.kernwidth <= 3.f && !p->degrid_simple)
+            if (p->cfg.kernwidth <= 3.f && !p->degrid_simple && square)
                 HIP_TRY(launch_degrid_tile(g, p->kb_mode, p->stream));
             else
-                HIP_TRY(launch_degrid(g, p->kb_mode, p->stream));
+                HIP_TRY(launch_degrid(g, p->kb_mode, p->stream));      // also every non-square grid (supported, not tuned)
         }
     }
     return TRON_OK;
@@ -616,8 +620,11 @@ extern "C" int tron_plan_create(tron_plan **out, const tron_config *cfg, const t
         return fail(TRON_ERR_INVALID, "nc=%d nt=%d: channel count outside [1, 4096]", d.nc, d.nt);
     if (!(cfg->kernwidth > 0.f) || cfg->kernwidth > 4.f)
         return fail(TRON_ERR_UNSUPPORTED, "kernel width %g outside (0, 4]", cfg->kernwidth);
-    if (d.nxos < 2 || d.nxos > 16384 || d.nxos != d.nyos || d.nx != d.ny)
-        return fail(TRON_ERR_INVALID, "grid %dx%d (image %dx%d) is not a supported square size", d.nxos, d.nyos, d.nx, d.ny);
+    // the adjoint is square by construction (nx = ny = nro/2, src/tron.cu:910-911); the forward transform also takes
+    // non-square images (the reference's "TODO: implement non-square images", :945)
+    if (d.nxos < 2 || d.nxos > 16384 || d.nyos < 2 || d.nyos > 16384 || d.nx < 1 || d.ny < 1 ||
+        (cfg->adjoint && (d.nxos != d.nyos || d.nx != d.ny)))
+        return fail(TRON_ERR_INVALID, "grid %dx%d (image %dx%d) is not a supported size", d.nxos, d.nyos, d.nx, d.ny);
     if (cfg->adjoint && d.nx > d.nxos)
         return fail(TRON_ERR_INVALID, "adjoint needs gridos >= 1 (nx=%d > nxos=%d)", d.nx, d.nxos);
     if (cfg->adjoint && (long long)d.nro / 2 + ((long long)(d.nxos / 2 - 1) * d.nro) / d.nxos >= d.nro)
@@ -650,7 +657,7 @@ extern "C" int tron_plan_create(tron_plan **out, const tron_config *cfg, const t
     dcf_constants(d.nro, d.npe1work, &p->dcf_a, &p->dcf_b);
     p->scale = grid_scale(d.nxos, d.npe1work);
 
-    const size_t n2 = (size_t)d.nxos * d.nxos;
+    const size_t n2 = (size_t)d.nxos * d.nyos;
     const size_t per_unit = (size_t)p->nchan * n2 * sizeof(float2);
     int units = cfg->adjoint ? d.nz : 1;
     // The heaviest tile (the k-space centre, crossed by every spoke) is one wave's serial work, so a
@@ -725,13 +732,14 @@ extern "C" int tron_plan_create(tron_plan **out, const tron_config *cfg, const t
         }
     } else {
         std::vector<float> dea(n2);
-        build_deapod_table(d.nxos, cfg->kernwidth, 1.f, dea.data());             // src/tron.cu:643
+        if (d.nxos == d.nyos) build_deapod_table(d.nxos, cfg->kernwidth, 1.f, dea.data());             // src/tron.cu:643
+        else build_deapod_table_rect(d.nyos, d.nxos, cfg->kernwidth, 1.f, dea.data());
         if ((rc = upload(&p->d_deapod, dea.data(), dea.size() * sizeof(float)))) return bail(rc);
     }
     unsigned int zero = 0;
     if ((rc = upload(&p->d_errflag, &zero, sizeof(zero)))) return bail(rc);
     p->poison = getenv("TRON_POISON_GRID") != nullptr;   // tests: NaN-fill the work grid so a read of a never-written point shows up
-    if (d.nxos == 512 && d.nx == 256) {
+    if (d.nxos == 512 && d.nx == 256 && d.nyos == 512 && d.ny == 256) {
         p->fft512 = true;
         if (const char *ff = getenv("TRON_FFT")) p->fft512 = strcmp(ff, "rocfft") != 0;
     }
