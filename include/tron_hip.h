@@ -178,6 +178,12 @@ int tron_degridradial2d(tron_plan *plan, void *d_nudata, const void *d_udata);
 /* Waits for everything the plan has launched. */
 int tron_plan_sync(tron_plan *plan);
 
+/* Adjoint plans with at least two full batches run gridding and the FFT passes of consecutive batches on two streams
+   (the reference alternates two streams per slice, src/tron.cu:732-734).  enable = 0 serialises the two lanes -- each
+   kernel then runs alone, which is what a per-kernel duration should be measured on -- enable = 1 restores the plan's
+   default.  *had_two_lanes (may be NULL) reports whether the plan has a second lane at all. */
+int tron_plan_two_lanes(tron_plan *plan, int enable, int *had_two_lanes);
+
 /* Per-stage device timing with hipEvents on the plan's stream (off by default; costs one
    event pair per launch).  stage: 0 grid, 1 fft, 2 post (crop+deapod+SoS), 3 pre
    (pad+deapod), 4 degrid.  Returns accumulated milliseconds and launch count since the

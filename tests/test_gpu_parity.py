@@ -415,20 +415,42 @@ def test_c_client_matches_the_tron_binary(tmp_path):
     assert open(o1, "rb").read() == open(o2, "rb").read()
 
 
-def test_two_lane_pipeline_option(monkeypatch):
-    """TRON_DUAL_STREAM=1 (gridding and FFT on two streams, two work grids) gives the bytes of the default
-    single-stream pipeline, with enough batches to recycle both buffers."""
+def _adjoint_device_resident(data, flags, two_lanes=None):
+    cfg = lib.default_config(adjoint=1, **flags)
+    dims = lib.derive_dims(cfg, data.shape)
+    with lib.Plan(cfg, dims) as plan:
+        has = plan.two_lanes(True)
+        if two_lanes is not None:
+            plan.two_lanes(two_lanes)
+        d_in = lib.DeviceBuffer.from_numpy(np.asfortranarray(data).reshape(-1, order="F"))
+        d_out = lib.DeviceBuffer(dims.out_bytes)
+        plan.adjoint_device(d_out.ptr, d_in.ptr, 0, dims.nz, combine=1)
+        plan.sync()
+        return d_out.to_numpy(np.complex64, dims.out_bytes // 8), dims, has
+
+
+def test_two_lane_pipeline(monkeypatch):
+    """Device-resident runs of at least two full batches put gridding and the FFT passes of consecutive batches on two
+    streams with two work grids (default since round 2; the reference alternates two streams per slice,
+    src/tron.cu:732-734).  Same bytes as the serialised pipeline, with enough batches to recycle both buffers; the
+    tron_plan_two_lanes switch, the environment override and CU masks likewise."""
     data = synth.kspace(2, 512, 9 * 20, seed=1501)
     flags = dict(golden_angle=1, data_undersamp=20 / 512 + 1e-6, prof_slide=20)
     monkeypatch.setenv("TRON_CHUNK_SLICES", "2")
-    ref, d = lib.recon(data, adjoint=True, **flags)
-    assert d.nz == 9 and d.nxos == 512
+    monkeypatch.setenv("TRON_DUAL_STREAM", "0")
+    ref, d, has = _adjoint_device_resident(data, flags)
+    assert d.nz == 9 and d.nxos == 512 and not has
+    monkeypatch.delenv("TRON_DUAL_STREAM")
+    got, _, has = _adjoint_device_resident(data, flags)               # the default: two lanes
+    assert has and np.array_equal(got, ref)
+    got, _, _ = _adjoint_device_resident(data, flags, two_lanes=False)    # serialised through the C ABI switch
+    assert np.array_equal(got, ref)
     monkeypatch.setenv("TRON_DUAL_STREAM", "1")
-    got, _ = lib.recon(data, adjoint=True, **flags)
-    assert np.array_equal(got, ref)
     monkeypatch.setenv("TRON_CU_SPLIT", "4")
-    got, _ = lib.recon(data, adjoint=True, **flags)
+    got, _, _ = _adjoint_device_resident(data, flags)
     assert np.array_equal(got, ref)
+    host, _ = lib.recon(data, adjoint=True, **flags)                  # the host-buffer entry point on the same plan settings
+    assert np.array_equal(host.reshape(-1, order="F"), ref)
 
 
 def test_forward_batches_split_into_chunks(oracle, monkeypatch):

@@ -601,7 +601,8 @@ static hipError_t launch_binned_cpb(const GridParams &p, int half_in, hipStream_
     const int chunks = p.vslices > 1 ? 1 : (p.nchan - p.coil0 + CPB - 1) / CPB;
     const int entries = p.tile_entries > 0 ? p.tile_entries : q.ntiles;
     dim3 grid((unsigned)((size_t)entries * q.nslices), (unsigned)chunks);
-    const size_t lds = sizeof(BinLds<CPB, CW>);
+    size_t lds = sizeof(BinLds<CPB, CW>);
+    if (p.lds_pad > 0 && (size_t)p.lds_pad > lds && p.lds_pad <= 64 * 1024) lds = (size_t)p.lds_pad;   // fewer workgroups per CU (two-lane pipeline)
     if (lds > 64 * 1024) {   // above the default dynamic-LDS limit: raise it once per instantiation
         static hipError_t once = [] {
             hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(grid_binned_kernel<CPB, CW, false>),

@@ -42,6 +42,7 @@ struct GridParams {
     float2 *partial;         // [slice][slot][part][coil][32 x 32] partial tiles
     // binned kernel, linear angles: `vslices` consecutive slices share one pass (nslices = groups, nslices_total = slices)
     int vslices, nslices_total;
+    int lds_pad;             // binned kernel: request at least this much LDS per workgroup (0: what it needs); leaves CU room for a second lane
 };
 
 struct PostParams {           // crop + deapodise + (optional) root-sum-of-squares, adjoint tail

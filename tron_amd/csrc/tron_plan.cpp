@@ -127,6 +127,7 @@ struct tron_plan {
     float2 *d_fft_tmp = nullptr;   // chunk * nchan * 256 * 512
     std::map<std::pair<int, int>, FftPlan> fft;   // (batch, direction) -> plan
     // timing
+    int grid_lds_pad = 0;          // TRON_GRID_LDS_PAD (two-lane experiments): LDS request of the binned gridding kernel
     bool slices_per_pass = true;   // TRON_SLICES_PER_PASS=0 turns the linear-angle slice grouping off (A/B, tests)
     bool poison = false;           // TRON_POISON_GRID (tests): NaN-fill the work grid
     int debug_skip = 0;            // environment knobs, read once at plan creation (never on the launch path)
@@ -259,6 +260,7 @@ void fill_grid_consts(const tron_plan *p, GridParams &g)
     g.dcf_b = p->dcf_b;
     memcpy(g.kb_poly, p->kb_poly, sizeof(g.kb_poly));
     g.debug = p->debug_skip;
+    g.lds_pad = p->grid_lds_pad;
 }
 
 // Adjoint for slices [zfirst, zfirst+zcount).  d_in_z0 points at the first spoke of slice
@@ -297,7 +299,8 @@ int adjoint_run_raw(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, 
     // Two lanes: gridding is VALU/LDS bound and leaves HBM idle, the FFT passes are HBM bound and leave the
     // VALUs idle.  All gridding launches go to `stream`, all FFT launches to `stream2`; chunk k's FFT waits
     // for chunk k's gridding, and gridding of chunk k+2 waits until the FFT has released buffer k&1.
-    const bool dual = p->dual && p->fft512 && combine && zcount > 1;
+    // (worth it only when each lane still gets full-size launches: +4.9 % at 8 coils x 256 slices, +2.9 % at 128, 0 below)
+    const bool dual = p->dual && p->fft512 && combine && zcount >= 2 * p->chunk;
     // equal batches: a short last launch would be bound by the centre tile's serial chain (e.g. 128 slices = 64 + 64, not 85 + 43)
     // (the work buffers hold 1.5 x chunk so that the batches can be evened out upwards)
     int nbatch = std::max(1, (zcount + p->chunk / 2) / p->chunk);
@@ -750,9 +753,10 @@ extern "C" int tron_plan_create(tron_plan **out, const tron_config *cfg, const t
             tw[2 * k + 1] = (float)sin(2.0 * M_PI * k / 512.0);
         }
         if ((rc = upload(&p->d_tw512, tw.data(), tw.size() * sizeof(float)))) return bail(rc);
-        // off by default: measured +2 % (the gridding kernel already fills every CU's LDS, so the FFT
-        // lane only gets the tail); TRON_DUAL_STREAM=1 turns it on
-        p->dual = false;
+        // Two lanes (gridding on `stream`, FFT passes on `stream2`, two Cartesian buffers): round 1 measured +2 % and left
+        // it off; with the round-2 FFT passes it is +4.9 % at 8 coils x 256 slices (+2.7 % at 6 coils, +2 % at 4, 0 at 1),
+        // so adjoint plans with at least two full batches and more than one channel have it on.  TRON_DUAL_STREAM=0/1 overrides.
+        p->dual = cfg->adjoint && p->nchan > 1 && d.nz >= 2 * p->chunk;
         if (const char *ds = getenv("TRON_DUAL_STREAM")) p->dual = d.nz > 1 && atoi(ds) != 0;
         if (p->dual) {
             // TRON_CU_SPLIT=k: give the (HBM-bound) FFT lane every k-th CU and the (VALU/LDS-bound) gridding lane
@@ -797,6 +801,7 @@ extern "C" int tron_plan_create(tron_plan **out, const tron_config *cfg, const t
     if (const char *dbg = getenv("TRON_DEBUG_SKIP")) p->debug_skip = atoi(dbg);
     p->degrid_simple = getenv("TRON_DEGRID_SIMPLE") != nullptr;
     if (const char *sp = getenv("TRON_SLICES_PER_PASS")) p->slices_per_pass = atoi(sp) != 0;
+    if (const char *lp = getenv("TRON_GRID_LDS_PAD")) p->grid_lds_pad = atoi(lp);
     p->no_disc = getenv("TRON_NO_DISC") != nullptr;
     p->pin_host = cfg->pin_host != 0;
     if (const char *ph = getenv("TRON_PIN_HOST")) p->pin_host = atoi(ph) != 0;
@@ -1163,6 +1168,19 @@ extern "C" int tron_degridradial2d(tron_plan *p, void *d_nudata, const void *d_u
         HIP_TRY(launch_degrid_tile(g, p->kb_mode, p->stream));
     else
         HIP_TRY(launch_degrid(g, p->kb_mode, p->stream));
+    return TRON_OK;
+}
+
+// Gridding and FFT launches of consecutive batches overlap on two streams when the plan has a second lane; enable = 0
+// serialises them on one stream (each kernel then runs alone: what a per-kernel duration should be measured on),
+// enable = 1 restores the plan's default.  Returns TRON_OK; *had_two_lanes (optional) tells whether the plan has the lane.
+extern "C" int tron_plan_two_lanes(tron_plan *p, int enable, int *had_two_lanes)
+{
+    if (!p) return fail(TRON_ERR_INVALID, "null plan");
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    if (p->stream2) HIP_TRY(hipStreamSynchronize(p->stream2));
+    if (had_two_lanes) *had_two_lanes = p->stream2 != nullptr && p->d_grid2 != nullptr;
+    p->dual = enable != 0 && p->stream2 != nullptr && p->d_grid2 != nullptr;
     return TRON_OK;
 }
 

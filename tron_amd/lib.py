@@ -55,7 +55,7 @@ EXPORTS = [
     "tron_config_default", "tron_derive_dims", "tron_plan_create", "tron_plan_destroy",
     "tron_recon_radial2d", "tron_recon_radial2d_range", "tron_recon_radial2d_block", "tron_recon_radial2d_multi", "tron_nufft_adj_radial2d", "tron_cgnr_radial2d", "tron_nufft_radial2d",
     "tron_precompensate", "tron_gridradial2d", "tron_degridradial2d", "tron_plan_sync",
-    "tron_plan_timing", "tron_plan_timing_get", "tron_plan_timing_reset",
+    "tron_plan_timing", "tron_plan_timing_get", "tron_plan_timing_reset", "tron_plan_two_lanes",
     "tron_host_trig_table", "tron_host_band_table", "tron_host_deapod_table",
     "tron_device_count", "tron_device_malloc", "tron_device_free", "tron_memcpy_h2d", "tron_memcpy_d2h",
     "tron_last_error", "tron_version",
@@ -100,6 +100,7 @@ def load():
     sig("tron_gridradial2d", i, [p, p, p, i])
     sig("tron_degridradial2d", i, [p, p, p])
     sig("tron_plan_sync", i, [p])
+    sig("tron_plan_two_lanes", i, [p, i, ctypes.POINTER(i)])
     sig("tron_plan_timing", i, [p, i])
     sig("tron_plan_timing_get", i, [p, i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)])
     sig("tron_plan_timing_reset", i, [p])
@@ -267,6 +268,12 @@ class Plan:
 
     def sync(self):
         check(load().tron_plan_sync(self._h))
+
+    def two_lanes(self, enable=True) -> bool:
+        """Serialise (False) or restore (True) the gridding || FFT overlap; returns whether the plan has a second lane."""
+        had = ctypes.c_int(0)
+        check(load().tron_plan_two_lanes(self._h, int(enable), ctypes.byref(had)))
+        return bool(had.value)
 
     def timing(self, enable=True):
         check(load().tron_plan_timing(self._h, int(enable)))
