@@ -776,8 +776,17 @@ extern "C" int tron_plan_create(tron_plan **out, const tron_config *cfg, const t
                     return bail(fail(TRON_ERR_HIP, "cannot create CU-masked streams"));
                 hipStreamDestroy(p->stream);
                 p->stream = masked;
-            } else if (hipStreamCreateWithFlags(&p->stream2, hipStreamNonBlocking) != hipSuccess)
-                return bail(fail(TRON_ERR_HIP, "cannot create the FFT lane"));
+            } else {
+                // the FFT lane's workgroups are short and light: at a higher stream priority they slip into every slot the
+                // gridding lane frees instead of queueing behind its backlog (TRON_FFT_PRIO: 0 = same priority)
+                int lo = 0, hi = 0, prio = 0;
+                hipDeviceGetStreamPriorityRange(&lo, &hi);          // lo = least urgent (numerically greatest), hi = most urgent
+                const char *fp = getenv("TRON_FFT_PRIO");
+                const int want = fp ? atoi(fp) : -1;                // -1: most urgent, +1: least urgent
+                prio = want < 0 ? hi : (want > 0 ? lo : 0);
+                if (hipStreamCreateWithPriority(&p->stream2, hipStreamNonBlocking, prio) != hipSuccess)
+                    return bail(fail(TRON_ERR_HIP, "cannot create the FFT lane"));
+            }
             for (int i = 0; i < 2; ++i)
                 if (hipEventCreateWithFlags(&p->ev_g[i], hipEventDisableTiming) != hipSuccess ||
                     hipEventCreateWithFlags(&p->ev_f[i], hipEventDisableTiming) != hipSuccess)
