@@ -362,6 +362,8 @@ def main():
                         launch_ms=round(ms / n, 4), stage_share={k: round(v[0] / tot, 3) for k, v in stages.items()},
                         two_lanes=two_lanes,
                         launch_ms_overlapped=overlapped if two_lanes else None,
+                        frac_overlapped=(round(bytes_per_launch / (overlapped[dom] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+                                         if two_lanes and dom in overlapped else None),
                         measured=("kernel alone: the plan's two lanes (gridding || FFT passes of the next batch, as in the timed region) "
                                   "serialised for this timing pass; launch_ms_overlapped = the same launches while overlapped"
                                   if two_lanes else "kernel alone (the plan runs one lane)"))
