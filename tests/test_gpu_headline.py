@@ -90,3 +90,17 @@ def test_config2_linear_256_image_to_512x512_spokes_and_back(oracle, kb):
     assert (q.nx, q.npe1work) == (256, 512)
     back, _ = lib.recon(want, adjoint=True, kb_mode=kb)
     assert rel_l2(back, back_want) <= TOL
+
+
+@pytest.mark.timeout(1200)
+def test_cgnr_at_the_metric_shape(oracle):
+    """CGNR (src/tron.cu:665-720) at the headline size: 512 x 402 golden-angle spokes, 2 coils, 2 non-overlapping slices,
+    2 iterations -- the fused 256 -> 512 forward FFT, tiled degridding with a per-slice angle stride, binned gridding and
+    the batched reductions, against the oracle's restatement."""
+    data = synth.kspace(2, NRO, 402 * 2, seed=synth.SEED_BASE + 25)
+    flags = dict(data_undersamp=0.7852, prof_slide=402)
+    want, p = oracle.recon_cgnr(data, 2, golden=1, **flags)
+    got, dims = lib.recon(data, adjoint=True, golden_angle=1, niter=2, **flags)
+    assert (dims.nz, dims.npe1work, dims.nxos) == (2, 402, 512) and p.nz == 2
+    for z in range(2):
+        assert rel_l2(got[..., z], want[..., z]) <= TOL, z
