@@ -82,6 +82,7 @@ struct tron_plan {
     hipStream_t stream2 = nullptr;  // FFT lane of the adjoint pipeline (gridding stays on `stream`)
     hipEvent_t ev_g[2] = {nullptr, nullptr}, ev_f[2] = {nullptr, nullptr};   // grid done / buffer free, per buffer
     bool dual = false;
+    bool fft_pending[2] = {false, false};   // two-lane pipeline: an FFT launch that reads work buffer b may still be in flight (ev_f[b])
     // device tables
     float2 *d_trig = nullptr;
     size_t ntrig = 0;
@@ -290,7 +291,10 @@ int ensure_work(tron_plan *p, int units)
 }
 
 // in_stride_spokes: spokes between the windows of consecutive slices in d_in_z0 (0 = prof_slide: views into the stream)
-int adjoint_run_raw(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, int zcount, int combine, int in_stride_spokes)
+// defer_join: leave the FFT lane running when the call returns (device-resident entry point: the caller synchronises with
+// tron_plan_sync); the next call's first gridding launches then overlap this call's last FFT passes.
+int adjoint_run_raw(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, int zcount, int combine, int in_stride_spokes,
+                    bool defer_join)
 {
     const tron_dims &d = p->d;
     const size_t n2 = (size_t)d.nxos * d.nxos;
@@ -308,6 +312,12 @@ int adjoint_run_raw(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, 
     const int even = (zcount + nbatch - 1) / nbatch;
     const int step = dual ? std::max(1, std::min(even, (zcount + 1) / 2)) : even;
     if (int erc = ensure_work(p, std::min(step, std::max(zcount, 1)))) return erc;
+    if (!dual)      // one lane: everything of an earlier two-lane call that may still be running on the FFT lane comes first
+        for (int b = 0; b < 2; ++b)
+            if (p->fft_pending[b]) {
+                HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_f[b], 0));
+                p->fft_pending[b] = false;
+            }
     int lane_idx = 0;
     for (int z0 = 0; z0 < zcount; z0 += step, ++lane_idx) {
         const int cz = std::min(step, zcount - z0);
@@ -316,7 +326,7 @@ int adjoint_run_raw(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, 
         hipStream_t st_fft = dual ? p->stream2 : p->stream;
         float2 *grid_buf = b ? p->d_grid2 : p->d_grid;
         float2 *tmp_buf = p->d_fft_tmp;
-        if (dual && lane_idx >= 2) HIP_TRY(hipStreamWaitEvent(st, p->ev_f[b], 0));
+        if (dual && p->fft_pending[b]) HIP_TRY(hipStreamWaitEvent(st, p->ev_f[b], 0));   // the FFT (of this or an earlier call) that last read buffer b
         GridParams g;
         memset(&g, 0, sizeof(g));
         fill_grid_consts(p, g);
@@ -380,7 +390,10 @@ int adjoint_run_raw(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, 
                 HIP_TRY(launch_fft512_adjoint(grid_buf, tmp_buf, static_cast<float2 *>(d_out) + (size_t)z0 * d.nx * d.nx,
                                               p->d_tw512, p->d_deapod, rzero, p->nchan, cz, st_fft));
             }
-            if (dual) HIP_TRY(hipEventRecord(p->ev_f[b], st_fft));
+            if (dual) {
+                HIP_TRY(hipEventRecord(p->ev_f[b], st_fft));
+                p->fft_pending[b] = true;
+            }
             if ((rc = stage_check(p, "fft512"))) return rc;
             continue;
         }
@@ -402,7 +415,7 @@ int adjoint_run_raw(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, 
         }
         if ((rc = stage_check(p, "post"))) return rc;
     }
-    if (dual && lane_idx > 0) {   // later work on the main stream (e.g. the download) waits for the FFT lane
+    if (dual && lane_idx > 0 && !defer_join) {   // later work on the main stream (e.g. the download) waits for the FFT lane
         HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_f[(lane_idx - 1) & 1], 0));
     }
     return TRON_OK;
@@ -423,10 +436,11 @@ int combine_coils(tron_plan *p, float2 *d_out, const float2 *d_coil, int cz)
 // The adjoint with the plan's coil combination.  Root-sum-of-squares of one repetition is fused into the pipeline's
 // tail; Walsh's adaptive combination and nt > 1 (channel = coil + nc*repetition) run it uncombined into a scratch
 // buffer and combine from there.
-int adjoint_run(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, int zcount, int combine, int in_stride_spokes = 0)
+int adjoint_run(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, int zcount, int combine, int in_stride_spokes = 0,
+                bool defer_join = false)
 {
     if (!combine || (p->d.nt == 1 && p->cfg.coil_combine != 1))
-        return adjoint_run_raw(p, d_out, d_in_z0, zfirst, zcount, combine, in_stride_spokes);
+        return adjoint_run_raw(p, d_out, d_in_z0, zfirst, zcount, combine, in_stride_spokes, defer_join);
     const tron_dims &d = p->d;
     const size_t N = (size_t)p->nchan * d.nx * d.ny, elem = p->cfg.input_half ? 4 : 8;
     const int step = std::max(1, std::min(p->chunk, zcount));
@@ -441,7 +455,7 @@ int adjoint_run(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, int 
     for (int z0 = 0; z0 < zcount; z0 += step) {
         const int cz = std::min(step, zcount - z0);
         int rc = adjoint_run_raw(p, p->d_coil_tmp, static_cast<const unsigned char *>(d_in_z0) + (size_t)z0 * in_stride * d.nro * p->nchan * elem,
-                                 zfirst + z0, cz, 0, in_stride_spokes);
+                                 zfirst + z0, cz, 0, in_stride_spokes, false);
         if (rc) return rc;
         if ((rc = combine_coils(p, static_cast<float2 *>(d_out) + (size_t)z0 * d.nt * d.nx * d.ny, p->d_coil_tmp, cz))) return rc;
     }
@@ -870,6 +884,7 @@ extern "C" int tron_plan_sync(tron_plan *p)
     if (!p) return fail(TRON_ERR_INVALID, "tron_plan_sync: null plan");
     HIP_TRY(hipStreamSynchronize(p->stream));
     if (p->stream2) HIP_TRY(hipStreamSynchronize(p->stream2));
+    p->fft_pending[0] = p->fft_pending[1] = false;
     return check_errflag(p);
 }
 
@@ -887,7 +902,7 @@ extern "C" int tron_nufft_adj_radial2d(tron_plan *p, void *d_out, const void *d_
     HIP_TRY(hipSetDevice(p->cfg.device));
     const size_t elem = p->cfg.input_half ? 4 : 8;
     const unsigned char *in = static_cast<const unsigned char *>(d_in) + (size_t)zfirst * d.prof_slide * d.nro * p->nchan * elem;
-    return adjoint_run(p, d_out, in, zfirst, zcount, combine);
+    return adjoint_run(p, d_out, in, zfirst, zcount, combine, 0, true);   // asynchronous: the FFT lane is joined by tron_plan_sync / the next call
 }
 
 extern "C" int tron_cgnr_radial2d(tron_plan *p, void *d_out, const void *d_in, int zfirst, int zcount, int combine)
@@ -1188,6 +1203,7 @@ extern "C" int tron_plan_two_lanes(tron_plan *p, int enable, int *had_two_lanes)
     if (!p) return fail(TRON_ERR_INVALID, "null plan");
     HIP_TRY(hipStreamSynchronize(p->stream));
     if (p->stream2) HIP_TRY(hipStreamSynchronize(p->stream2));
+    p->fft_pending[0] = p->fft_pending[1] = false;
     if (had_two_lanes) *had_two_lanes = p->stream2 != nullptr && p->d_grid2 != nullptr;
     p->dual = enable != 0 && p->stream2 != nullptr && p->d_grid2 != nullptr;
     return TRON_OK;
