@@ -1,0 +1,453 @@
+// The batched pipelines of libtronhip on the device: adjoint (gridding -> FFT -> crop / deapodise / combine), forward
+// (pad / deapodise -> FFT -> degridding), CGNR on top of the two, and their work buffers.  Replaces
+// tron_nufft_adj_radial2d / tron_nufft_radial2d / tron_cgnr_radial2d of the reference (src/tron.cu:623-720).
+#include "tron_plan_impl.h"
+
+namespace tron {
+
+int drain_timers(tron_plan *p)
+{
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    if (p->stream2) HIP_TRY(hipStreamSynchronize(p->stream2));
+    for (int s = 0; s < STAGE_COUNT; ++s) {
+        for (auto &pr : p->ev[s]) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
+            p->ms_acc[s] += ms;
+            p->launches[s] += 1;
+            hipEventDestroy(pr.first);
+            hipEventDestroy(pr.second);
+        }
+        p->ev[s].clear();
+    }
+    return TRON_OK;
+}
+
+int get_fft(tron_plan *p, int batch, int inverse, FftPlan **out)
+{
+    auto key = std::make_pair(batch, inverse);
+    auto it = p->fft.find(key);
+    if (it == p->fft.end()) {
+        FftPlan f;
+        const size_t lengths[2] = {(size_t)p->d.nxos, (size_t)p->d.nyos};      // fastest (columns) first; square except non-square forward plans
+        // cufftPlan2d / cufftPlanMany of src/tron.cu:205-220: unnormalised C2C; CUFFT_INVERSE (+i)
+        // for the adjoint (:632), CUFFT_FORWARD (-i) for the forward transform (:645)
+        FFT_TRY(rocfft_plan_create(&f.plan, rocfft_placement_inplace,
+                                   inverse ? rocfft_transform_type_complex_inverse : rocfft_transform_type_complex_forward,
+                                   rocfft_precision_single, 2, lengths, (size_t)batch, nullptr));
+        FFT_TRY(rocfft_execution_info_create(&f.info));
+        FFT_TRY(rocfft_execution_info_set_stream(f.info, p->stream));
+        FFT_TRY(rocfft_plan_get_work_buffer_size(f.plan, &f.work_bytes));
+        if (f.work_bytes) {
+            HIP_TRY(hipMalloc(&f.work, f.work_bytes));
+            FFT_TRY(rocfft_execution_info_set_work_buffer(f.info, f.work, f.work_bytes));
+        }
+        // rocFFT builds its twiddle tables with a kernel on a stream of its own; make sure that has
+        // finished before the first execution on ours (a non-blocking stream does not wait for it)
+        HIP_TRY(hipDeviceSynchronize());
+        it = p->fft.emplace(key, f).first;
+    }
+    *out = &it->second;
+    return TRON_OK;
+}
+
+int run_fft(tron_plan *p, float2 *buf, int batch, int inverse)
+{
+    FftPlan *f = nullptr;
+    int rc = get_fft(p, batch, inverse, &f);
+    if (rc) return rc;
+    StageTimer t(p, STAGE_FFT);
+    void *bufs[1] = {buf};
+    FFT_TRY(rocfft_execute(f->plan, bufs, nullptr, f->info));
+    return TRON_OK;
+}
+
+int stage_check(tron_plan *p, const char *what)
+{
+    if (!p->sync_each) return TRON_OK;
+    hipError_t e = hipStreamSynchronize(p->stream);
+    if (e == hipSuccess && p->stream2) e = hipStreamSynchronize(p->stream2);
+    if (e != hipSuccess) return fail(TRON_ERR_HIP, "stage '%s' failed: %s", what, hipGetErrorString(e));
+    fprintf(stderr, "[tronhip] stage %s ok\n", what);
+    return TRON_OK;
+}
+
+void fill_grid_consts(const tron_plan *p, GridParams &g)
+{
+    g.band = p->d_band;
+    g.tile_order = p->d_tile_order;
+    g.errflag = p->d_errflag;
+    g.nxos = p->d.nxos;
+    g.nro = p->d.nro;
+    g.npe = p->d.npe1work;
+    g.nchan = p->nchan;
+    g.tiles_per_row = p->tiles_per_row;
+    g.ntiles = p->ntiles;
+    g.coil0 = 0;
+    g.W = p->cfg.kernwidth;
+    g.beta = p->beta;
+    g.scale = p->scale;
+    g.dcf_a = p->dcf_a;
+    g.dcf_b = p->dcf_b;
+    memcpy(g.kb_poly, p->kb_poly, sizeof(g.kb_poly));
+    g.debug = p->debug_skip;
+    g.lds_pad = p->grid_lds_pad;
+}
+
+// Adjoint for slices [zfirst, zfirst+zcount).  d_in_z0 points at the first spoke of slice
+// zfirst's window; d_out at that slice's output.
+// Work buffers (Cartesian grid, FFT intermediate) for `units` slices / images per batch.  Adjoint plans allocate their
+// full batch at creation; forward plans start empty and grow to what a call actually transforms (the host entry point
+// only ever asks for one image: no 1.5 GiB of work space for it).
+int ensure_work(tron_plan *p, int units)
+{
+    if (units <= p->work_units) return TRON_OK;
+    const tron_dims &d = p->d;
+    const size_t per_unit = (size_t)p->nchan * d.nxos * d.nyos * sizeof(float2);
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    if (p->stream2) HIP_TRY(hipStreamSynchronize(p->stream2));
+    for (float2 **b : {&p->d_grid, &p->d_grid2, &p->d_fft_tmp})
+        if (*b) { HIP_TRY(hipFree(*b)); *b = nullptr; }
+    p->work_units = 0;
+    if (hipMalloc(reinterpret_cast<void **>(&p->d_grid), (size_t)units * per_unit) != hipSuccess)
+        return fail(TRON_ERR_NOMEM, "cannot allocate %zu bytes of Cartesian work space", (size_t)units * per_unit);
+    if (p->poison) hipMemset(p->d_grid, 0xff, (size_t)units * per_unit);
+    if (p->fft512 && hipMalloc(reinterpret_cast<void **>(&p->d_fft_tmp), (size_t)units * p->nchan * 256 * 512 * sizeof(float2)) != hipSuccess)
+        return fail(TRON_ERR_NOMEM, "cannot allocate the FFT intermediate buffer");
+    if (p->dual && hipMalloc(reinterpret_cast<void **>(&p->d_grid2), (size_t)units * per_unit) != hipSuccess)
+        return fail(TRON_ERR_NOMEM, "cannot allocate the second Cartesian buffer");
+    p->work_units = units;
+    return TRON_OK;
+}
+
+// in_stride_spokes: spokes between the windows of consecutive slices in d_in_z0 (0 = prof_slide: views into the stream)
+// defer_join: leave the FFT lane running when the call returns (device-resident entry point: the caller synchronises with
+// tron_plan_sync); the next call's first gridding launches then overlap this call's last FFT passes.
+int adjoint_run_raw(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, int zcount, int combine, int in_stride_spokes,
+                    bool defer_join)
+{
+    const tron_dims &d = p->d;
+    const size_t n2 = (size_t)d.nxos * d.nxos;
+    const size_t elem = p->cfg.input_half ? 4 : 8;
+    const int golden = p->cfg.golden_angle;
+    // Two lanes: gridding is VALU/LDS bound and leaves HBM idle, the FFT passes are HBM bound and leave the
+    // VALUs idle.  All gridding launches go to `stream`, all FFT launches to `stream2`; chunk k's FFT waits
+    // for chunk k's gridding, and gridding of chunk k+2 waits until the FFT has released buffer k&1.
+    // (worth it only when each lane still gets full-size launches: +4.9 % at 8 coils x 256 slices, +2.9 % at 128, 0 below)
+    const bool dual = p->dual && p->fft512 && combine && zcount >= 2 * p->chunk;
+    // equal batches: a short last launch would be bound by the centre tile's serial chain (e.g. 128 slices = 64 + 64, not 85 + 43)
+    // (the work buffers hold 1.5 x chunk so that the batches can be evened out upwards)
+    int nbatch = std::max(1, (zcount + p->chunk / 2) / p->chunk);
+    if ((zcount + nbatch - 1) / nbatch > p->chunk_cap) nbatch = (zcount + p->chunk_cap - 1) / p->chunk_cap;
+    const int even = (zcount + nbatch - 1) / nbatch;
+    const int step = dual ? std::max(1, std::min(even, (zcount + 1) / 2)) : even;
+    if (int erc = ensure_work(p, std::min(step, std::max(zcount, 1)))) return erc;
+    if (!dual)      // one lane: everything of an earlier two-lane call that may still be running on the FFT lane comes first
+        for (int b = 0; b < 2; ++b)
+            if (p->fft_pending[b]) {
+                HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_f[b], 0));
+                p->fft_pending[b] = false;
+            }
+    int lane_idx = 0;
+    for (int z0 = 0; z0 < zcount; z0 += step, ++lane_idx) {
+        const int cz = std::min(step, zcount - z0);
+        const int b = dual ? (lane_idx & 1) : 0;
+        hipStream_t st = p->stream;
+        hipStream_t st_fft = dual ? p->stream2 : p->stream;
+        float2 *grid_buf = b ? p->d_grid2 : p->d_grid;
+        float2 *tmp_buf = p->d_fft_tmp;
+        if (dual && p->fft_pending[b]) HIP_TRY(hipStreamWaitEvent(st, p->ev_f[b], 0));   // the FFT (of this or an earlier call) that last read buffer b
+        GridParams g;
+        memset(&g, 0, sizeof(g));
+        fill_grid_consts(p, g);
+        const int in_stride = in_stride_spokes > 0 ? in_stride_spokes : d.prof_slide;
+        g.nudata = static_cast<const unsigned char *>(d_in_z0) + (size_t)z0 * in_stride * d.nro * p->nchan * elem;
+        g.udata = grid_buf;
+        g.trig = p->d_trig + (golden ? (size_t)(zfirst + z0) * d.prof_slide : 0);
+        g.in_slice_stride = (long long)in_stride * d.nro * p->nchan;
+        g.trig_slice_stride = golden ? d.prof_slide : 0;
+        g.nslices = cz;
+        g.apply_dcf = 1;
+        g.out_z = (long long)p->nchan * n2;
+        g.out_c = (long long)n2;
+        g.out_p = 1;
+        g.out_shift = 1;
+        // the fused FFT never reads beyond the sampled disc, so the gridding kernel need not store zeros there
+        const int rzero = (p->fft512 && combine && !p->no_disc) ? (int)floorf((float)(d.nxos / 2 - 1) + p->cfg.kernwidth) + 1 : 0;
+        g.skip_outside = rzero > 0 ? 1 : 0;
+        {
+            StageTimer t(p, STAGE_GRID, st);
+            if (p->binned) {
+                g.tile_order = p->d_tile_order32;
+                // linear angles: every slice has the same trajectory (src/tron.cu:509 depends on pe only), so with few coils
+                // several slices share one pass of the kernel (clipping, weights and the sort paid once per group)
+                const int vs = (!golden && cz > 1 && p->nchan <= 4 && p->slices_per_pass) ? std::max(1, 8 / p->nchan) : 1;
+                if (vs > 1) {
+                    g.vslices = vs;
+                    g.nslices_total = cz;
+                    g.nslices = (cz + vs - 1) / vs;
+                } else if (cz < p->split_below && p->nsplit_slots > 0) {
+                    // a launch this small would be bound by the centre tiles' serial chains: split them over spoke ranges
+                    if (p->partial_slices < (size_t)cz) {
+                        if (p->d_partial) { HIP_TRY(hipStreamSynchronize(st)); HIP_TRY(hipFree(p->d_partial)); p->d_partial = nullptr; }
+                        const size_t want = (size_t)std::min(p->split_below, std::max(cz, 8));
+                        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_partial),
+                                          want * p->nsplit_slots * p->max_parts * p->nchan * kBinnedTile * kBinnedTile * sizeof(float2)));
+                        p->partial_slices = want;
+                    }
+                    g.tile_order = p->d_tile_order32_split;
+                    g.tile_entries = p->split_entries;
+                    g.nsplit_slots = p->nsplit_slots;
+                    g.max_parts = p->max_parts;
+                    g.split_slots = p->d_split_slots;
+                    g.partial = p->d_partial;
+                }
+                HIP_TRY(launch_grid_binned(g, p->cfg.input_half, st));
+            } else {
+                HIP_TRY(launch_grid(g, p->kb_mode, p->cfg.input_half, st));
+            }
+        }
+        int rc = stage_check(p, "grid");
+        if (rc) return rc;
+        if (p->fft512 && combine) {
+            // fused: pruned inverse FFT + crop + deapodise + root-sum-of-squares (tron_fft512.hip)
+            if (dual) {
+                HIP_TRY(hipEventRecord(p->ev_g[b], st));
+                HIP_TRY(hipStreamWaitEvent(st_fft, p->ev_g[b], 0));
+            }
+            {
+                StageTimer t(p, STAGE_FFT, st_fft);
+                HIP_TRY(launch_fft512_adjoint(grid_buf, tmp_buf, static_cast<float2 *>(d_out) + (size_t)z0 * d.nx * d.nx,
+                                              p->d_tw512, p->d_deapod, rzero, p->nchan, cz, st_fft));
+            }
+            if (dual) {
+                HIP_TRY(hipEventRecord(p->ev_f[b], st_fft));
+                p->fft_pending[b] = true;
+            }
+            if ((rc = stage_check(p, "fft512"))) return rc;
+            continue;
+        }
+        rc = run_fft(p, p->d_grid, cz * p->nchan, 1);
+        if (rc) return rc;
+        if ((rc = stage_check(p, "fft"))) return rc;
+        PostParams q;
+        q.fft = p->d_grid;
+        q.out = static_cast<float2 *>(d_out) + (size_t)z0 * d.nx * d.nx * (combine ? 1 : p->nchan);
+        q.inv_deapod = p->d_deapod;
+        q.nx = d.nx;
+        q.nxos = d.nxos;
+        q.nchan = p->nchan;
+        q.nslices = cz;
+        q.combine = combine;
+        if (g.debug != 5) {
+            StageTimer t(p, STAGE_POST);
+            HIP_TRY(launch_post(q, p->stream));
+        }
+        if ((rc = stage_check(p, "post"))) return rc;
+    }
+    if (dual && lane_idx > 0 && !defer_join) {   // later work on the main stream (e.g. the download) waits for the FFT lane
+        HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_f[(lane_idx - 1) & 1], 0));
+    }
+    return TRON_OK;
+}
+
+// trig / deapod default to the plan's own tables (forward plans); the CGNR path of an adjoint plan passes the forward
+// operator's tables and a per-image angle stride (every slice has its own golden angles)
+// coilcombinesos / coilcombinewalsh (src/tron.cu:764,766) of `cz` slices of coil images [z][nchan*id + c]
+int combine_coils(tron_plan *p, float2 *d_out, const float2 *d_coil, int cz)
+{
+    if (p->cfg.coil_combine == 1 && p->d.nc > 16)
+        return fail(TRON_ERR_UNSUPPORTED, "Walsh coil combination handles up to 16 coils (nc=%d)", p->d.nc);
+    HIP_TRY(launch_coil_combine(d_out, d_coil, p->d.nx, p->d.nc, p->d.nt, p->cfg.coil_combine == 1 ? 1 : 0,
+                                std::max(0, p->cfg.walsh_patch), cz, p->stream));
+    return TRON_OK;
+}
+
+// The adjoint with the plan's coil combination.  Root-sum-of-squares of one repetition is fused into the pipeline's
+// tail; Walsh's adaptive combination and nt > 1 (channel = coil + nc*repetition) run it uncombined into a scratch
+// buffer and combine from there.
+int adjoint_run(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, int zcount, int combine, int in_stride_spokes,
+                bool defer_join)
+{
+    if (!combine || (p->d.nt == 1 && p->cfg.coil_combine != 1))
+        return adjoint_run_raw(p, d_out, d_in_z0, zfirst, zcount, combine, in_stride_spokes, defer_join);
+    const tron_dims &d = p->d;
+    const size_t N = (size_t)p->nchan * d.nx * d.ny, elem = p->cfg.input_half ? 4 : 8;
+    const int step = std::max(1, std::min(p->chunk, zcount));
+    if (p->coil_tmp_slices < step) {
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        if (p->d_coil_tmp) HIP_TRY(hipFree(p->d_coil_tmp));
+        p->d_coil_tmp = nullptr; p->coil_tmp_slices = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_coil_tmp), step * N * sizeof(float2)));
+        p->coil_tmp_slices = step;
+    }
+    const int in_stride = in_stride_spokes > 0 ? in_stride_spokes : d.prof_slide;
+    for (int z0 = 0; z0 < zcount; z0 += step) {
+        const int cz = std::min(step, zcount - z0);
+        int rc = adjoint_run_raw(p, p->d_coil_tmp, static_cast<const unsigned char *>(d_in_z0) + (size_t)z0 * in_stride * d.nro * p->nchan * elem,
+                                 zfirst + z0, cz, 0, in_stride_spokes, false);
+        if (rc) return rc;
+        if ((rc = combine_coils(p, static_cast<float2 *>(d_out) + (size_t)z0 * d.nt * d.nx * d.ny, p->d_coil_tmp, cz))) return rc;
+    }
+    return TRON_OK;
+}
+
+int forward_run(tron_plan *p, void *d_out, const void *d_in, int nimg, const float2 *trig, int trig_img_stride,
+                const float *deapod)
+{
+    const tron_dims &d = p->d;
+    const size_t n2 = (size_t)d.nxos * d.nyos;
+    const bool square = d.nx == d.ny;
+    if (!trig) trig = p->d_trig;
+    if (!deapod) deapod = p->d_deapod;
+    if (int erc = ensure_work(p, std::max(1, std::min(p->chunk, nimg)))) return erc;
+    for (int k0 = 0; k0 < nimg; k0 += p->chunk) {
+        const int ck = std::min(p->chunk, nimg - k0);
+        const float2 *img = static_cast<const float2 *>(d_in) + (size_t)k0 * p->nchan * d.nx * d.ny;
+        if (p->fft512) {
+            // fused: pad + deapodise + shift + pruned forward FFT (tron_fft512.hip)
+            StageTimer t(p, STAGE_FFT);
+            HIP_TRY(launch_fft512_forward(img, p->d_fft_tmp, p->d_grid, p->d_tw512, deapod, p->nchan, ck, p->stream));
+        } else {
+            PreParams a;
+            a.img = img;
+            a.fft = p->d_grid;
+            a.inv_deapod = deapod;
+            a.nx = d.nx;
+            a.nxos = d.nxos;
+            a.nchan = p->nchan;
+            a.nimg = ck;
+            a.ny = square ? 0 : d.ny;
+            a.nyos = square ? 0 : d.nyos;
+            {
+                StageTimer t(p, STAGE_PRE);
+                HIP_TRY(launch_pre(a, p->stream));
+            }
+            int rc = run_fft(p, p->d_grid, ck * p->nchan, 0);
+            if (rc) return rc;
+        }
+        DegridParams g;
+        memset(&g, 0, sizeof(g));
+        g.udata = p->d_grid;
+        g.nudata = static_cast<float2 *>(d_out) + (size_t)k0 * p->nchan * d.nro * d.npe1work;
+        g.trig = trig + (size_t)k0 * trig_img_stride;
+        g.trig_img_stride = trig_img_stride;
+        g.tile_order = p->d_tile_order32;
+        g.in_z = (long long)p->nchan * n2;
+        g.in_c = (long long)n2;
+        g.in_p = 1;
+        g.in_shift = 1;
+        g.in_transposed = p->fft512 ? 1 : 0;      // launch_fft512_forward stores the grid transposed
+        g.debug = p->debug_skip;
+        g.n = d.nxos;
+        g.nrows = square ? 0 : d.nyos;
+        g.nrep = p->nchan;
+        g.nro = d.nro;
+        g.npe = d.npe1work;
+        g.nimg = ck;
+        g.W = p->cfg.kernwidth;
+        g.beta = p->beta;
+        memcpy(g.kb_poly, p->kb_poly, sizeof(g.kb_poly));
+        {
+            StageTimer t(p, STAGE_DEGRID);
+            if (p->cfg.kernwidth <= 3.f && !p->degrid_simple && square)
+                HIP_TRY(launch_degrid_tile(g, p->kb_mode, p->stream));
+            else
+                HIP_TRY(launch_degrid(g, p->kb_mode, p->stream));      // also every non-square grid (supported, not tuned)
+        }
+    }
+    return TRON_OK;
+}
+
+// CGNR, src/tron.cu:665-720 as Knopp et al. 2007 Alg. 1 intends it (the reference marks its own version "NOT WORKING
+// CORRECTLY YET", :670; DESIGN.md lists the five repairs F1-F5), for slices [zfirst, zfirst+zcount) of a
+// device-resident spoke stream, all slices of a chunk advancing together.  d_out: combine ? SoS images [z][nx*ny]
+// : coil images [z][nchan*id + c].
+int cgnr_run(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, int zcount, int combine)
+{
+    const tron_dims &d = p->d;
+    if (p->cfg.input_half) return fail(TRON_ERR_UNSUPPORTED, "CGNR needs complex64 k-space (the residual lives in fp32)");
+    const size_t n = (size_t)p->nchan * d.nro * d.npe1work;          // data-space elements per slice
+    const size_t N = (size_t)p->nchan * d.nx * d.ny;                 // image-space elements per slice (F2)
+    const size_t spoke_bytes = (size_t)d.nro * p->nchan * sizeof(float2);
+    const int step = std::max(1, std::min(p->chunk, zcount));
+    if (p->cg_slices < step) {
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        for (void *q : {(void *)p->d_cg_r, (void *)p->d_cg_v, (void *)p->d_cg_zt, (void *)p->d_cg_pt, (void *)p->d_cg_x,
+                        (void *)p->d_cg_partial, (void *)p->d_cg_num, (void *)p->d_cg_coef})
+            if (q) HIP_TRY(hipFree(q));
+        p->d_cg_r = p->d_cg_v = p->d_cg_zt = p->d_cg_pt = p->d_cg_x = nullptr;
+        p->d_cg_partial = p->d_cg_num = nullptr; p->d_cg_coef = nullptr; p->cg_slices = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_cg_r), step * n * sizeof(float2)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_cg_v), step * n * sizeof(float2)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_cg_zt), step * N * sizeof(float2)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_cg_pt), step * N * sizeof(float2)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_cg_x), step * N * sizeof(float2)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_cg_partial), (size_t)step * kCgPartials * sizeof(double)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_cg_num), step * sizeof(double)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_cg_coef), step * sizeof(float)));
+        p->cg_slices = step;
+    }
+    const float unscale = (float)d.nxos * (float)d.npe1work;          // F3: the gridding kernel's 1/nxos/npe (src/tron.cu:532) divided out
+    const int golden = p->cfg.golden_angle;
+    hipStream_t st = p->stream;
+    int rc;
+    for (int z0 = 0; z0 < zcount; z0 += step) {
+        const int cz = std::min(step, zcount - z0);
+        const unsigned char *y = static_cast<const unsigned char *>(d_in_z0) + (size_t)z0 * d.prof_slide * spoke_bytes;
+        // r = y: the (overlapping) windows of the stream, one contiguous copy per slice (:685; F5)
+        for (int z = 0; z < cz; ++z)
+            HIP_TRY(hipMemcpyAsync(p->d_cg_r + (size_t)z * n, y + (size_t)z * d.prof_slide * spoke_bytes, n * sizeof(float2),
+                                   hipMemcpyDeviceToDevice, st));
+        // ztilde = A^H W r (:686), ptilde = ztilde (:687), x = 0 (:683)
+        if ((rc = adjoint_run(p, p->d_cg_zt, p->d_cg_r, zfirst + z0, cz, 0, d.npe1work))) return rc;
+        HIP_TRY(launch_cg_scale_norm2(p->d_cg_zt, N, cz, unscale, p->d_cg_partial, st));
+        HIP_TRY(launch_cg_finish(p->d_cg_partial, p->d_cg_num, p->d_cg_coef, 0, cz, st));
+        HIP_TRY(hipMemcpyAsync(p->d_cg_pt, p->d_cg_zt, cz * N * sizeof(float2), hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemsetAsync(p->d_cg_x, 0, cz * N * sizeof(float2), st));
+        // the forward operator's angles: the slice's own index range (F4); golden angles are shared with the adjoint's table
+        const float2 *trig = golden ? p->d_trig + (size_t)(zfirst + z0) * d.prof_slide : (p->d_trig_fwd ? p->d_trig_fwd : p->d_trig);
+        const int trig_stride = golden ? d.prof_slide : 0;
+        for (int t = 0; t < p->cfg.niter; ++t) {
+            if ((rc = forward_run(p, p->d_cg_v, p->d_cg_pt, cz, trig, trig_stride, p->d_deapod_fwd))) return rc;   // v = A ptilde (:691)
+            HIP_TRY(launch_cg_wnorm2(p->d_cg_v, n, cz, p->nchan, d.nro, p->dcf_a, p->dcf_b, p->d_cg_partial, st));  // <W v, v> (:693,696)
+            HIP_TRY(launch_cg_finish(p->d_cg_partial, p->d_cg_num, p->d_cg_coef, 1, cz, st));                       // alpha (:697; F1)
+            HIP_TRY(launch_cg_axpy(p->d_cg_x, p->d_cg_pt, p->d_cg_coef, 1.f, N, cz, st));                            // x += alpha ptilde (:699)
+            if (t == p->cfg.niter - 1) break;                                                                       // (:701)
+            HIP_TRY(launch_cg_axpy(p->d_cg_r, p->d_cg_v, p->d_cg_coef, -1.f, n, cz, st));                           // r -= alpha v (:703)
+            if ((rc = adjoint_run(p, p->d_cg_zt, p->d_cg_r, zfirst + z0, cz, 0, d.npe1work))) return rc;            // ztilde = A^H W r (:707)
+            HIP_TRY(launch_cg_scale_norm2(p->d_cg_zt, N, cz, unscale, p->d_cg_partial, st));
+            HIP_TRY(launch_cg_finish(p->d_cg_partial, p->d_cg_num, p->d_cg_coef, 2, cz, st));                       // beta (:709; F1)
+            HIP_TRY(launch_cg_xpby(p->d_cg_pt, p->d_cg_zt, p->d_cg_coef, N, cz, st));                               // ptilde = ztilde + beta ptilde (:710)
+        }
+        if (combine) {
+            if ((rc = combine_coils(p, static_cast<float2 *>(d_out) + (size_t)z0 * d.nt * d.nx * d.ny, p->d_cg_x, cz))) return rc;        // (:764)
+        } else
+            HIP_TRY(hipMemcpyAsync(static_cast<float2 *>(d_out) + (size_t)z0 * N, p->d_cg_x, cz * N * sizeof(float2), hipMemcpyDeviceToDevice, st));   // (:713)
+    }
+    return TRON_OK;
+}
+
+int ensure_buffer(void **buf, size_t *have, size_t want)
+{
+    if (*have >= want && *buf) return TRON_OK;
+    if (*buf) HIP_TRY(hipFree(*buf));
+    *buf = nullptr;
+    *have = 0;
+    HIP_TRY(hipMalloc(buf, want));
+    *have = want;
+    return TRON_OK;
+}
+
+int check_errflag(tron_plan *p)
+{
+    unsigned int flag = 0;
+    HIP_TRY(hipMemcpy(&flag, p->d_errflag, sizeof(flag), hipMemcpyDeviceToHost));
+    if (flag) {
+        HIP_TRY(hipMemset(p->d_errflag, 0, sizeof(flag)));
+        return fail(TRON_ERR_HIP, "gridding kernel reported an internal overflow (flag %u)", flag);
+    }
+    return TRON_OK;
+}
+
+}  // namespace tron
