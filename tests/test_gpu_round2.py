@@ -73,25 +73,56 @@ def test_multi_device_workers_in_one_process(tmp_path):
     assert open(a, "rb").read() == open(b, "rb").read()
 
 
-def test_split_centre_tiles_are_deterministic_and_agree_with_unsplit(oracle, monkeypatch):
-    """Launches of fewer than 64 slices deal the k-space-centre tiles to several workgroups over disjoint spoke ranges
-    and add the partial tiles in a fixed order: bit-identical run to run, and equal to the unsplit kernel up to fp32
-    summation order (src/tron.cu:507-530 sums spoke by spoke)."""
+def test_centre_relief_and_split_tiles_are_deterministic_and_agree_with_the_plain_kernel(oracle, monkeypatch):
+    """The k-space-centre tiles' corner blocks see every spoke.  Grids whose centre is a tile corner take the samples
+    |r| < 14 out of those tiles and grid them with workgroups of their own (the origin-centred inner tile, dealt over
+    spoke ranges, added onto the centre tiles in a fixed order); other grids deal whole centre tiles to several workgroups
+    when the launch is small.  Both are bit-identical run to run and equal to the plain kernel up to fp32 summation order
+    (src/tron.cu:507-530 sums spoke by spoke)."""
     data = synth.kspace(2, 512, 402 * 3, seed=1301)
     flags = dict(golden_angle=1, data_undersamp=0.7852, prof_slide=402)
-    a, dims = lib.recon(data, adjoint=True, **flags)
+    a, dims = lib.recon(data, adjoint=True, **flags)                  # centre relief (default for a 512^2 grid)
     b, _ = lib.recon(data, adjoint=True, **flags)
     assert dims.nz == 3 and np.array_equal(a, b)
-    monkeypatch.setenv("TRON_SPLIT_BELOW", "0")                      # never split
+    monkeypatch.setenv("TRON_CENTRE_RELIEF", "0")
+    s1, _ = lib.recon(data, adjoint=True, **flags)                    # whole centre tiles split over spoke ranges (3 < 64 slices)
+    s2, _ = lib.recon(data, adjoint=True, **flags)
+    assert np.array_equal(s1, s2)
+    monkeypatch.setenv("TRON_SPLIT_BELOW", "0")                      # neither: the plain kernel
     c, _ = lib.recon(data, adjoint=True, **flags)
-    assert not np.array_equal(a, c), "the split path did not run"
-    assert rel_l2(a, c) <= 2e-6
+    assert not np.array_equal(a, c), "the relief path did not run"
+    assert not np.array_equal(s1, c), "the split path did not run"
+    assert rel_l2(a, c) <= 2e-6 and rel_l2(s1, c) <= 2e-6
     want, _ = oracle.recon(data, adjoint=1, zfirst=1, zcount=1, golden=1, data_undersamp=0.7852, prof_slide=402)
     assert rel_l2(a[..., 1], want[..., 1]) <= 1e-5
+    assert rel_l2(s1[..., 1], want[..., 1]) <= 1e-5
     monkeypatch.setenv("TRON_SPLIT_BELOW", "64")
     monkeypatch.setenv("TRON_SPLIT_TARGET", "700")                   # many tiles split, up to 8 parts
     e, _ = lib.recon(data, adjoint=True, **flags)
     assert rel_l2(e, c) <= 2e-6
+
+
+@pytest.mark.parametrize("W", [1.0, 2.0, 3.0])
+@pytest.mark.parametrize("nxos_nro", [(128, 128), (192, 96), (256, 256)])
+def test_centre_relief_shapes(oracle, monkeypatch, W, nxos_nro):
+    """Centre relief on every grid it applies to (centre on a tile corner: nxos a multiple of 64) for the three kernel
+    widths' inner radii (15, 14, 13), few spokes (one part) and many (several parts), 1 / 4 / 6 coils; against the oracle
+    and against the plain kernel."""
+    nxos, nro = nxos_nro
+    for nc, npe, nz in ((1, 7, 2), (6, 120, 2), (4, 333, 1)):
+        data = synth.kspace(nc, nro, npe * nz, seed=1400 + nc)
+        us = (npe + 0.5) / nro                                       # nro * us truncates to npe (src/tron.cu:916-919)
+        flags = dict(golden_angle=1, data_undersamp=us, prof_slide=npe, kernwidth=W, gridos=2.0 * nxos / nro)
+        got, dims = lib.recon(data, adjoint=True, **flags)
+        assert (dims.nxos, dims.nz, dims.npe1work) == (nxos, nz, npe)
+        want, _ = oracle.recon(data, adjoint=1, golden=1, data_undersamp=us, prof_slide=npe, kernwidth=W, gridos=2.0 * nxos / nro)
+        assert rel_l2(got, want) <= 1e-5, (W, nxos, nc, npe)
+        monkeypatch.setenv("TRON_CENTRE_RELIEF", "0")
+        monkeypatch.setenv("TRON_SPLIT_BELOW", "0")
+        plain, _ = lib.recon(data, adjoint=True, **flags)
+        monkeypatch.delenv("TRON_CENTRE_RELIEF")
+        monkeypatch.delenv("TRON_SPLIT_BELOW")
+        assert rel_l2(got, plain) <= 2e-6
 
 
 @pytest.mark.parametrize("kb", [lib.KB_FAST, lib.KB_EXACT])

@@ -73,6 +73,8 @@ struct BinLds {
 };
 
 // Stores the two horizontally adjacent points (X0, Y), (X0+1, Y) of coil c, slice z: v = (re0, im0, re1, im1).
+// ACC: adds to what is stored there (the origin-centred inner tile lands on the four centre tiles' corners).
+template <bool ACC = false>
 __device__ __forceinline__ void store_point_pair(const GridParams &p, int z, int c, int X0, int Y, const float4 v)
 {
     const int n = p.nxos, h = n / 2;
@@ -84,23 +86,79 @@ __device__ __forceinline__ void store_point_pair(const GridParams &p, int z, int
     const bool pair = (X0 + 1 + h < n) && p.out_p == 1 && (colA & 1) == 0;
     float2 *o = p.udata + (size_t)z * p.out_z + ((size_t)row * n + colA) * p.out_p + (size_t)c * p.out_c;
     if (pair && (n & 1) == 0) {
-        *reinterpret_cast<float4 *>(o) = v;
+        float4 w = v;
+        if (ACC) {
+            const float4 old = *reinterpret_cast<const float4 *>(o);
+            w.x += old.x; w.y += old.y; w.z += old.z; w.w += old.w;
+        }
+        *reinterpret_cast<float4 *>(o) = w;
     } else {
-        if (X0 + h < n) o[0] = make_float2(v.x, v.y);
+        if (X0 + h < n) o[0] = ACC ? make_float2(o[0].x + v.x, o[0].y + v.y) : make_float2(v.x, v.y);
         if (X0 + 1 + h < n) {
             const int colB = p.out_shift ? (X0 + 1 < 0 ? X0 + 1 + n : X0 + 1) : X0 + 1 + h;
-            p.udata[(size_t)z * p.out_z + ((size_t)row * n + colB) * p.out_p + (size_t)c * p.out_c] = make_float2(v.z, v.w);
+            float2 *ob = p.udata + (size_t)z * p.out_z + ((size_t)row * n + colB) * p.out_p + (size_t)c * p.out_c;
+            *ob = ACC ? make_float2(ob->x + v.z, ob->y + v.w) : make_float2(v.z, v.w);
         }
     }
 }
 
+// How the k-space samples of a batch reach LDS:
+//   kInRegs32 / kInRegs16  loaded into registers one batch ahead (fp32 / complex-half), scaled by the density
+//                          compensation and written to LDS by the staging pass (any coil count, slice groups);
+//   kInLdsDma              fp32, even coil counts: `global_load_lds_dwordx4` copies each sample's coil pairs straight
+//                          into the [pair][record] image (lane-linear: record = lane), no registers, no ds_write pass;
+//                          the density compensation is folded into the x weights instead.  The copies are issued when
+//                          the batch opens and must have landed before its apply loop: they fly under staging, scan
+//                          and placement, which is why the barriers in between are raw (LDS counter only) -- a
+//                          __syncthreads() there would wait for them.
+enum { kInRegs32 = 0, kInRegs16 = 1, kInLdsDma = 2 };
+
+// LDS-only workgroup barrier: every LDS access of this wave has completed; outstanding global loads keep flying.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+__device__ __forceinline__ unsigned lds_addr(const void *q)    // byte address inside the workgroup's LDS allocation
+{
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const void *)q;
+}
+
+// One 16-byte-per-lane copy global -> LDS: lane l's bytes land at lds_dst + 16 l (lds_dst wave-uniform).  Issued from
+// inline assembly on purpose: hipcc would otherwise wait vmcnt(0) before the next LDS read of ANY address.
+__device__ __forceinline__ void lds_dma16(const void *gsrc, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(__builtin_amdgcn_readfirstlane((int)lds_dst)) : "memory");
+}
+
+// Phase clock of tools/gridprof.py (-DTRON_BIN_PROFILE builds only): shader-clock cycles per wave and phase, summed
+// over all waves of all launches since the last read; production builds carry none of it.
+#ifdef TRON_BIN_PROFILE
+constexpr int kProfSlots = 16, kProfCopies = 4096;               // copies: same-address atomics would dominate the kernel
+__device__ unsigned long long g_bin_prof[kProfCopies * kProfSlots];
+#define PROF_DECL unsigned prof_acc[kProfSlots] = {}; unsigned long long prof_t = __builtin_readcyclecounter()
+#define PROF_MARK(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); prof_acc[i] += (unsigned)(t_ - prof_t); prof_t = t_; } while (0)
+#define PROF_FLUSH do { if (lane == 0) { for (int i_ = 0; i_ < kProfSlots; ++i_) if (prof_acc[i_]) atomicAdd(&g_bin_prof[((blockIdx.x * 4 + wave) % kProfCopies) * kProfSlots + i_], (unsigned long long)prof_acc[i_]); } } while (0)
+#else
+#define PROF_DECL
+#define PROF_MARK(i)
+#define PROF_FLUSH
+#endif
+
 #ifndef TRON_BIN_WAVES
 #define TRON_BIN_WAVES 3
 #endif
-template <int CPB, int CW, bool HALF>
+template <int CPB, int CW, int IN>
 __global__ void __launch_bounds__(kBinThreads, TRON_BIN_WAVES)
 grid_binned_kernel(const GridParams p)
 {
+    constexpr bool HALF = IN == kInRegs16;
+    constexpr bool DMA = IN == kInLdsDma;
+    static_assert(!DMA || CPB % 2 == 0, "LDS-DMA staging copies coil pairs");
     using C = BinCfg<CPB, CW>;
     extern __shared__ __align__(16) unsigned char lds_raw[];
     BinLds<CPB, CW> &L = *reinterpret_cast<BinLds<CPB, CW> *>(lds_raw);
@@ -125,13 +183,20 @@ grid_binned_kernel(const GridParams p)
     const int n = p.nxos;
     const int h = n / 2;
     const int rmax = n / 2 - 1;
-    if (tile < 0 || tile >= p.ntiles) {
+    // inner_r0 > 0 (centre relief): the radial sampling density ~ npe / (pi r) makes the point blocks next to the k-space
+    // centre the serial chain of the four tiles that meet there (their corner blocks see every spoke, a typical block
+    // 1 in 80), so samples |r| < inner_r0 are taken OUT of those tiles and gridded by workgroups of their own: the
+    // "inner tile" (id ntiles) is the 32x32 square centred on the origin, dealt over spoke ranges like a split tile, and
+    // grid_reduce_parts_kernel adds its parts onto the centre tiles' corners.
+    const bool inner = p.inner_r0 > 0 && tile == p.ntiles;
+    if (tile < 0 || (tile >= p.ntiles && !inner)) {
         if (threadIdx.x == 0) atomicOr(p.errflag, 128u);
         return;
     }
 
-    const int x0 = (tile % p.tiles_per_row) * kBinTile - h;     // tile origin, centred coordinates
-    const int y0 = (tile / p.tiles_per_row) * kBinTile - h;
+    const int x0 = inner ? -kBinTile / 2 : (tile % p.tiles_per_row) * kBinTile - h;     // tile origin, centred coordinates
+    const int y0 = inner ? -kBinTile / 2 : (tile / p.tiles_per_row) * kBinTile - h;
+    const bool outer = p.inner_r0 > 0 && !inner && (x0 == 0 || x0 == -kBinTile) && (y0 == 0 || y0 == -kBinTile);
     if (p.skip_outside) {
         // nearest point of the tile to the k-space centre; beyond rmax + W every band is empty (src/tron.cu:498-502,512)
         const int ax = max(max(x0, -(x0 + kBinTile - 1)), 0), ay = max(max(y0, -(y0 + kBinTile - 1)), 0);
@@ -175,6 +240,7 @@ grid_binned_kernel(const GridParams p)
     const float by_lo = (float)y0 - p.W - eps, by_hi = (float)(y0 + kBinTile - 1) + p.W + eps;
     const int cx0 = x0 - CW, cy0 = y0 - CW;                     // base cell (0,0) of the histogram
 
+    PROF_DECL;
     for (int round0 = pe_lo; round0 < pe_hi && TRON_DBG_LT(p, 4); round0 += kBinMaxSpokes) {
         // ---- clip: one thread per spoke, accepted spokes compacted in acquisition order ---------
         if (tid == 0) L.sp_start[0] = 0;
@@ -193,6 +259,20 @@ grid_binned_kernel(const GridParams p)
                 if (lo <= hi) {
                     rlo = (int)ceilf(lo);
                     int rhi = (int)floorf(hi);
+                    if (inner) {                                // only the samples the centre tiles leave out
+                        rlo = max(rlo, 1 - p.inner_r0);
+                        rhi = min(rhi, p.inner_r0 - 1);
+                    } else if (outer) {
+                        // a quadrant tile holds one side of a spoke plus at most W sqrt(2) < inner_r0 beyond the origin
+                        if (rhi >= p.inner_r0) {
+                            if (rlo <= -p.inner_r0) atomicOr(p.errflag, 16u);
+                            rlo = max(rlo, p.inner_r0);
+                        } else if (rlo <= -p.inner_r0) {
+                            rhi = min(rhi, -p.inner_r0);
+                        } else {
+                            rhi = rlo - 1;
+                        }
+                    }
                     if (rhi - rlo + 1 > C::SLOT) {              // cannot happen for a 32x32 tile with W <= 4
                         atomicOr(p.errflag, 2u);
                         rhi = rlo + C::SLOT - 1;
@@ -246,7 +326,8 @@ grid_binned_kernel(const GridParams p)
         //      b+1 are fetched into registers while batch b is scanned, placed and applied ----------
         constexpr int RPT = (C::NREC + kBinThreads - 1) / kBinThreads;      // records per thread per batch
         int pf_pe[RPT], pf_r[RPT];
-        float2 pf_d[RPT][CPB];
+        float2 pf_cs[RPT];                                      // the spoke's (cos, sin): fetched with the batch, not in the staging pass
+        float2 pf_d[DMA ? 1 : RPT][DMA ? 1 : CPB];
         auto batch_end = [&](int s0) {
             const int base = L.sp_start[s0];
             int s1 = s0 + 1;
@@ -272,72 +353,102 @@ grid_binned_kernel(const GridParams p)
                     const int r = (int)(short)(L.sp_seg[lo] & 0xffff) + (target - L.sp_start[lo]);
                     pf_pe[j] = pe;
                     pf_r[j] = r;
-                    const int ro = (p.nro == n ? r : (r * p.nro) / n) + p.nro / 2;   // src/tron.cu:517,519 (truncating division)
-                    const size_t sbase = ((size_t)p.nro * pe + ro) * p.nchan + c0;
-                    if (vs > 1) {
-                        // channel c = (slice c / nchan of the group, coil c % nchan): one load per channel, each coalesced along the spoke
-#pragma unroll
-                        for (int c = 0; c < CPB; ++c)
-                            pf_d[j][c] = c < ncb ? load_sample<HALF>(in_bytes, (size_t)(c / p.nchan) * (size_t)p.in_slice_stride + sbase + (c % p.nchan))
-                                                 : make_float2(0.f, 0.f);
-                    } else if (!HALF && CPB % 2 == 0 && (ncb & 1) == 0 && (p.nchan & 1) == 0 && (c0 & 1) == 0) {
-                        // the coils of one sample are contiguous: 16-byte loads (coils beyond ncb are zero padding)
-                        const float4 *src4 = reinterpret_cast<const float4 *>(reinterpret_cast<const float2 *>(in_bytes) + sbase);
-#pragma unroll
-                        for (int c = 0; c < CPB / 2; ++c) {
-                            const float4 v = 2 * c < ncb ? src4[c] : make_float4(0.f, 0.f, 0.f, 0.f);
-                            pf_d[j][2 * c] = make_float2(v.x, v.y);
-                            pf_d[j][2 * c + 1] = make_float2(v.z, v.w);
-                        }
-                    } else if (HALF && CPB % 4 == 0 && ncb == CPB && (p.nchan & 3) == 0 && (c0 & 3) == 0) {
-                        // complex-half storage: four coils of one sample per 16-byte load
-                        const uint4 *src4 = reinterpret_cast<const uint4 *>(reinterpret_cast<const __half2 *>(in_bytes) + sbase);
-#pragma unroll
-                        for (int c = 0; c < CPB / 4; ++c) {
-                            const uint4 v = src4[c];
-                            const unsigned w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) {
-                                __half2 hh;
-                                __builtin_memcpy(&hh, &w[k], 4);
-                                pf_d[j][4 * c + k] = __half22float2(hh);
+                    pf_cs[j] = trig[pe];
+                    if constexpr (!DMA) {
+                        const int ro = (p.nro == n ? r : (r * p.nro) / n) + p.nro / 2;   // src/tron.cu:517,519 (truncating division)
+                        const size_t sbase = ((size_t)p.nro * pe + ro) * p.nchan + c0;
+                        if (vs > 1) {
+                            // channel c = (slice c / nchan of the group, coil c % nchan): one load per channel, each coalesced along the spoke
+    #pragma unroll
+                            for (int c = 0; c < CPB; ++c)
+                                pf_d[j][c] = c < ncb ? load_sample<HALF>(in_bytes, (size_t)(c / p.nchan) * (size_t)p.in_slice_stride + sbase + (c % p.nchan))
+                                                     : make_float2(0.f, 0.f);
+                        } else if (!HALF && CPB % 2 == 0 && (ncb & 1) == 0 && (p.nchan & 1) == 0 && (c0 & 1) == 0) {
+                            // the coils of one sample are contiguous: 16-byte loads (coils beyond ncb are zero padding)
+                            const float4 *src4 = reinterpret_cast<const float4 *>(reinterpret_cast<const float2 *>(in_bytes) + sbase);
+    #pragma unroll
+                            for (int c = 0; c < CPB / 2; ++c) {
+                                const float4 v = 2 * c < ncb ? src4[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+                                pf_d[j][2 * c] = make_float2(v.x, v.y);
+                                pf_d[j][2 * c + 1] = make_float2(v.z, v.w);
                             }
+                        } else if (HALF && CPB % 4 == 0 && ncb == CPB && (p.nchan & 3) == 0 && (c0 & 3) == 0) {
+                            // complex-half storage: four coils of one sample per 16-byte load
+                            const uint4 *src4 = reinterpret_cast<const uint4 *>(reinterpret_cast<const __half2 *>(in_bytes) + sbase);
+    #pragma unroll
+                            for (int c = 0; c < CPB / 4; ++c) {
+                                const uint4 v = src4[c];
+                                const unsigned w[4] = {v.x, v.y, v.z, v.w};
+    #pragma unroll
+                                for (int k = 0; k < 4; ++k) {
+                                    __half2 hh;
+                                    __builtin_memcpy(&hh, &w[k], 4);
+                                    pf_d[j][4 * c + k] = __half22float2(hh);
+                                }
+                            }
+                        } else {
+    #pragma unroll
+                            for (int c = 0; c < CPB; ++c)
+                                pf_d[j][c] = c < ncb ? load_sample<HALF>(in_bytes, sbase + c) : make_float2(0.f, 0.f);
                         }
-                    } else {
-#pragma unroll
-                        for (int c = 0; c < CPB; ++c)
-                            pf_d[j][c] = c < ncb ? load_sample<HALF>(in_bytes, sbase + c) : make_float2(0.f, 0.f);
                     }
                 }
             }
         };
 
         int sp0 = 0, sp1 = 0;
+        PROF_MARK(0);                                           // setup + clip + segment scan
         if (nacc > 0 && TRON_DBG_LT(p, 3)) {
             sp1 = batch_end(0);
             if (TRON_DBG_LT(p, 2)) prefetch(0, sp1);
         }
+        PROF_MARK(1);                                           // first prefetch
         while (sp0 < nacc && TRON_DBG_LT(p, 3)) {
             const int rec_base = L.sp_start[sp0];
             const int nrec = L.sp_start[sp1] - rec_base;
 
+            float pf_kx[RPT], pf_ky[RPT];
+#pragma unroll
+            for (int j = 0; j < RPT; ++j) {                           // (first use of the prefetched registers: every ordinary load has landed)
+                pf_kx[j] = (float)pf_r[j] * pf_cs[j].x;               // src/tron.cu:514-515
+                pf_ky[j] = (float)pf_r[j] * pf_cs[j].y;
+            }
+            if constexpr (DMA) {
+                // this batch's samples, global -> LDS image [pair][record]: the previous apply loop (the only reader of
+                // L.d) ended at the barrier that closed the last iteration
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int j = 0; j < RPT; ++j) {
+                    const int rec = tid + j * kBinThreads;
+                    if (rec < nrec && TRON_DBG_LT(p, 2)) {
+                        const int r = pf_r[j];
+                        const int ro = (p.nro == n ? r : (r * p.nro) / n) + p.nro / 2;   // src/tron.cu:517,519 (truncating division)
+                        const float2 *src = reinterpret_cast<const float2 *>(in_bytes) + ((size_t)p.nro * pf_pe[j] + ro) * p.nchan + c0;
+                        const unsigned dst0 = lds_addr(reinterpret_cast<const float4 *>(L.d) + j * kBinThreads + wave * 64);
+#pragma unroll
+                        for (int c = 0; c < CPB / 2; ++c)
+                            if (2 * c < ncb) lds_dma16(src + 2 * c, dst0 + (unsigned)(c * C::NREC * sizeof(float4)));
+                    }
+                }
+            }
             for (int c = tid; c < C::NCELLS; c += kBinThreads) L.hist[c] = 0u;
-            __syncthreads();
+            PROF_MARK(2);                                       // first use of the prefetch, DMA issue, histogram clear
+            lds_barrier();
+            PROF_MARK(3);                                       // barrier
 
             // ---- A. stage + count: records are dealt out flat, 64 consecutive records per wave pass ----
 #pragma unroll
             for (int j = 0; j < RPT; ++j) {
                 const int rec = tid + j * kBinThreads;
                 if (rec >= nrec || !TRON_DBG_LT(p, 2)) continue;
-                const int pe = pf_pe[j], r = pf_r[j];
-                const float2 cs = trig[pe];
-                const float kx = (float)r * cs.x;                     // src/tron.cu:514-515
-                const float ky = (float)r * cs.y;
+                const int r = pf_r[j];
+                const float kx = pf_kx[j], ky = pf_ky[j];
                 const int fx = (int)floorf(kx), fy = (int)floorf(ky);
                 const int bx = fx - CW + 1, by = fy - CW + 1;
                 float *wxr = L.wx + rec * C::NWP, *wyr = L.wy + rec * C::NWP;
                 wxr[0] = 0.f; wxr[C::NWP - 1] = 0.f;
                 wyr[0] = 0.f; wyr[C::NWP - 1] = 0.f;
+                float sdc;
                 {   // the 2 x NW weights as NW interleaved packed polynomials (x and y share an instruction); each
                     // component is the fmaf chain of kb_weight<TRON_KB_FAST>                    src/tron.cu:516
                     v2f dxy[C::NW], sxy[C::NW], wxy[C::NW];
@@ -355,17 +466,19 @@ grid_binned_kernel(const GridParams p)
 #pragma unroll
                         for (int i = 0; i < C::NW; ++i) wxy[i] = __builtin_elementwise_fma(wxy[i], sxy[i], cf);
                     }
+                    const int ro = (p.nro == n ? r : (r * p.nro) / n) + p.nro / 2;
+                    sdc = 1.0f;
+                    if (p.apply_dcf) sdc = p.dcf_a * fabsf((float)ro - (float)(p.nro / 2)) + p.dcf_b;   // src/tron.cu:412
+                    const float sx = DMA ? sdc : 1.0f;               // LDS-DMA: the samples are in LDS unscaled, the x weights carry the DCF
 #pragma unroll
                     for (int i = 0; i < C::NW; ++i) {
-                        wxr[1 + i] = fabsf(dxy[i].x) < kb.W ? wxy[i].x : 0.0f;
+                        wxr[1 + i] = fabsf(dxy[i].x) < kb.W ? wxy[i].x * sx : 0.0f;
                         wyr[1 + i] = fabsf(dxy[i].y) < kb.W ? wxy[i].y : 0.0f;
                     }
                 }
-                const int ro = (p.nro == n ? r : (r * p.nro) / n) + p.nro / 2;
-                float sdc = 1.0f;
-                if (p.apply_dcf) sdc = p.dcf_a * fabsf((float)ro - (float)(p.nro / 2)) + p.dcf_b;   // src/tron.cu:412
                 // samples go to LDS coil-pair-major ([pair][record], 16 bytes each): conflict-free stores
-                if (CPB % 2 == 0) {
+                if constexpr (DMA) {
+                } else if (CPB % 2 == 0) {
                     float4 *dst4 = reinterpret_cast<float4 *>(L.d);
 #pragma unroll
                     for (int c = 0; c < CPB / 2; ++c) {
@@ -392,6 +505,7 @@ grid_binned_kernel(const GridParams p)
                     L.rank[rec] = (unsigned char)rk;
                 }
             }
+            PROF_MARK(4);                                       // stage
             // next batch: bounds now, samples in flight while this batch is scanned / placed / applied
             const int nsp0 = sp1;
             int nsp1 = nsp0;
@@ -399,7 +513,9 @@ grid_binned_kernel(const GridParams p)
                 nsp1 = batch_end(nsp0);
                 if (TRON_DBG_LT(p, 2)) prefetch(nsp0, nsp1);
             }
-            __syncthreads();
+            PROF_MARK(5);                                       // next batch: bounds + prefetch
+            lds_barrier();
+            PROF_MARK(6);                                       // barrier
 
             // ---- B. exclusive scan over cells ------------------------------------------------
             {
@@ -419,7 +535,7 @@ grid_binned_kernel(const GridParams p)
                     if (lane >= o) v += t;
                 }
                 if (lane == 63) L.wcnt[wave] = v;
-                __syncthreads();
+                lds_barrier();
                 int run = v - tsum;
 #pragma unroll
                 for (int w = 0; w < 4; ++w)
@@ -431,7 +547,9 @@ grid_binned_kernel(const GridParams p)
                     run += cnt[k];
                 }
             }
-            __syncthreads();
+            PROF_MARK(7);                                       // scan (one barrier inside)
+            lds_barrier();
+            PROF_MARK(8);                                       // barrier
 
             // ---- C. place record ids in cell order ---------------------------------------------
             for (int rec = tid; rec < nrec; rec += kBinThreads) {
@@ -448,7 +566,11 @@ grid_binned_kernel(const GridParams p)
                     L.sorted[pos] = (unsigned)rec | ((key & 63u) << 10) | (((key >> 12) & 0x3fffu) << 16) | (((key >> 29) & 1u) << 30);
                 }
             }
-            __syncthreads();
+            PROF_MARK(9);                                       // place
+            if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the batch's samples are in LDS
+            PROF_MARK(10);                                      // wait for the DMA
+            lds_barrier();
+            PROF_MARK(11);                                      // barrier
 
             // ---- D. apply: each thread walks the 2CW+1 cell rows its 2x2 points can see as ONE loop
             //         (row ranges concatenated), so a wave runs max-over-lanes(total), not sum of row maxima
@@ -483,6 +605,13 @@ grid_binned_kernel(const GridParams p)
                         if (i1 < total) ent_next = L.sorted[i1 + dl_next];
                     }
                     const int id = (int)(ent & 1023u);
+                    // the samples are asked for FIRST, with the weights: one LDS round trip per visit, not two
+                    float4 dd[CPB / 2 > 0 ? CPB / 2 : 1];
+                    if (CPB % 2 == 0) {
+                        const float4 *d4 = reinterpret_cast<const float4 *>(L.d) + id;
+#pragma unroll
+                        for (int c = 0; c < CPB / 2; ++c) dd[c] = d4[c * C::NREC];
+                    }
                     const int jp = 2 * CW - row;                       // padded wy index for row Y0 (Y0+1 uses jp+1)
                     const int ip = mx + 2 * CW - (int)((ent >> 10) & 63u);   // padded wx index for column X0
                     const float *wxr = L.wx + id * C::NWP + ip;
@@ -501,10 +630,6 @@ grid_binned_kernel(const GridParams p)
                             if (Rlo[q] == 0) wq[q] += wq[q];                                      // r = 0 sits in both loops
                     }
                     if (CPB % 2 == 0) {
-                        const float4 *d4 = reinterpret_cast<const float4 *>(L.d) + id;
-                        float4 dd[CPB / 2 > 0 ? CPB / 2 : 1];
-#pragma unroll
-                        for (int c = 0; c < CPB / 2; ++c) dd[c] = d4[c * C::NREC];
 #pragma unroll
                         for (int c = 0; c < CPB / 2; ++c) {
                             const float4 d = dd[c];
@@ -529,13 +654,16 @@ grid_binned_kernel(const GridParams p)
                     }
                 }
             }
-            __syncthreads();
+            PROF_MARK(12);                                      // apply
+            lds_barrier();
+            PROF_MARK(13);                                      // barrier
             sp0 = nsp0;
             sp1 = nsp1;
         }
     }
 
-    if (nparts > 1) {
+    PROF_MARK(14);
+    if (nparts > 1 || inner) {
         // partial tile of this spoke range, tile-local [coil][row][col], already scaled; summed by grid_reduce_parts_kernel
         float2 *part_base = p.partial + ((((size_t)z * p.nsplit_slots + slot) * p.max_parts + part) * p.nchan) * (kBinTile * kBinTile);
 #pragma unroll
@@ -548,6 +676,7 @@ grid_binned_kernel(const GridParams p)
                     v.z = acc[2 * qy + 1][c].x * p.scale; v.w = acc[2 * qy + 1][c].y * p.scale;
                     *reinterpret_cast<float4 *>(part_base + (size_t)(c0 + c) * (kBinTile * kBinTile) + (my + qy) * kBinTile + mx) = v;
                 }
+        PROF_FLUSH;
         return;
     }
 #pragma unroll
@@ -563,6 +692,8 @@ grid_binned_kernel(const GridParams p)
                 if (vs > 1) store_point_pair(p, zbase + c / p.nchan, c % p.nchan, X0, Y0 + qy, v);
                 else store_point_pair(p, z, c0 + c, X0, Y0 + qy, v);
             }
+    PROF_MARK(15);                                              // output store
+    PROF_FLUSH;
 }
 
 // Adds the partial tiles of a split tile in part order (fixed order: results do not depend on scheduling) and stores
@@ -576,7 +707,9 @@ grid_reduce_parts_kernel(const GridParams p)
     const int tile = entry & 0xffff, nparts = (entry >> 20) & 15;
     const int c = p.coil0 + blockIdx.y;
     const int n = p.nxos, h = n / 2;
-    const int x0 = (tile % p.tiles_per_row) * kBinTile - h, y0 = (tile / p.tiles_per_row) * kBinTile - h;
+    const bool inner = p.inner_r0 > 0 && tile == p.ntiles;      // origin-centred tile: added onto the centre tiles' stores
+    const int x0 = inner ? -kBinTile / 2 : (tile % p.tiles_per_row) * kBinTile - h;
+    const int y0 = inner ? -kBinTile / 2 : (tile / p.tiles_per_row) * kBinTile - h;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int mx = 2 * (lane & 15), my = 8 * wave + 2 * (lane >> 4);
     const float2 *base = p.partial + (((size_t)z * p.nsplit_slots + slot) * p.max_parts * p.nchan + c) * (kBinTile * kBinTile);
@@ -587,7 +720,8 @@ grid_reduce_parts_kernel(const GridParams p)
             const float4 v = *reinterpret_cast<const float4 *>(base + (size_t)g * p.nchan * (kBinTile * kBinTile) + (my + qy) * kBinTile + mx);
             sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
         }
-        store_point_pair(p, z, c, x0 + mx, y0 + my + qy, sum);
+        if (inner) store_point_pair<true>(p, z, c, x0 + mx, y0 + my + qy, sum);
+        else store_point_pair(p, z, c, x0 + mx, y0 + my + qy, sum);
     }
 }
 
@@ -603,20 +737,34 @@ static hipError_t launch_binned_cpb(const GridParams &p, int half_in, hipStream_
     dim3 grid((unsigned)((size_t)entries * q.nslices), (unsigned)chunks);
     size_t lds = sizeof(BinLds<CPB, CW>);
     if (p.lds_pad > 0 && (size_t)p.lds_pad > lds && p.lds_pad <= 64 * 1024) lds = (size_t)p.lds_pad;   // fewer workgroups per CU (two-lane pipeline)
+    // sample path: complex-half and odd coil counts / slice groups / unaligned streams go through registers; fp32 with
+    // even coil counts (16-byte coil pairs) is copied global -> LDS directly
+    int in_mode = half_in ? kInRegs16 : kInRegs32;
+#ifndef TRON_BIN_NO_LDS_DMA
+    if (!half_in && CPB % 2 == 0 && p.vslices <= 1 && (p.nchan & 1) == 0 && (p.coil0 & 1) == 0
+        && (reinterpret_cast<uintptr_t>(p.nudata) & 15) == 0)
+        in_mode = kInLdsDma;
+#endif
     if (lds > 64 * 1024) {   // above the default dynamic-LDS limit: raise it once per instantiation
         static hipError_t once = [] {
-            hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(grid_binned_kernel<CPB, CW, false>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BinLds<CPB, CW>));
-            hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(grid_binned_kernel<CPB, CW, true>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BinLds<CPB, CW>));
-            return e1 != hipSuccess ? e1 : e2;
+            hipError_t e = hipSuccess;
+            const void *fns[3] = {reinterpret_cast<const void *>(grid_binned_kernel<CPB, CW, kInRegs32>),
+                                  reinterpret_cast<const void *>(grid_binned_kernel<CPB, CW, kInRegs16>),
+                                  reinterpret_cast<const void *>(grid_binned_kernel<CPB, CW, (CPB % 2 == 0 ? kInLdsDma : kInRegs32)>)};
+            for (const void *f : fns) {
+                const hipError_t e1 = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BinLds<CPB, CW>));
+                if (e == hipSuccess) e = e1;
+            }
+            return e;
         }();
         if (once != hipSuccess) return once;
     }
-    if (half_in)
-        hipLaunchKernelGGL((grid_binned_kernel<CPB, CW, true>), grid, dim3(kBinThreads), lds, s, q);
+    if (in_mode == kInRegs16)
+        hipLaunchKernelGGL((grid_binned_kernel<CPB, CW, kInRegs16>), grid, dim3(kBinThreads), lds, s, q);
+    else if (in_mode == kInLdsDma)
+        hipLaunchKernelGGL((grid_binned_kernel<CPB, CW, (CPB % 2 == 0 ? kInLdsDma : kInRegs32)>), grid, dim3(kBinThreads), lds, s, q);
     else
-        hipLaunchKernelGGL((grid_binned_kernel<CPB, CW, false>), grid, dim3(kBinThreads), lds, s, q);
+        hipLaunchKernelGGL((grid_binned_kernel<CPB, CW, kInRegs32>), grid, dim3(kBinThreads), lds, s, q);
     if (q.nsplit_slots > 0)
         hipLaunchKernelGGL(grid_reduce_parts_kernel, dim3((unsigned)((size_t)q.nsplit_slots * q.nslices), (unsigned)(p.nchan - p.coil0)),
                            dim3(kBinThreads), 0, s, q);
@@ -656,6 +804,20 @@ hipError_t launch_grid_binned(const GridParams &p, int half_in, hipStream_t s)
         default: return hipErrorInvalidValue;
     }
 }
+
+#ifdef TRON_BIN_PROFILE
+extern "C" int tron_debug_grid_profile(unsigned long long *out, int n)   // reads and clears the phase clock
+{
+    static unsigned long long h[kProfCopies * kProfSlots];
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(h, HIP_SYMBOL(g_bin_prof), sizeof(h)) != hipSuccess) return 1;
+    for (int i = 0; i < n && i < kProfSlots; ++i) {
+        out[i] = 0;
+        for (int c = 0; c < kProfCopies; ++c) out[i] += h[c * kProfSlots + i];
+    }
+    for (size_t i = 0; i < sizeof(h) / sizeof(h[0]); ++i) h[i] = 0;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_bin_prof), h, sizeof(h)) != hipSuccess;
+}
+#endif
 
 __global__ void warm_grid_binned_tu() {}
 

@@ -24,6 +24,7 @@ void build_deapod_table_rect(int rows, int cols, float kernwidth, float sigma, f
 void build_tile_order(int nxos, int tile, std::vector<int> &order);
 void build_split_tile_order(int nxos, int tile, int npe, float W, int target, int max_parts,
                             std::vector<int> &order, std::vector<int> &slots);
+bool build_centre_relief_order(int nxos, int tile, int npe, float W, int max_parts, int &inner_r0, std::vector<int> &order, std::vector<int> &slots);
 float kb_beta(float kernwidth);
 double kb_poly_fit(float kernwidth, float *poly, int nterms);
 void dcf_constants(int nro, int npe1work, float *a, float *b);

@@ -42,6 +42,8 @@ struct GridParams {
     float2 *partial;         // [slice][slot][part][coil][32 x 32] partial tiles
     // binned kernel, linear angles: `vslices` consecutive slices share one pass (nslices = groups, nslices_total = slices)
     int vslices, nslices_total;
+    int inner_r0;            // binned kernel, centre relief (0: off): samples |r| < inner_r0 are gridded by the origin-centred inner tile
+                             // (entry tile id == ntiles, dealt over spoke ranges; slot 0 of split_slots), the four centre tiles take |r| >= inner_r0
     int lds_pad;             // binned kernel: request at least this much LDS per workgroup (0: what it needs); leaves CU room for a second lane
 };
 

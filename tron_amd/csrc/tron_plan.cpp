@@ -142,6 +142,17 @@ extern "C" int tron_plan_create(tron_plan **out, const tron_config *cfg, const t
                 if ((rc = upload(&p->d_tile_order32_split, sorder.data(), sorder.size() * sizeof(int)))) return bail(rc);
                 if ((rc = upload(&p->d_split_slots, slots.data(), slots.size() * sizeof(int)))) return bail(rc);
             }
+            // centre relief: the samples next to the k-space centre get workgroups of their own (tron_grid_binned.hip)
+            std::vector<int> rorder, rslots;
+            int r0 = 0;
+            const char *re = getenv("TRON_CENTRE_RELIEF");
+            if (!(re && atoi(re) == 0) && build_centre_relief_order(d.nxos, kBinnedTile, d.npe1work, cfg->kernwidth, 8, r0, rorder, rslots)) {
+                p->relief_entries = (int)rorder.size();
+                p->relief_parts = (rslots[0] >> 20) & 15;
+                p->relief_r0 = r0;
+                if ((rc = upload(&p->d_tile_order32_relief, rorder.data(), rorder.size() * sizeof(int)))) return bail(rc);
+                if ((rc = upload(&p->d_relief_slots, rslots.data(), rslots.size() * sizeof(int)))) return bail(rc);
+            }
         }
         std::vector<float> dea((size_t)d.nx * d.nx);
         build_deapod_table(d.nx, cfg->kernwidth, cfg->gridos, dea.data());        // src/tron.cu:635
@@ -270,6 +281,9 @@ extern "C" int tron_plan_destroy(tron_plan *p)
     hipFree(p->d_tile_order32_split);
     hipFree(p->d_split_slots);
     hipFree(p->d_partial);
+    hipFree(p->d_tile_order32_relief);
+    hipFree(p->d_relief_slots);
+    hipFree(p->d_relief_partial);
     hipFree(p->d_deapod);
     hipFree(p->d_errflag);
     hipFree(p->d_grid);

@@ -72,6 +72,11 @@ struct tron_plan {
     int *d_tile_order32_split = nullptr, *d_split_slots = nullptr;
     int split_entries = 0, nsplit_slots = 0, max_parts = 0, split_below = 0;
     float2 *d_partial = nullptr;
+    // centre relief of the binned gridding kernel (GridParams::inner_r0): entry list with the inner tile's parts, its slot
+    int *d_tile_order32_relief = nullptr, *d_relief_slots = nullptr;
+    int relief_entries = 0, relief_parts = 0, relief_r0 = 0;
+    float2 *d_relief_partial = nullptr;
+    size_t relief_slices = 0;
     size_t partial_slices = 0;
     float *d_deapod = nullptr;
     unsigned int *d_errflag = nullptr;
