@@ -1,18 +1,19 @@
 #!/bin/bash
-# usage (GPU box): tools/pmcx.sh <outdir> "<counter list pass 1>;<pass 2>;..." <script + args>   -- generic PMC passes, per-kernel sums
-R=$GRAFT_REPO_ROOT; out=$R/gpurun_out/$1; passes=$2; shift 2; mkdir -p $out; cd /tmp; export TMPDIR=/tmp
+# usage (on the GPU box): tools/pmcx.sh <outdir> "<counters of pass 1>" ["<counters of pass 2>" ...] -- <python script + args...>
+# ad-hoc counter passes (one rocprofv3 --pmc run each) with per-kernel sums; `rocprofv3 --list-avail` names the counters
+R=$GRAFT_REPO_ROOT; out=$R/gpurun_out/$1; shift; mkdir -p $out; cd /tmp; export TMPDIR=/tmp
+passes=(); while [ "$1" != "--" ]; do passes+=("$1"); shift; done; shift
 i=0
-IFS=';' read -ra P <<< "$passes"
-for pass in "${P[@]}"; do
+for pass in "${passes[@]}"; do
   i=$((i+1)); rocprofv3 --pmc $pass --kernel-trace -d $out/p$i --output-format csv -- python3 $R/"$@" > $out/p$i.log 2>&1
 done
-python3 - <<PY
+python3 - <<PY | tee $out/summary.txt
 import csv,glob,collections
 agg=collections.defaultdict(lambda: collections.defaultdict(float))
 for f in glob.glob('$out/p*/*/*_counter_collection.csv'):
     for r in csv.DictReader(open(f)):
-        agg[r['Kernel_Name'].split('(')[0][-44:]][r['Counter_Name']]+=float(r['Counter_Value'])
+        agg[r['Kernel_Name'].split('(')[0][-40:]][r['Counter_Name']]+=float(r['Counter_Value'])
 for k,v in agg.items():
-    if 'warm' in k: continue
-    print(k); print('   '+'  '.join(f"{n}={val:.4g}" for n,val in sorted(v.items())))
+    if any(t in k for t in ("grid","post","fft","pre")) and 'warm' not in k:
+        print(k); print('   '+'  '.join(f"{n}={val:.4g}" for n,val in sorted(v.items())))
 PY

@@ -67,6 +67,7 @@ struct BinLds {
     unsigned key[C::NREC];
     unsigned char rank[C::NREC];
     int wcnt[8];
+    int clipw[2 * 4 * (kBinMaxSpokes / kBinThreads)];   // per (chunk, wave): accepted spokes, their records
     float wx[C::NREC * C::NWP];
     float wy[C::NREC * C::NWP];
     float2 d[C::NREC * CPB];
@@ -242,14 +243,20 @@ grid_binned_kernel(const GridParams p)
 
     PROF_DECL;
     for (int round0 = pe_lo; round0 < pe_hi && TRON_DBG_LT(p, 4); round0 += kBinMaxSpokes) {
-        // ---- clip: one thread per spoke, accepted spokes compacted in acquisition order ---------
-        if (tid == 0) L.sp_start[0] = 0;
-        int nacc = 0;                                           // accepted so far in this round (uniform)
-        for (int chunk0 = round0; chunk0 < min(pe_hi, round0 + kBinMaxSpokes); chunk0 += kBinThreads) {
-            const int pe = chunk0 + tid;
-            bool accept = false;
-            int rlo = 0, len = 0;
-            if (pe < pe_hi && pe < round0 + kBinMaxSpokes) {
+        // ---- clip: one thread per spoke (kBinMaxSpokes / 256 spokes each), accepted spokes compacted in acquisition
+        //      order together with the exclusive scan of their segment lengths: one exchange of per-wave totals ------
+        constexpr int NCH = kBinMaxSpokes / kBinThreads;
+        static_assert(kBinMaxSpokes % kBinThreads == 0, "whole chunks of spokes");
+        bool c_acc[NCH];
+        int c_rlo[NCH], c_len[NCH], c_incl[NCH];
+        unsigned long long c_m[NCH];
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int pe = round0 + k * kBinThreads + tid;
+            c_acc[k] = false;
+            c_rlo[k] = 0;
+            c_len[k] = 0;
+            if (pe < pe_hi) {
                 const float2 cs = trig[pe];
                 const float ic = safe_rcp(cs.x), is = safe_rcp(cs.y);
                 const float xa = bx_lo * ic, xb = bx_hi * ic;
@@ -257,7 +264,7 @@ grid_binned_kernel(const GridParams p)
                 const float lo = fmaxf(fmaxf(fminf(xa, xb), fminf(ya, yb)), -(float)rmax);
                 const float hi = fminf(fminf(fmaxf(xa, xb), fmaxf(ya, yb)), (float)rmax);
                 if (lo <= hi) {
-                    rlo = (int)ceilf(lo);
+                    int rlo = (int)ceilf(lo);
                     int rhi = (int)floorf(hi);
                     if (inner) {                                // only the samples the centre tiles leave out
                         rlo = max(rlo, 1 - p.inner_r0);
@@ -277,50 +284,49 @@ grid_binned_kernel(const GridParams p)
                         atomicOr(p.errflag, 2u);
                         rhi = rlo + C::SLOT - 1;
                     }
-                    len = rhi - rlo + 1;
-                    accept = len > 0;
+                    c_rlo[k] = rlo;
+                    c_len[k] = max(rhi - rlo + 1, 0);
+                    c_acc[k] = c_len[k] > 0;
                 }
             }
-            const unsigned long long m = __ballot(accept);
-            if (lane == 0) L.wcnt[wave] = __popcll(m);
-            __syncthreads();
-            int base = nacc, total = 0;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const int cnt = L.wcnt[w];
-                if (w < wave) base += cnt;
-                total += cnt;
-            }
-            if (accept) {
-                const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
-                L.sp_pe[slot] = pe;
-                L.sp_seg[slot] = (rlo & 0xffff) | (len << 16);
-            }
-            nacc += total;
-            __syncthreads();
-        }
-        // exclusive scan of the segment lengths (nacc <= 512: two elements per thread)
-        {
-            const int i0 = 2 * tid, i1 = 2 * tid + 1;
-            const int l0 = i0 < nacc ? (L.sp_seg[i0] >> 16) : 0;
-            const int l1 = i1 < nacc ? (L.sp_seg[i1] >> 16) : 0;
-            int v = l0 + l1;
+            c_m[k] = __ballot(c_acc[k]);
+            int v = c_len[k];                                   // inclusive scan of the lengths within the wave
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
                 const int t = __shfl_up(v, o);
                 if (lane >= o) v += t;
             }
-            if (lane == 63) L.wcnt[4 + wave] = v;
-            __syncthreads();
-            int wbase = 0;
-#pragma unroll
-            for (int w = 0; w < 4; ++w)
-                if (w < wave) wbase += L.wcnt[4 + w];
-            const int excl = wbase + v - (l0 + l1);
-            if (i0 < nacc) L.sp_start[i0 + 1] = excl + l0;
-            if (i1 < nacc) L.sp_start[i1 + 1] = excl + l0 + l1;
-            __syncthreads();
+            c_incl[k] = v;
+            if (lane == 63) {
+                L.clipw[(k * 4 + wave) * 2] = __popcll(c_m[k]);
+                L.clipw[(k * 4 + wave) * 2 + 1] = v;
+            }
         }
+        if (tid == 0) L.sp_start[0] = 0;
+        __syncthreads();
+        int nacc = 0;                                           // accepted spokes of this round (uniform)
+        {
+            int bcnt[NCH], blen[NCH];
+            int run_c = 0, run_l = 0;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k)
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    if (w == wave) { bcnt[k] = run_c; blen[k] = run_l; }
+                    run_c += L.clipw[(k * 4 + w) * 2];
+                    run_l += L.clipw[(k * 4 + w) * 2 + 1];
+                }
+            nacc = run_c;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k)
+                if (c_acc[k]) {
+                    const int slot = bcnt[k] + __popcll(c_m[k] & ((1ull << lane) - 1ull));
+                    L.sp_pe[slot] = round0 + k * kBinThreads + tid;
+                    L.sp_seg[slot] = (c_rlo[k] & 0xffff) | (c_len[k] << 16);
+                    L.sp_start[slot + 1] = blen[k] + c_incl[k];
+                }
+        }
+        __syncthreads();
 
         // ---- batches: the longest run of spokes whose records fit in NREC; the k-space samples of batch
         //      b+1 are fetched into registers while batch b is scanned, placed and applied ----------
@@ -328,27 +334,42 @@ grid_binned_kernel(const GridParams p)
         int pf_pe[RPT], pf_r[RPT];
         float2 pf_cs[RPT];                                      // the spoke's (cos, sin): fetched with the batch, not in the staging pass
         float2 pf_d[DMA ? 1 : RPT][DMA ? 1 : CPB];
-        auto batch_end = [&](int s0) {
-            const int base = L.sp_start[s0];
-            int s1 = s0 + 1;
-            while (s1 < nacc && L.sp_start[s1 + 1] - base <= C::NREC) ++s1;
-            return s1;
-        };
-        auto prefetch = [&](int s0, int s1) {
-            const int base = L.sp_start[s0];
-            const int cnt = L.sp_start[s1] - base;
+        // The next batch = the longest run of accepted spokes s0 .. s1-1 whose records fit in NREC, and for each of this
+        // thread's records the spoke that holds it.  Every wave does this on its own, lanes along the spokes: ONE LDS read
+        // fetches 64 segment ends, a ballot finds how many fit, and the ends are handed round with v_readlane -- no serial
+        // scan for s1, no binary search per record (each step of either was a dependent LDS round trip).
+        int pf_cnt = 0, pf_base = 0;                            // records of the prefetched batch, records before it
+        auto prefetch = [&](int s0, int base) -> int {
+            int spk[RPT];
+#pragma unroll
+            for (int j = 0; j < RPT; ++j) spk[j] = s0;
+            int s1 = s0, cnt = 0;
+            for (int sb = s0;; sb += 64) {
+                const int idx = sb + 1 + lane;                  // e = where spoke idx starts = where idx - 1 ends
+                const int e = L.sp_start[min(idx, nacc)] - base;
+                const unsigned long long m = __ballot(idx <= nacc && e <= C::NREC);   // monotone along the lanes; spoke s0 always fits (SLOT <= NREC)
+                const int nfit = m == ~0ull ? 64 : __builtin_ctzll(~m);
+                for (int k = 0; k < nfit; ++k) {
+                    const int ek = __builtin_amdgcn_readlane(e, k);
+#pragma unroll
+                    for (int j = 0; j < RPT; ++j)
+                        if (tid + j * kBinThreads >= ek) spk[j] = sb + 1 + k;
+                }
+                if (nfit > 0) {
+                    cnt = __builtin_amdgcn_readlane(e, nfit - 1);
+                    s1 = sb + nfit;
+                }
+                if (nfit < 64) break;
+            }
+            pf_base = base;
+            pf_cnt = cnt;
 #pragma unroll
             for (int j = 0; j < RPT; ++j) {
                 const int rec = tid + j * kBinThreads;
                 pf_pe[j] = -1;
                 if (rec < cnt) {
-                    // which spoke of the batch holds record `rec`: sp_start[sp] <= base + rec < sp_start[sp+1]
-                    int lo = s0, hi = s1 - 1;
+                    const int lo = spk[j];                      // sp_start[lo] <= base + rec < sp_start[lo + 1]
                     const int target = base + rec;
-                    while (lo < hi) {
-                        const int mid = (lo + hi + 1) >> 1;
-                        if (L.sp_start[mid] <= target) lo = mid; else hi = mid - 1;
-                    }
                     const int pe = L.sp_pe[lo];
                     const int r = (int)(short)(L.sp_seg[lo] & 0xffff) + (target - L.sp_start[lo]);
                     pf_pe[j] = pe;
@@ -394,18 +415,15 @@ grid_binned_kernel(const GridParams p)
                     }
                 }
             }
+            return s1;
         };
 
         int sp0 = 0, sp1 = 0;
         PROF_MARK(0);                                           // setup + clip + segment scan
-        if (nacc > 0 && TRON_DBG_LT(p, 3)) {
-            sp1 = batch_end(0);
-            if (TRON_DBG_LT(p, 2)) prefetch(0, sp1);
-        }
+        if (nacc > 0 && TRON_DBG_LT(p, 3)) sp1 = prefetch(0, 0);
         PROF_MARK(1);                                           // first prefetch
         while (sp0 < nacc && TRON_DBG_LT(p, 3)) {
-            const int rec_base = L.sp_start[sp0];
-            const int nrec = L.sp_start[sp1] - rec_base;
+            const int nrec = pf_cnt;
 
             float pf_kx[RPT], pf_ky[RPT];
 #pragma unroll
@@ -509,10 +527,7 @@ grid_binned_kernel(const GridParams p)
             // next batch: bounds now, samples in flight while this batch is scanned / placed / applied
             const int nsp0 = sp1;
             int nsp1 = nsp0;
-            if (nsp0 < nacc) {
-                nsp1 = batch_end(nsp0);
-                if (TRON_DBG_LT(p, 2)) prefetch(nsp0, nsp1);
-            }
+            if (nsp0 < nacc) nsp1 = prefetch(nsp0, pf_base + nrec);
             PROF_MARK(5);                                       // next batch: bounds + prefetch
             lds_barrier();
             PROF_MARK(6);                                       // barrier
