@@ -44,7 +44,7 @@ struct BinCfg {
     // batches that allows; with fewer coils the kernel fits 4 waves per SIMD and a FOURTH workgroup per CU (<= 40 KiB)
     // beats larger batches (measured on one box, gridding us per coil-slice, 36 KiB of records -> this:
     // 4 coils 3.51 -> 3.13, 2 coils 5.96 -> 5.45, 1 coil 11.1 -> 9.9; 8 coils at 24/28 KiB: 2.28 -> 2.45)
-    static constexpr int REC_BYTES = 2 * NWP * 4 + CPB * 8 + 4 + 4 + 1;
+    static constexpr int REC_BYTES = 2 * NWP * 4 + CPB * 8 + 8 + 4 + 1;
 #ifdef TRON_BIN_REC_KB
     static constexpr int REC_KB = TRON_BIN_REC_KB;
 #else
@@ -63,7 +63,10 @@ struct BinLds {
     int sp_start[kBinMaxSpokes + 1];      // exclusive scan of len
     unsigned hist[C::NCELLS];             // 4 x 8-bit per-wave counters per cell
     unsigned short start[C::NCELLS + 1];
-    unsigned sorted[C::NREC];             // per sorted slot: record id | fxrel<<10 | |r|<<16 | (r==0)<<30
+    // per sorted slot, everything the apply loop needs besides the weights, pre-shifted into LDS byte offsets:
+    //   .x = record's weight-row offset (id * 4 NWP) | 4 fxrel << 15 | 4 fyrel << 23 | (r == 0) << 31
+    //   .y = |r| | record's sample offset (id * 16, or * 8 for one coil) << 16
+    uint2 sorted[C::NREC];
     unsigned key[C::NREC];
     unsigned char rank[C::NREC];
     int wcnt[8];
@@ -577,8 +580,8 @@ grid_binned_kernel(const GridParams p)
                     const int wb = (int)((below & 0xff) + ((below >> 8) & 0xff) + ((below >> 16) & 0xff));
                     const int pos = L.start[cell] + wb + L.rank[rec];
                     if (pos >= C::NREC) { atomicOr(p.errflag, 8u); continue; }
-                    // everything the apply loop needs besides the weights: id, cell column, |r|, r == 0
-                    L.sorted[pos] = (unsigned)rec | ((key & 63u) << 10) | (((key >> 12) & 0x3fffu) << 16) | (((key >> 29) & 1u) << 30);
+                    L.sorted[pos] = make_uint2((unsigned)(rec * C::NWP * 4) | ((key & 63u) << 17) | (((key >> 6) & 63u) << 25) | (((key >> 29) & 1u) << 31),
+                                               ((key >> 12) & 0x3fffu) | ((unsigned)(rec * (CPB % 2 == 0 ? 16 : 8)) << 16));
                 }
             }
             PROF_MARK(9);                                       // place
@@ -602,44 +605,47 @@ grid_binned_kernel(const GridParams p)
                     cum[dy + 1] = cum[dy] + (kend - kbeg);
                 }
                 const int total = cum[NR];
+                // where visit i sits in the sorted list: i + delta[its row] = i + delta[0] + the gaps of the rows i has passed
+                // (cum is non-decreasing, so the tests nest); byte offsets into L.sorted
+                int gap8[NR];
+#pragma unroll
+                for (int dy = 1; dy < NR; ++dy) gap8[dy] = (delta[dy] - delta[dy - 1]) * 8;
+                const char *sorted0 = reinterpret_cast<const char *>(L.sorted) + delta[0] * 8;
+                auto entry_of = [&](const int i) {
+                    int off = 0;
+#pragma unroll
+                    for (int dy = 1; dy < NR; ++dy) off += i >= cum[dy] ? gap8[dy] : 0;
+                    return *reinterpret_cast<const uint2 *>(sorted0 + i * 8 + off);
+                };
+                // byte addresses of the padded weights of this thread's first column / row inside a record's weight row:
+                // ip = mx + 2CW - fxrel, jp = 2CW - (fyrel - my)
+                const char *wx0 = reinterpret_cast<const char *>(L.wx) + (mx + 2 * CW) * 4;
+                const char *wy0 = reinterpret_cast<const char *>(L.wy) + (my + 2 * CW) * 4;
                 // software pipeline: the sorted entry of visit i+1 is fetched while visit i is processed
-                int row_next = 0, dl_next = delta[0];
-#pragma unroll
-                for (int dy = 1; dy < NR; ++dy)
-                    if (0 >= cum[dy]) { row_next = dy; dl_next = delta[dy]; }
-                unsigned ent_next = total > 0 ? L.sorted[dl_next] : 0u;
+                uint2 ent_next = make_uint2(0u, 0u);
+                if (0 < total) ent_next = entry_of(0);
                 for (int i = 0; i < total; ++i) {
-                    const unsigned ent = ent_next;
-                    const int row = row_next;
-                    {
-                        const int i1 = i + 1;
-                        row_next = 0; dl_next = delta[0];
-#pragma unroll
-                        for (int dy = 1; dy < NR; ++dy)
-                            if (i1 >= cum[dy]) { row_next = dy; dl_next = delta[dy]; }
-                        if (i1 < total) ent_next = L.sorted[i1 + dl_next];
-                    }
-                    const int id = (int)(ent & 1023u);
+                    const uint2 ent = ent_next;
+                    if (i + 1 < total) ent_next = entry_of(i + 1);
                     // the samples are asked for FIRST, with the weights: one LDS round trip per visit, not two
                     float4 dd[CPB / 2 > 0 ? CPB / 2 : 1];
+                    const char *drec = reinterpret_cast<const char *>(L.d) + (ent.y >> 16);
                     if (CPB % 2 == 0) {
-                        const float4 *d4 = reinterpret_cast<const float4 *>(L.d) + id;
 #pragma unroll
-                        for (int c = 0; c < CPB / 2; ++c) dd[c] = d4[c * C::NREC];
+                        for (int c = 0; c < CPB / 2; ++c) dd[c] = *reinterpret_cast<const float4 *>(drec + (size_t)c * C::NREC * sizeof(float4));
                     }
-                    const int jp = 2 * CW - row;                       // padded wy index for row Y0 (Y0+1 uses jp+1)
-                    const int ip = mx + 2 * CW - (int)((ent >> 10) & 63u);   // padded wx index for column X0
-                    const float *wxr = L.wx + id * C::NWP + ip;
-                    const float *wyr = L.wy + id * C::NWP + jp;
+                    const unsigned woff = ent.x & 0x7fffu;
+                    const float *wxr = reinterpret_cast<const float *>(wx0 + woff - ((ent.x >> 15) & 0xffu));
+                    const float *wyr = reinterpret_cast<const float *>(wy0 + woff - ((ent.x >> 23) & 0xffu));
                     const float wxa = wxr[0], wxb = wxr[1];
                     const float wya = wyr[0], wyb = wyr[1];
-                    const int ar = (int)((ent >> 16) & 0x3fffu);
+                    const int ar = (int)(ent.y & 0xffffu);
                     float wq[4];
                     wq[0] = wxa * wya; wq[1] = wxb * wya; wq[2] = wxa * wyb; wq[3] = wxb * wyb;   // src/tron.cu:516
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
                         if ((unsigned)(ar - Rlo[q]) > (unsigned)(Rhi[q] - Rlo[q])) wq[q] = 0.f;    // src/tron.cu:512,521
-                    if (has_centre && ((ent >> 30) & 1u)) {
+                    if (has_centre && (int)ent.x < 0) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
                             if (Rlo[q] == 0) wq[q] += wq[q];                                      // r = 0 sits in both loops
@@ -659,7 +665,7 @@ grid_binned_kernel(const GridParams p)
                     } else {
 #pragma unroll
                         for (int c = 0; c < CPB; ++c) {
-                            const float2 d = L.d[c * C::NREC + id];
+                            const float2 d = *reinterpret_cast<const float2 *>(drec + (size_t)c * C::NREC * sizeof(float2));
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
                                 acc[q][c].x = fmaf(d.x, wq[q], acc[q][c].x);
