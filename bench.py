@@ -217,12 +217,16 @@ def traffic_capture(kernel_prefix, units_per_launch_now):
         return None, True, "no capture"
     if tj.get("source_hash") != kernel_source_hash():
         return None, True, f"capture {tj.get('source_hash')} != sources {kernel_source_hash()}"
+    # the gridding stage is grid_binned_kernel plus the pass that adds the inner tile's parts (one launch each per batch)
+    prefixes = (kernel_prefix, "grid_reduce_parts_kernel") if kernel_prefix == "grid_binned_kernel" else (kernel_prefix,)
+    per_launch = 0.0
     for name, c in tj.get("kernels", {}).items():
-        if name.startswith(kernel_prefix) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-            per_launch = (2.0 * c["FETCH_SIZE"]["kib"] / c["FETCH_SIZE"]["dispatches"]
-                          + c["WRITE_SIZE"]["kib"] / c["WRITE_SIZE"]["dispatches"]) * 1024.0
-            scale = units_per_launch_now / float(tj.get("coil_slices_per_launch", units_per_launch_now))
-            return int(per_launch * scale), False, tj.get("command", "")
+        if name.startswith(prefixes) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            per_launch += (2.0 * c["FETCH_SIZE"]["kib"] / c["FETCH_SIZE"]["dispatches"]
+                           + c["WRITE_SIZE"]["kib"] / c["WRITE_SIZE"]["dispatches"]) * 1024.0
+    if per_launch > 0.0:
+        scale = units_per_launch_now / float(tj.get("coil_slices_per_launch", units_per_launch_now))
+        return int(per_launch * scale), False, tj.get("command", "")
     return None, True, "kernel not in capture"
 
 
