@@ -8,17 +8,24 @@
 // (~1e-7), not bit for bit.  That is why this kernel serves TRON_KB_FAST only; TRON_KB_EXACT keeps
 // the order-preserving gather.
 //
-// One workgroup = 4 waves = one 32x32 tile; each thread owns 2x2 points.  Per batch of <= NREC records:
-//   A  stage   lanes run along the spoke: coalesced k-space read, DCF, 2x(2CW) weights once per
-//              sample; the sample's base cell gets a packed per-wave counter bumped with ONE
-//              integer LDS atomic (ds_add_rtn_u32: 6.6 cycles per wave instruction on MI355X,
-//              vs 194 for ds_add_f32), which returns the sample's rank in its (wave, cell) bucket;
-//   B  scan    exclusive prefix sum over the (32+2CW-1)^2 cells -> CSR row starts;
-//   C  place   record ids are written to their sorted slots: cell start + earlier waves' counts + rank
-//              (deterministic: each wave issues its atomics in program order);
-//   D  apply   a thread reads, for each of the 2CW+1 cell rows its 2x2 points can see, ONE contiguous
-//              id range, and accumulates weight pair x weight pair x sample for all coils in registers.
-// No floating-point atomics anywhere; the output is written once, coil-planar, in FFT-native order.
+// One workgroup = 4 waves = one 32x32 tile; each thread owns 2x2 points.  Once per tile the spokes are clipped against
+// tile + halo (thread = spoke) and compacted in acquisition order.  Then, per batch of <= NREC records:
+//   plan    (one batch ahead) the longest run of spokes that fits, and which spoke holds each record: lanes along the
+//           spokes, one LDS read + ballot + v_readlane per wave, no dependent LDS chains;
+//   stage   lanes run along the spoke: 2x(2CW) weights once per sample (packed polynomials), the samples copied
+//           global -> LDS by LDS-DMA (fp32, even coil counts) or through registers; the sample's base cell gets a packed
+//           per-wave counter bumped with ONE integer LDS atomic (ds_add_rtn_u32: 6.6 cycles per wave instruction on
+//           MI355X, vs 194 for ds_add_f32), which returns the sample's rank in its (wave, cell) bucket;
+//   scan    exclusive prefix sum over the (32+2CW-1)^2 cells -> CSR row starts;
+//   place   8-byte entries (pre-shifted LDS offsets of the record's weights and samples, its cell, |r|) are written to
+//           their sorted slots: cell start + earlier waves' counts + rank (deterministic: each wave issues its atomics
+//           in program order);
+//   apply   a thread reads, for the 2CW+1 cell rows its 2x2 points can see, ONE concatenated entry range, and
+//           accumulates weight pair x weight pair x sample for all coils in registers.
+// Centre relief (GridParams::inner_r0): the samples next to the k-space centre, which every spoke passes, are gridded by
+// workgroups of their own (the origin-centred inner tile, dealt over spoke ranges) and added onto the four centre tiles.
+// No floating-point atomics anywhere; the output is written once, coil-planar, in FFT-native order.  DESIGN.md 4.1 has
+// the measurements (phase clock, counters: the kernel is VALU-issue-bound).
 #include <stdlib.h>
 
 #include "tron_device.h"
@@ -610,17 +617,21 @@ grid_binned_kernel(const GridParams p)
                 int gap8[NR];
 #pragma unroll
                 for (int dy = 1; dy < NR; ++dy) gap8[dy] = (delta[dy] - delta[dy - 1]) * 8;
-                const char *sorted0 = reinterpret_cast<const char *>(L.sorted) + delta[0] * 8;
+                const unsigned sorted0 = lds_addr(L.sorted) + (unsigned)(delta[0] * 8);
                 auto entry_of = [&](const int i) {
                     int off = 0;
 #pragma unroll
                     for (int dy = 1; dy < NR; ++dy) off += i >= cum[dy] ? gap8[dy] : 0;
-                    return *reinterpret_cast<const uint2 *>(sorted0 + i * 8 + off);
+                    const __attribute__((address_space(3))) unsigned *q =
+                        (const __attribute__((address_space(3))) unsigned *)(size_t)(sorted0 + (unsigned)off + (unsigned)(i * 8));
+                    return make_uint2(q[0], q[1]);
                 };
                 // byte addresses of the padded weights of this thread's first column / row inside a record's weight row:
                 // ip = mx + 2CW - fxrel, jp = 2CW - (fyrel - my)
-                const char *wx0 = reinterpret_cast<const char *>(L.wx) + (mx + 2 * CW) * 4;
-                const char *wy0 = reinterpret_cast<const char *>(L.wy) + (my + 2 * CW) * 4;
+                // (LDS byte addresses as integers: base + thread offset in ONE register, so a visit adds and subtracts only)
+                typedef const __attribute__((address_space(3))) float *lds_fp;
+                const unsigned wx0 = lds_addr(L.wx) + (unsigned)((mx + 2 * CW) * 4);
+                const unsigned wy0 = lds_addr(L.wy) + (unsigned)((my + 2 * CW) * 4);
                 // software pipeline: the sorted entry of visit i+1 is fetched while visit i is processed
                 uint2 ent_next = make_uint2(0u, 0u);
                 if (0 < total) ent_next = entry_of(0);
@@ -635,8 +646,8 @@ grid_binned_kernel(const GridParams p)
                         for (int c = 0; c < CPB / 2; ++c) dd[c] = *reinterpret_cast<const float4 *>(drec + (size_t)c * C::NREC * sizeof(float4));
                     }
                     const unsigned woff = ent.x & 0x7fffu;
-                    const float *wxr = reinterpret_cast<const float *>(wx0 + woff - ((ent.x >> 15) & 0xffu));
-                    const float *wyr = reinterpret_cast<const float *>(wy0 + woff - ((ent.x >> 23) & 0xffu));
+                    const lds_fp wxr = (lds_fp)(size_t)(wx0 + woff - ((ent.x >> 15) & 0xffu));
+                    const lds_fp wyr = (lds_fp)(size_t)(wy0 + woff - ((ent.x >> 23) & 0xffu));
                     const float wxa = wxr[0], wxb = wxr[1];
                     const float wya = wyr[0], wyb = wyr[1];
                     const int ar = (int)(ent.y & 0xffffu);
