@@ -125,6 +125,25 @@ def test_centre_relief_shapes(oracle, monkeypatch, W, nxos_nro):
         assert rel_l2(got, plain) <= 2e-6
 
 
+@pytest.mark.parametrize("nc,nz", [(1, 11), (2, 5), (4, 3)])
+def test_centre_relief_with_linear_angle_slice_groups(oracle, monkeypatch, nc, nz):
+    """Linear angles: 8 / nc slices share one gridding pass (slice groups ride in the coil dimension); the inner tile's
+    parts are then per (group, channel) and the reduce pass maps a channel back to its slice and coil -- ragged last
+    group included."""
+    nro, npe = 256, 150
+    data = synth.kspace(nc, nro, npe * nz, seed=1500 + nc)
+    us = (npe + 0.5) / nro
+    flags = dict(golden_angle=0, data_undersamp=us, prof_slide=npe)
+    got, dims = lib.recon(data, adjoint=True, **flags)
+    assert (dims.nxos, dims.nz) == (256, nz)
+    want, _ = oracle.recon(data, adjoint=1, golden=0, data_undersamp=us, prof_slide=npe)
+    assert rel_l2(got, want) <= 1e-5
+    monkeypatch.setenv("TRON_CENTRE_RELIEF", "0")
+    plain, _ = lib.recon(data, adjoint=True, **flags)
+    assert not np.array_equal(got, plain), "the relief path did not run"
+    assert rel_l2(got, plain) <= 2e-6
+
+
 @pytest.mark.parametrize("kb", [lib.KB_FAST, lib.KB_EXACT])
 def test_repetitions_nt_gt_1(oracle, kb):
     """nt > 1 (channel = coil + nc*repetition, .ra dims [nc, nt, ...]): every repetition is gridded and combined on its

@@ -697,7 +697,9 @@ grid_binned_kernel(const GridParams p)
     PROF_MARK(14);
     if (nparts > 1 || inner) {
         // partial tile of this spoke range, tile-local [coil][row][col], already scaled; summed by grid_reduce_parts_kernel
-        float2 *part_base = p.partial + ((((size_t)z * p.nsplit_slots + slot) * p.max_parts + part) * p.nchan) * (kBinTile * kBinTile);
+        // (slice groups: the group's vs * nchan channels take the place of the coils)
+        const int pch = vs > 1 ? vs * p.nchan : p.nchan;
+        float2 *part_base = p.partial + ((((size_t)z * p.nsplit_slots + slot) * p.max_parts + part) * pch) * (kBinTile * kBinTile);
 #pragma unroll
         for (int qy = 0; qy < 2; ++qy)
 #pragma unroll
@@ -729,7 +731,7 @@ grid_binned_kernel(const GridParams p)
 }
 
 // Adds the partial tiles of a split tile in part order (fixed order: results do not depend on scheduling) and stores
-// the sum exactly as an unsplit workgroup would.  grid = (split slots x slices, nchan), block = 256.
+// the sum exactly as an unsplit workgroup would.  grid = (split slots x slices [or slice groups], channels), block = 256.
 __global__ void __launch_bounds__(kBinThreads)
 grid_reduce_parts_kernel(const GridParams p)
 {
@@ -737,23 +739,29 @@ grid_reduce_parts_kernel(const GridParams p)
     const int slot = blockIdx.x / p.nslices;
     const int entry = p.split_slots[slot];                      // tile id | parts << 20
     const int tile = entry & 0xffff, nparts = (entry >> 20) & 15;
-    const int c = p.coil0 + blockIdx.y;
+    // slice groups (vslices > 1): channel ch of group z is coil ch % nchan of slice z * vslices + ch / nchan
+    const int vs = p.vslices > 1 ? p.vslices : 1;
+    const int pch = vs > 1 ? vs * p.nchan : p.nchan;
+    const int ch = vs > 1 ? (int)blockIdx.y : p.coil0 + (int)blockIdx.y;
+    const int zs = vs > 1 ? z * vs + ch / p.nchan : z;
+    const int c = vs > 1 ? ch % p.nchan : ch;
+    if (vs > 1 && zs >= p.nslices_total) return;
     const int n = p.nxos, h = n / 2;
     const bool inner = p.inner_r0 > 0 && tile == p.ntiles;      // origin-centred tile: added onto the centre tiles' stores
     const int x0 = inner ? -kBinTile / 2 : (tile % p.tiles_per_row) * kBinTile - h;
     const int y0 = inner ? -kBinTile / 2 : (tile / p.tiles_per_row) * kBinTile - h;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int mx = 2 * (lane & 15), my = 8 * wave + 2 * (lane >> 4);
-    const float2 *base = p.partial + (((size_t)z * p.nsplit_slots + slot) * p.max_parts * p.nchan + c) * (kBinTile * kBinTile);
+    const float2 *base = p.partial + (((size_t)z * p.nsplit_slots + slot) * p.max_parts * pch + ch) * (kBinTile * kBinTile);
 #pragma unroll
     for (int qy = 0; qy < 2; ++qy) {
         float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int g = 0; g < nparts; ++g) {
-            const float4 v = *reinterpret_cast<const float4 *>(base + (size_t)g * p.nchan * (kBinTile * kBinTile) + (my + qy) * kBinTile + mx);
+            const float4 v = *reinterpret_cast<const float4 *>(base + (size_t)g * pch * (kBinTile * kBinTile) + (my + qy) * kBinTile + mx);
             sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
         }
-        if (inner) store_point_pair<true>(p, z, c, x0 + mx, y0 + my + qy, sum);
-        else store_point_pair(p, z, c, x0 + mx, y0 + my + qy, sum);
+        if (inner) store_point_pair<true>(p, zs, c, x0 + mx, y0 + my + qy, sum);
+        else store_point_pair(p, zs, c, x0 + mx, y0 + my + qy, sum);
     }
 }
 
@@ -798,7 +806,8 @@ static hipError_t launch_binned_cpb(const GridParams &p, int half_in, hipStream_
     else
         hipLaunchKernelGGL((grid_binned_kernel<CPB, CW, kInRegs32>), grid, dim3(kBinThreads), lds, s, q);
     if (q.nsplit_slots > 0)
-        hipLaunchKernelGGL(grid_reduce_parts_kernel, dim3((unsigned)((size_t)q.nsplit_slots * q.nslices), (unsigned)(p.nchan - p.coil0)),
+        hipLaunchKernelGGL(grid_reduce_parts_kernel, dim3((unsigned)((size_t)q.nsplit_slots * q.nslices),
+                                                          (unsigned)(p.vslices > 1 ? p.vslices * p.nchan : p.nchan - p.coil0)),
                            dim3(kBinThreads), 0, s, q);
     return hipGetLastError();
 }
@@ -808,7 +817,7 @@ static hipError_t launch_binned_cw(const GridParams &p, int half_in, hipStream_t
 {
     if (p.vslices > 1) {                       // slices in the coil dimension: vslices * nchan channels per pass
         const int nv = p.vslices * p.nchan;
-        if (nv > 8 || p.nsplit_slots > 0 || p.coil0 != 0 || p.trig_slice_stride != 0) return hipErrorInvalidValue;
+        if (nv > 8 || (p.nsplit_slots > 0 && p.inner_r0 <= 0) || p.coil0 != 0 || p.trig_slice_stride != 0) return hipErrorInvalidValue;
         if (nv > 4) return launch_binned_cpb<8, CW>(p, half_in, s);
         if (nv > 2) return launch_binned_cpb<4, CW>(p, half_in, s);
         return launch_binned_cpb<2, CW>(p, half_in, s);

@@ -186,12 +186,14 @@ int adjoint_run_raw(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, 
                     g.vslices = vs;
                     g.nslices_total = cz;
                     g.nslices = (cz + vs - 1) / vs;
-                } else if (p->relief_entries > 0) {
+                }
+                if (p->relief_entries > 0) {
                     // the samples next to the k-space centre go to the inner tile's workgroups; their parts are added
                     // onto the centre tiles by the reduce pass that follows the gridding kernel on this stream
-                    if (p->relief_slices < (size_t)cz) {
+                    const size_t need = (size_t)cz + (vs > 1 ? vs : 0);               // whole slice groups
+                    if (p->relief_slices < need) {
                         if (p->d_relief_partial) { HIP_TRY(hipStreamSynchronize(st)); HIP_TRY(hipFree(p->d_relief_partial)); p->d_relief_partial = nullptr; }
-                        const size_t want = (size_t)std::max(cz, std::min(step, 64));
+                        const size_t want = std::max(need, (size_t)std::min(step, 64) + 8);
                         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_relief_partial),
                                           want * p->relief_parts * p->nchan * kBinnedTile * kBinnedTile * sizeof(float2)));
                         p->relief_slices = want;
@@ -203,7 +205,7 @@ int adjoint_run_raw(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, 
                     g.split_slots = p->d_relief_slots;
                     g.partial = p->d_relief_partial;
                     g.inner_r0 = p->relief_r0;
-                } else if (cz < p->split_below && p->nsplit_slots > 0) {
+                } else if (vs <= 1 && cz < p->split_below && p->nsplit_slots > 0) {
                     // a launch this small would be bound by the centre tiles' serial chains: split them over spoke ranges
                     if (p->partial_slices < (size_t)cz) {
                         if (p->d_partial) { HIP_TRY(hipStreamSynchronize(st)); HIP_TRY(hipFree(p->d_partial)); p->d_partial = nullptr; }
