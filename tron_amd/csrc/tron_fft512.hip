@@ -113,6 +113,89 @@ struct Fft512Params {
 __device__ __forceinline__ int crop_index(int k) { return k < kFKeep / 2 ? k + kFKeep / 2 : k - (kF - kFKeep / 2); }
 
 // grid = (512/16, nimg); block = 256
+// A wave transforms four lines.  A line's loads used to be issued and waited for before its transform (four waves per SIMD
+// hid too little of the HBM latency: 3.6 TB/s of the kernel's own traffic, where a plain copy with the same access shape
+// reaches 5.5-5.8, tools/probe/copywidth.hip).  Now line j+1 is copied global -> LDS by LDS-DMA while line j is transformed:
+// no registers (prefetching into registers cost a wave per SIMD: measured slower), and no LDS either -- the four 4 KiB
+// line buffers live in the part of the transposition tile the exchange regions leave unused until the end.  The
+// twiddles come from LDS so that no compiler-tracked global load (whose wait would drain the DMA, the counters being
+// in-order) sits between the copy's issue and its use.
+#ifndef TRON_FFT_ROWS_NO_DMA
+__global__ void __launch_bounds__(256) fft512_rows_kernel(const Fft512Params p)
+{
+    __shared__ float2 s_t[kFKeep * (kLinesPerWg + 1)];     // exchange regions | line buffers, then [kept col][line], +1 pad
+    __shared__ float2 s_tw[kF];
+    static_assert(kFKeep * (kLinesPerWg + 1) >= 4 * kXch + 4 * kF, "exchange regions + line buffers must fit the transposition tile");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t img = blockIdx.y;
+    const int row0 = blockIdx.x * kLinesPerWg;
+    const float2 *src = p.in + img * (size_t)kF * kF;
+    float2 *xch = s_t + wave * kXch;
+    float2 *lbuf = s_t + 4 * kXch + wave * kF;            // this wave's line buffer: the line as it lies in memory
+    // the gridded spokes fill a disc of radius nxos/2 - 1 + W (src/tron.cu:498-502): 21 % of the square is zero and is
+    // neither copied nor read from the buffer
+    auto row_lim = [&](const int row) {
+        const int Y = row < kF / 2 ? row : row - kF;
+        return p.rzero2 > 0 ? p.rzero2 - Y * Y : 0x7fffffff;
+    };
+    auto inside = [&](const int col, const int lim) {
+        const int X = col < kF / 2 ? col : col - kF;
+        return X * X <= lim;
+    };
+    auto copy_line = [&](const int lr) {                    // 4 x (64 lanes x 16 bytes = two points per lane)
+        const int lim = row_lim(row0 + lr);
+        const float2 *line = src + (size_t)(row0 + lr) * kF;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int col = k * 128 + 2 * lane;
+            if (inside(col, lim) || inside(col + 1, lim)) lds_dma16(line + col, lds_addr(lbuf) + (unsigned)(k * 128 * sizeof(float2)));
+        }
+    };
+    copy_line(wave * 4);
+    for (int i = threadIdx.x; i < kF; i += 256) s_tw[i] = p.tw[i];
+    __syncthreads();
+    float2 keep[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int lr = wave * 4 + j;
+        const int lim = row_lim(row0 + lr);
+        float2 v[8];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // line j has landed
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float2 t = lbuf[q * 64 + lane];
+            v[q] = inside(q * 64 + lane, lim) ? t : make_float2(0.f, 0.f);
+        }
+        if (j < 3) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the buffer has been read: line j+1 may overwrite it
+            copy_line(lr + 1);
+        }
+        fft512_inv(v, xch, s_tw, lane);
+        // keep k = lane + 64*j2 for j2 in {0,1,6,7}
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) keep[j][jj] = v[jj < 2 ? jj : jj + 4];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int j2 = jj < 2 ? jj : jj + 4;
+            s_t[crop_index(lane + 64 * j2) * (kLinesPerWg + 1) + wave * 4 + j] = keep[j][jj];
+        }
+    __syncthreads();
+    // transposed store: tmp[img][col][row0 .. row0+15]  (128 contiguous bytes per column)
+    float2 *dst = p.tmp + img * (size_t)kFKeep * kF;
+    for (int e = threadIdx.x; e < kFKeep * kLinesPerWg; e += 256) {
+        const int col = e / kLinesPerWg, r = e % kLinesPerWg;
+#ifndef TRON_FFT_NO_NT
+        st_nt(&dst[(size_t)col * kF + row0 + r], s_t[col * (kLinesPerWg + 1) + r]);
+#else
+        dst[(size_t)col * kF + row0 + r] = s_t[col * (kLinesPerWg + 1) + r];
+#endif
+    }
+}
+#else
 __global__ void __launch_bounds__(256) fft512_rows_kernel(const Fft512Params p)
 {
     // one LDS buffer: the waves' exchange regions while the lines are transformed, then the transposition tile (the kept
@@ -166,6 +249,7 @@ __global__ void __launch_bounds__(256) fft512_rows_kernel(const Fft512Params p)
 #endif
     }
 }
+#endif
 
 // grid = (256/16, nslices); block = 256.  Column FFTs + crop + deapodise + root-sum-of-squares.
 // SINGLE (one channel): the deapodised complex image passes through (src/tron.cu:265-266).  Otherwise only sum |.|^2 is
@@ -175,6 +259,88 @@ __global__ void __launch_bounds__(256) fft512_rows_kernel(const Fft512Params p)
 #ifndef TRON_FFT_COLS_WAVES
 #define TRON_FFT_COLS_WAVES 3
 #endif
+#ifndef TRON_FFT_COLS_NO_DMA
+// The next line (4 KiB, contiguous) is copied global -> LDS by LDS-DMA while the current one is transformed, as in pass 1:
+// 16 registers fewer than the register prefetch it replaces, so the kernel fits four waves per SIMD.
+template <bool SINGLE>
+__global__ void __launch_bounds__(256, 4) fft512_cols_post_kernel(const Fft512Params p)
+{
+    __shared__ float2 s_t[kFKeep * (kLinesPerWg + 1)];     // exchange regions | line buffers, then [kept row][col in block]
+    __shared__ float2 s_tw[kF];
+    static_assert(kFKeep * (kLinesPerWg + 1) >= 4 * kXch + 4 * kF, "exchange regions + line buffers must fit the transposition tile");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int z = blockIdx.y;
+    const int col0 = blockIdx.x * kLinesPerWg;
+    float2 *xch = s_t + wave * kXch;
+    float2 *lbuf = s_t + 4 * kXch + wave * kF;
+    float val[4][4];
+    float2 single[SINGLE ? 4 : 1][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            val[j][jj] = 0.f;
+            if (SINGLE) single[j][jj] = make_float2(0.f, 0.f);
+        }
+    const float2 *base = p.in + (size_t)z * p.nchan * (size_t)kFKeep * kF + (size_t)(col0 + wave * 4) * kF;
+    auto copy_line = [&](const float2 *line) {
+        // the intermediate is written once by pass 1 and read once here: streaming (non-temporal) accesses on both sides
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#ifndef TRON_FFT_NO_NT
+            lds_dma16_nt(line + k * 128 + 2 * lane, lds_addr(lbuf) + (unsigned)(k * 128 * sizeof(float2)));
+#else
+            lds_dma16(line + k * 128 + 2 * lane, lds_addr(lbuf) + (unsigned)(k * 128 * sizeof(float2)));
+#endif
+        }
+    };
+    copy_line(base);
+    for (int i = threadIdx.x; i < kF; i += 256) s_tw[i] = p.tw[i];
+    __syncthreads();
+    for (int c = 0; c < p.nchan; ++c) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float2 v[8];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this line has landed
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = lbuf[q * 64 + lane];
+            {
+                const int jn = (j + 1) & 3, cn = c + (j == 3 ? 1 : 0);
+                if (cn < p.nchan) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the buffer has been read
+                    copy_line(base + (size_t)cn * kFKeep * kF + (size_t)jn * kF);
+                }
+            }
+            fft512_inv(v, xch, s_tw, lane);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int j2 = jj < 2 ? jj : jj + 4;
+                const float2 u = v[j2];
+                if (SINGLE) single[j][jj] = u;
+                else val[j][jj] += u.x * u.x + u.y * u.y;                     // src/tron.cu:262 (the factor 1/w^2 is applied below)
+            }
+        }
+    }
+    __syncthreads();                                       // every wave is done with its exchange region and line buffer
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int j2 = jj < 2 ? jj : jj + 4;
+            const int rowc = crop_index(lane + 64 * j2);
+            const float inv = p.inv_deapod[rowc * kFKeep + col0 + wave * 4 + j];   // src/tron.cu:398-400
+            const float2 o = SINGLE ? make_float2(single[j][jj].x * inv, single[j][jj].y * inv)     // src/tron.cu:259-266
+                                    : make_float2(sqrtf(val[j][jj]) * inv, 0.f);
+            s_t[rowc * (kLinesPerWg + 1) + wave * 4 + j] = o;
+        }
+    __syncthreads();
+    float2 *dst = p.out + (size_t)z * kFKeep * kFKeep;
+    for (int e = threadIdx.x; e < kFKeep * kLinesPerWg; e += 256) {
+        const int row = e / kLinesPerWg, cc = e % kLinesPerWg;
+        dst[(size_t)row * kFKeep + col0 + cc] = s_t[row * (kLinesPerWg + 1) + cc];
+    }
+}
+#else
 template <bool SINGLE>
 __global__ void __launch_bounds__(256, TRON_FFT_COLS_WAVES) fft512_cols_post_kernel(const Fft512Params p)
 {
@@ -248,6 +414,7 @@ __global__ void __launch_bounds__(256, TRON_FFT_COLS_WAVES) fft512_cols_post_ker
         dst[(size_t)row * kFKeep + col0 + cc] = s_t[row * (kLinesPerWg + 1) + cc];
     }
 }
+#endif
 
 hipError_t launch_fft512_adjoint(const float2 *grid, float2 *tmp, float2 *out, const float2 *tw, const float *inv_deapod, int rzero,
                                  int nchan, int nslices, hipStream_t s)

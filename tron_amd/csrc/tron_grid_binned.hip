@@ -124,28 +124,6 @@ __device__ __forceinline__ void store_point_pair(const GridParams &p, int z, int
 //                          __syncthreads() there would wait for them.
 enum { kInRegs32 = 0, kInRegs16 = 1, kInLdsDma = 2 };
 
-// LDS-only workgroup barrier: every LDS access of this wave has completed; outstanding global loads keep flying.
-__device__ __forceinline__ void lds_barrier()
-{
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
-
-__device__ __forceinline__ unsigned lds_addr(const void *q)    // byte address inside the workgroup's LDS allocation
-{
-    return (unsigned)(size_t)(__attribute__((address_space(3))) const void *)q;
-}
-
-// One 16-byte-per-lane copy global -> LDS: lane l's bytes land at lds_dst + 16 l (lds_dst wave-uniform).  Issued from
-// inline assembly on purpose: hipcc would otherwise wait vmcnt(0) before the next LDS read of ANY address.
-__device__ __forceinline__ void lds_dma16(const void *gsrc, unsigned lds_dst)
-{
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(__builtin_amdgcn_readfirstlane((int)lds_dst)) : "memory");
-}
-
 // Phase clock of tools/gridprof.py (-DTRON_BIN_PROFILE builds only): shader-clock cycles per wave and phase, summed
 // over all waves of all launches since the last read; production builds carry none of it.
 #ifdef TRON_BIN_PROFILE
