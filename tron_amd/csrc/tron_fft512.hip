@@ -262,27 +262,32 @@ __global__ void __launch_bounds__(256) fft512_rows_kernel(const Fft512Params p)
 #ifndef TRON_FFT_COLS_NO_DMA
 // The next line (4 KiB, contiguous) is copied global -> LDS by LDS-DMA while the current one is transformed, as in pass 1:
 // 16 registers fewer than the register prefetch it replaces, so the kernel fits four waves per SIMD.
-template <bool SINGLE>
+// LPW = columns per wave (4 LPW per workgroup).  A 64-slice launch has 16 x 64 = 1 024 workgroups of 16 columns = exactly
+// the 4 per CU that fit; launches of fewer slices use 8 or 4 columns per workgroup so that the chip is still full (a
+// 32-slice launch at 16 columns left half of it idle: 7 % of `bench.py --slices 32`).
+template <bool SINGLE, int LPW>
 __global__ void __launch_bounds__(256, 4) fft512_cols_post_kernel(const Fft512Params p)
 {
-    __shared__ float2 s_t[kFKeep * (kLinesPerWg + 1)];     // exchange regions | line buffers, then [kept row][col in block]
+    constexpr int kCols = 4 * LPW;
+    constexpr int kTileElems = kFKeep * (kCols + 1);       // [kept row][col in block], +1 pad
+    constexpr int kLdsElems = kTileElems > 4 * kXch + 4 * kF ? kTileElems : 4 * kXch + 4 * kF;
+    __shared__ float2 s_t[kLdsElems];                      // exchange regions | line buffers, then the output tile
     __shared__ float2 s_tw[kF];
-    static_assert(kFKeep * (kLinesPerWg + 1) >= 4 * kXch + 4 * kF, "exchange regions + line buffers must fit the transposition tile");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int z = blockIdx.y;
-    const int col0 = blockIdx.x * kLinesPerWg;
+    const int col0 = blockIdx.x * kCols;
     float2 *xch = s_t + wave * kXch;
     float2 *lbuf = s_t + 4 * kXch + wave * kF;
-    float val[4][4];
-    float2 single[SINGLE ? 4 : 1][4];
+    float val[LPW][4];
+    float2 single[SINGLE ? LPW : 1][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < LPW; ++j)
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
             val[j][jj] = 0.f;
             if (SINGLE) single[j][jj] = make_float2(0.f, 0.f);
         }
-    const float2 *base = p.in + (size_t)z * p.nchan * (size_t)kFKeep * kF + (size_t)(col0 + wave * 4) * kF;
+    const float2 *base = p.in + (size_t)z * p.nchan * (size_t)kFKeep * kF + (size_t)(col0 + wave * LPW) * kF;
     auto copy_line = [&](const float2 *line) {
         // the intermediate is written once by pass 1 and read once here: streaming (non-temporal) accesses on both sides
 #pragma unroll
@@ -299,13 +304,13 @@ __global__ void __launch_bounds__(256, 4) fft512_cols_post_kernel(const Fft512Pa
     __syncthreads();
     for (int c = 0; c < p.nchan; ++c) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < LPW; ++j) {
             float2 v[8];
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this line has landed
 #pragma unroll
             for (int q = 0; q < 8; ++q) v[q] = lbuf[q * 64 + lane];
             {
-                const int jn = (j + 1) & 3, cn = c + (j == 3 ? 1 : 0);
+                const int jn = (j + 1) % LPW, cn = c + (j == LPW - 1 ? 1 : 0);
                 if (cn < p.nchan) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the buffer has been read
                     copy_line(base + (size_t)cn * kFKeep * kF + (size_t)jn * kF);
@@ -323,25 +328,25 @@ __global__ void __launch_bounds__(256, 4) fft512_cols_post_kernel(const Fft512Pa
     }
     __syncthreads();                                       // every wave is done with its exchange region and line buffer
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < LPW; ++j)
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
             const int j2 = jj < 2 ? jj : jj + 4;
             const int rowc = crop_index(lane + 64 * j2);
-            const float inv = p.inv_deapod[rowc * kFKeep + col0 + wave * 4 + j];   // src/tron.cu:398-400
+            const float inv = p.inv_deapod[rowc * kFKeep + col0 + wave * LPW + j];   // src/tron.cu:398-400
             const float2 o = SINGLE ? make_float2(single[j][jj].x * inv, single[j][jj].y * inv)     // src/tron.cu:259-266
                                     : make_float2(sqrtf(val[j][jj]) * inv, 0.f);
-            s_t[rowc * (kLinesPerWg + 1) + wave * 4 + j] = o;
+            s_t[rowc * (kCols + 1) + wave * LPW + j] = o;
         }
     __syncthreads();
     float2 *dst = p.out + (size_t)z * kFKeep * kFKeep;
-    for (int e = threadIdx.x; e < kFKeep * kLinesPerWg; e += 256) {
-        const int row = e / kLinesPerWg, cc = e % kLinesPerWg;
-        dst[(size_t)row * kFKeep + col0 + cc] = s_t[row * (kLinesPerWg + 1) + cc];
+    for (int e = threadIdx.x; e < kFKeep * kCols; e += 256) {
+        const int row = e / kCols, cc = e % kCols;
+        dst[(size_t)row * kFKeep + col0 + cc] = s_t[row * (kCols + 1) + cc];
     }
 }
 #else
-template <bool SINGLE>
+template <bool SINGLE, int LPW_UNUSED>
 __global__ void __launch_bounds__(256, TRON_FFT_COLS_WAVES) fft512_cols_post_kernel(const Fft512Params p)
 {
     __shared__ float2 s_t[kFKeep * (kLinesPerWg + 1)];     // [kept row][col in block]; the exchange regions until then
@@ -426,10 +431,22 @@ hipError_t launch_fft512_adjoint(const float2 *grid, float2 *tmp, float2 *out, c
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     p.in = tmp;
-    if (nchan == 1)
-        hipLaunchKernelGGL(fft512_cols_post_kernel<true>, dim3(kFKeep / kLinesPerWg, nslices), dim3(256), 0, s, p);
-    else
-        hipLaunchKernelGGL(fft512_cols_post_kernel<false>, dim3(kFKeep / kLinesPerWg, nslices), dim3(256), 0, s, p);
+#ifndef TRON_FFT_COLS_NO_DMA
+    // enough workgroups to fill the chip (4 per CU x 256 CUs): 16 columns each from 64 slices on, 8 from 32, else 4
+    const int lpw = nslices >= 64 ? 4 : (nslices >= 32 ? 2 : 1);
+#else
+    const int lpw = 4;
+#endif
+    const dim3 grid_c(kFKeep / (4 * lpw), nslices);
+    if (nchan == 1) {
+        if (lpw == 4) hipLaunchKernelGGL((fft512_cols_post_kernel<true, 4>), grid_c, dim3(256), 0, s, p);
+        else if (lpw == 2) hipLaunchKernelGGL((fft512_cols_post_kernel<true, 2>), grid_c, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((fft512_cols_post_kernel<true, 1>), grid_c, dim3(256), 0, s, p);
+    } else {
+        if (lpw == 4) hipLaunchKernelGGL((fft512_cols_post_kernel<false, 4>), grid_c, dim3(256), 0, s, p);
+        else if (lpw == 2) hipLaunchKernelGGL((fft512_cols_post_kernel<false, 2>), grid_c, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((fft512_cols_post_kernel<false, 1>), grid_c, dim3(256), 0, s, p);
+    }
     return hipGetLastError();
 }
 
