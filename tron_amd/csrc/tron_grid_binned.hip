@@ -734,9 +734,18 @@ grid_reduce_parts_kernel(const GridParams p)
 #pragma unroll
     for (int qy = 0; qy < 2; ++qy) {
         float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int g = 0; g < nparts; ++g) {
-            const float4 v = *reinterpret_cast<const float4 *>(base + (size_t)g * pch * (kBinTile * kBinTile) + (my + qy) * kBinTile + mx);
-            sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+        // eight parts at a time with all their loads in flight (a load-add chain per part made this tiny kernel take
+        // one HBM round trip per part); summed in part order all the same
+        for (int g0 = 0; g0 < nparts; g0 += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                v[k] = g0 + k < nparts
+                           ? *reinterpret_cast<const float4 *>(base + (size_t)(g0 + k) * pch * (kBinTile * kBinTile) + (my + qy) * kBinTile + mx)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (g0 + k < nparts) { sum.x += v[k].x; sum.y += v[k].y; sum.z += v[k].z; sum.w += v[k].w; }
         }
         if (inner) store_point_pair<true>(p, zs, c, x0 + mx, y0 + my + qy, sum);
         else store_point_pair(p, zs, c, x0 + mx, y0 + my + qy, sum);
