@@ -165,7 +165,7 @@ grid_binned_kernel(const GridParams p)
     // vslices > 1 (linear angles: every slice has the SAME trajectory, src/tron.cu:509 depends on pe only): `vslices`
     // consecutive slices ride in the coil dimension -- register channel c = slice (c / nchan) of the group, coil c % nchan
     // -- so clipping, weights and the sort are paid once per group instead of once per slice
-    const int vs = p.vslices > 1 ? p.vslices : 1;
+    const int vs = DMA ? 1 : (p.vslices > 1 ? p.vslices : 1);   // (the LDS-DMA instantiation never carries slice groups)
     const int zbase = z * vs;
     const int c0 = vs > 1 ? 0 : p.coil0 + blockIdx.y * CPB;
     const int ncb = vs > 1 ? min(CPB, (p.nslices_total - zbase) * p.nchan) : min(CPB, p.nchan - c0);
