@@ -55,7 +55,7 @@ struct BinCfg {
 #ifdef TRON_BIN_REC_KB
     static constexpr int REC_KB = TRON_BIN_REC_KB;
 #else
-    static constexpr int REC_KB = CPB >= 8 ? 36 : (CPB >= 2 ? 24 : 28);
+    static constexpr int REC_KB = CPB >= 8 ? 36 : (CPB >= 6 ? 30 : (CPB >= 2 ? 24 : 28));   // 6 coils: 256 records too
 #endif
     static constexpr int NREC_RAW = (REC_KB * 1024) / REC_BYTES;
     static constexpr int NREC = NREC_RAW >= 512 ? 512 : (NREC_RAW / 64) * 64;
@@ -812,10 +812,16 @@ static hipError_t launch_binned_cw(const GridParams &p, int half_in, hipStream_t
     const int nc = p.nchan - p.coil0;
     static const int force = getenv("TRON_GRID_CPB") ? atoi(getenv("TRON_GRID_CPB")) : 0;   // tuning knob
     if (force == 8) return launch_binned_cpb<8, CW>(p, half_in, s);
+    if (force == 6) return launch_binned_cpb<6, CW>(p, half_in, s);
     if (force == 4) return launch_binned_cpb<4, CW>(p, half_in, s);
     // one padded 8-coil pass beats two 4-coil passes: the per-sample work (weights, sort) is paid per pass
-    // (6 coils: 3.3 vs 4.9 us per coil-slice; 12 coils: 4.1 vs 4.4)
-    if (nc >= 5) return launch_binned_cpb<8, CW>(p, half_in, s);
+    // (6 coils: 3.3 vs 4.9 us per coil-slice; 12 coils: 4.1 vs 4.4); passes of 6 coils where they pad less than passes of 8
+    // (5, 6, 10, 12 coils: the whole-body data set has 6) -- fp32 input only, complex-half loads come in fours
+    if (nc >= 5) {
+        const int pad8 = (nc + 7) / 8 * 8, pad6 = (nc + 5) / 6 * 6;
+        if (pad6 < pad8 && !half_in) return launch_binned_cpb<6, CW>(p, half_in, s);
+        return launch_binned_cpb<8, CW>(p, half_in, s);
+    }
     if (nc >= 4) return launch_binned_cpb<4, CW>(p, half_in, s);
     if (nc >= 2) return launch_binned_cpb<2, CW>(p, half_in, s);
     return launch_binned_cpb<1, CW>(p, half_in, s);
