@@ -1,0 +1,35 @@
+"""Where a wave of the arc gridding kernel spends its cycles, phase by phase, and how full its loops run (kernel work tooling).
+Needs a -DTRON_ARC_PROFILE build of tron_grid_arc.hip copied over tron_amd/lib/libtronhip.so:
+    tools/build_variants.sh aprof:"-DTRON_ARC_PROFILE":tron_grid_arc.hip     (then, on the GPU box)
+    cp tron_amd/lib/libtronhip_aprof.so tron_amd/lib/libtronhip.so; python tools/arcprof.py [coils] [slices]"""
+import ctypes, os, sys
+import numpy as np
+os.environ.setdefault("TRON_DUAL_STREAM", "0")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tron_amd import lib
+nc = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+nz = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+NRO, NPE = 512, int(os.environ.get("NPE", "402"))
+NAMES = ["tile setup + run table", "barrier", "DMA issue", "window search", "DMA wait", "barrier", "gather", "output store"]
+cfg = lib.default_config(adjoint=1, golden_angle=1, data_undersamp=0.7852, prof_slide=NPE, kb_mode=lib.KB_FAST)
+dims = lib.derive_dims(cfg, (nc, 1, NRO, NPE * nz, 1))
+rng = np.random.default_rng(1)
+data = (rng.random(2 * nc * NRO * NPE * nz, dtype=np.float32) * 2 - 1)
+L = lib.load()
+fn = L.tron_debug_arc_profile
+fn.restype, fn.argtypes = ctypes.c_int, [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
+buf = (ctypes.c_ulonglong * 16)()
+with lib.Plan(cfg, dims) as plan:
+    d_in = lib.DeviceBuffer.from_numpy(data)
+    d_out = lib.DeviceBuffer(dims.out_bytes)
+    plan.adjoint_device(d_out.ptr, d_in.ptr, 0, nz, 1); plan.sync()
+    assert fn(buf, 16) == 0                                   # clears the warm-up launch
+    plan.adjoint_device(d_out.ptr, d_in.ptr, 0, nz, 1); plan.sync()
+    assert fn(buf, 16) == 0
+tot = float(sum(buf[:8]))
+print(f"nc={nc} nz={nz}: {tot:.3e} wave-cycles in total")
+for name, v in zip(NAMES, buf):
+    print(f"  {name:40s} {100.0 * v / tot:6.2f} %")
+print(f"  outer (spoke) iterations per slice {buf[12] / nz:.0f}, lanes active {buf[13] / max(buf[12], 1) / 64:.3f}")
+print(f"  inner (radius) iterations per slice {buf[14] / nz:.0f}, lanes active {buf[15] / max(buf[14], 1) / 64:.3f}; "
+      f"gather cycles per inner iteration {buf[6] / max(buf[14], 1):.0f}")

@@ -128,6 +128,15 @@ __device__ __forceinline__ void lds_dma16_nt(const void *gsrc, unsigned lds_dst)
                  : "=&s"(keep) : "v"(gsrc), "s"(__builtin_amdgcn_readfirstlane((int)lds_dst)) : "memory");
 }
 
+// The same with the source as a wave-uniform base (an SGPR pair) plus a 32-bit byte offset per lane: no 64-bit vector
+// address arithmetic at the call site.
+__device__ __forceinline__ void lds_dma16_s(const void *sbase, unsigned voff, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+
 __device__ __forceinline__ float safe_rcp(float c)
 {
     return fabsf(c) > 1e-12f ? 1.0f / c : copysignf(1e12f, c);

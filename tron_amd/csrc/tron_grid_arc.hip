@@ -1,0 +1,778 @@
+// Gridding kernel of the TRON_KB_FAST path for radial trajectories: every thread WALKS THE ARC of spokes that can reach
+// its 2x2 grid points.
+//
+// Same (sample, point) pairs and the same arithmetic per pair as the reference's gridradial2d (src/tron.cu:465-536: kx, ky
+// :514-515, weights :516, band :498-502,:512, density compensation :412-414, scale :532), found the way the reference
+// finds them -- per point, per spoke, the radii inside the band -- but with the spokes SORTED BY LINE ANGLE: the spokes
+// whose samples can fall inside a point's Kaiser-Bessel footprint are then one contiguous run of the sorted list (those
+// within asin((W + 1/2)(|cos| + |sin|) / R) of the point's own direction), and on each of them the radii are one interval
+// that the thread clips analytically.  No sort of samples by cell, no per-sample staging pass, no per-batch planning: the
+// only per-sample work is one LDS-DMA copy.  Sums run spoke-angle-major instead of acquisition-major and the window comes
+// from a table (quadratic interpolation, 1e-7 of the reference's expression), so results agree with the reference to fp32
+// summation-order noise (~1e-7 relative L2), not bit for bit: TRON_KB_FAST only.
+//
+// Everything that depends on the trajectory alone is worked out ONCE, when the plan is created (arc_prep_kernel: the angle
+// sets of all slices are known then), and kept in HBM, ~20 bytes per (slice, tile, crossing spoke):
+//   clip    thread = spoke of the angle-sorted list (host tables).  The spokes that cross tile + halo are one run of the
+//           list (a convex region subtends an interval of directions); the run is cut at the direction perpendicular to the
+//           tile centre so that it never wraps.  Segment = u in [ulo, ulo + len) with the spoke's direction flipped where
+//           needed so that u = |r| > 0 (the tiles of this kernel never hold r = 0: the k-space centre belongs to the inner
+//           tile of the binned kernel, GridParams::inner_r0).
+//   deal    the run is dealt round-robin into K batches ("combs": batch b = entries b, b + K, ...), K = the fewest batches
+//           whose records fit in half the LDS sample space.  A comb covers the whole tile evenly, so every thread has work
+//           in every batch; each entry gets its record offset inside its comb.
+// grid_arc_kernel, one workgroup = 4 waves = one 32x32 tile, each thread 2x2 points, CPB coils in registers; per slice:
+//   table   the tile's run (<= 512 entries of 20 bytes) is copied to LDS;
+//   window  each thread finds its own run [jlo, jhi] of the list by binary search on the line angles;
+//   batch   the comb's samples are copied global -> LDS by global_load_lds_dwordx4 (one wave instruction per spoke
+//           segment and coil pair) into one of TWO buffers: batch b + 1 flies while batch b is gathered, one barrier each;
+//   gather  thread: for its comb members, clip the spoke against the 2x2 block + footprint, then per radius: two products
+//           for (kx, ky), four table lookups, band tests, 4 points x CPB coils of packed FMAs from four 16-byte LDS reads.
+// No floating-point atomics; the output is written once, coil-planar, in FFT-native order (tron_grid_store.h).
+#include <stdlib.h>
+
+#include "tron_device.h"
+#include "tron_grid_store.h"
+
+namespace tron {
+
+constexpr int kArcTile = 32;
+constexpr int kArcThreads = 256;
+constexpr int kArcMaxNpe = 768;        // spokes per window (prep: thread = spoke, three per thread)
+constexpr int kArcMaxSpokes = 512;     // spokes of one tile's run
+constexpr int kArcMaxBatches = 96;
+constexpr int kArcSeg = 64;            // longest spoke segment through tile + halo: (32 + 2 * 3) sqrt(2) = 54
+constexpr float kPi = 3.14159265358979f;
+
+template <int CPB>
+struct ArcCfg {
+    // sample records per batch.  One buffer: same-box A/B at 8 coils, gridding us per coil-slice: two buffers of 304 records
+    // (batch b + 1 copied while batch b is gathered) 1.69-1.70, of 256 1.72-1.75; ONE buffer of 608 1.58-1.59 -- half the
+    // batches means twice the comb members per thread and batch, and the lanes of a wave run far more evenly.
+    // Three workgroups per CU at 6 and 8 coils (the accumulators allow 3 waves per SIMD anyway), four below.
+#ifdef TRON_ARC_NREC
+    static constexpr int NREC = TRON_ARC_NREC;
+#else
+    static constexpr int NREC = CPB >= 8 ? 608 : (CPB >= 6 ? 800 : (CPB >= 4 ? 800 : 1600));
+#endif
+    static constexpr int WAVES = CPB >= 6 ? 3 : 4;
+#ifdef TRON_ARC_DOUBLE_BUFFER
+    static constexpr int NBUF = 2;
+#else
+    static constexpr int NBUF = 1;
+#endif
+};
+
+template <int CPB>
+struct ArcLds {
+    float4 lut[kArcLutEntries];            // Kaiser-Bessel window on [i, i + 1) / scale: c0 + f (c1 + f c2)
+    unsigned s_a[kArcMaxSpokes];           // run entry: sample index of its first record | (records run downwards) << 31
+    unsigned s_b[kArcMaxSpokes];           //            ulo | len << 10 | record offset inside its batch << 17
+    float2 s_cs[kArcMaxSpokes];            //            (cos, sin) of the (flipped) direction
+    float phi[kArcMaxSpokes];              //            line angle, unwrapped
+    float4 d[ArcCfg<CPB>::NBUF * (CPB / 2) * ArcCfg<CPB>::NREC];   // samples [buffer][coil pair][record]
+};
+
+int grid_arc_nrec(int nchan)               // records per batch for a plan of nchan channels (must match launch_grid_arc's choice of CPB)
+{
+    if (nchan >= 5) {
+        const int pad8 = (nchan + 7) / 8 * 8, pad6 = (nchan + 5) / 6 * 6;
+        return pad6 < pad8 ? ArcCfg<6>::NREC : ArcCfg<8>::NREC;
+    }
+    return nchan >= 3 ? ArcCfg<4>::NREC : ArcCfg<2>::NREC;
+}
+
+// Phase clock of tools/arcprof.py (-DTRON_ARC_PROFILE builds only): shader-clock cycles per wave and phase plus loop
+// counters, summed over all waves of all launches since the last read; production builds carry none of it.
+#ifdef TRON_ARC_PROFILE
+constexpr int kArcProfSlots = 16, kArcProfCopies = 4096;
+__device__ unsigned long long g_arc_prof[kArcProfCopies * kArcProfSlots];
+#define APROF_DECL unsigned prof_acc[kArcProfSlots] = {}; unsigned long long prof_t = __builtin_readcyclecounter()
+#define APROF_MARK(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); prof_acc[i] += (unsigned)(t_ - prof_t); prof_t = t_; } while (0)
+#define APROF_COUNT(i, v) do { prof_acc[i] += (unsigned)(v); } while (0)
+#define APROF_FLUSH do { for (int i_ = 12; i_ < 16; ++i_) for (int o_ = 32; o_ > 0; o_ >>= 1) prof_acc[i_] += __shfl_xor(prof_acc[i_], o_); if (lane == 0) { for (int i_ = 0; i_ < kArcProfSlots; ++i_) if (prof_acc[i_]) atomicAdd(&g_arc_prof[((blockIdx.x * 4 + wave) % kArcProfCopies) * kArcProfSlots + i_], (unsigned long long)prof_acc[i_]); } } while (0)
+#else
+#define APROF_DECL
+#define APROF_MARK(i)
+#define APROF_COUNT(i, v)
+#define APROF_FLUSH
+#endif
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(3))) v4f *lds_f4p;
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Plan-time pass: the run of every (window, tile), dealt into combs.  grid = (tiles, windows), block = 256.
+struct ArcPrepLds {
+    unsigned s_a[kArcMaxSpokes];
+    unsigned s_b[kArcMaxSpokes];
+    float2 s_cs[kArcMaxSpokes];
+    float phi[kArcMaxSpokes];
+    int bstart[kArcMaxBatches + 1];
+    int wsum[8];
+    int umin, umax, total, kfail, base;
+};
+
+__global__ void __launch_bounds__(kArcThreads)
+arc_prep_kernel(const ArcPrepParams p)
+{
+    __shared__ ArcPrepLds L;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int tile = blockIdx.x;
+    const int w = blockIdx.y;
+    const int n = p.nxos, h = n / 2, rmax = n / 2 - 1;
+    const int tpr = n / kArcTile;
+    const int x0 = (tile % tpr) * kArcTile - h, y0 = (tile / tpr) * kArcTile - h;
+    const bool outer = (x0 == 0 || x0 == -kArcTile) && (y0 == 0 || y0 == -kArcTile);
+    const unsigned short *order = p.order + (size_t)w * p.npe;
+    const float *phis = p.phi + (size_t)w * p.npe;
+    const float2 *sorted_cs = p.cs + (size_t)w * p.npe;
+    int4 *hdr = p.hdr + (size_t)w * p.ntiles + tile;
+
+    // line angles: the run is unwrapped at the direction perpendicular to the tile centre (no spoke of the run is near it)
+    float wrap = atan2f((float)y0 + 15.5f, (float)x0 + 15.5f) + 0.5f * kPi;
+    wrap -= floorf(wrap / kPi) * kPi;
+    const float eps = 0.01f;
+    const float bx_lo = (float)x0 - p.W - eps, bx_hi = (float)(x0 + kArcTile - 1) + p.W + eps;
+    const float by_lo = (float)y0 - p.W - eps, by_hi = (float)(y0 + kArcTile - 1) + p.W + eps;
+
+    if (tid == 0) { L.umin = 1 << 30; L.umax = -1; L.total = 0; L.kfail = 0; L.base = 0; }
+    __syncthreads();
+
+    // ---- clip: thread = spoke of the angle-sorted list -----------------------------------------------------------
+    constexpr int NCH = kArcMaxNpe / kArcThreads;
+    int c_src[NCH], c_pos[NCH], c_seg[NCH];
+    float c_phi[NCH];
+    float2 c_cs[NCH];
+    {
+        int lmin = 1 << 30, lmax = -1, lsum = 0;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int j = tid + k * kArcThreads;
+            c_pos[k] = -1;
+            c_seg[k] = 0;
+            c_src[k] = 0;
+            c_phi[k] = 0.f;
+            c_cs[k] = make_float2(1.f, 0.f);
+            if (j < p.npe) {
+                const int pe = order[j];
+                const float ph = phis[j];
+                const float2 cs = sorted_cs[j];
+                const float ic = safe_rcp(cs.x), is = safe_rcp(cs.y);
+                const float xa = bx_lo * ic, xb = bx_hi * ic;
+                const float ya = by_lo * is, yb = by_hi * is;
+                const float lo = fmaxf(fmaxf(fminf(xa, xb), fminf(ya, yb)), -(float)rmax);
+                const float hi = fminf(fminf(fmaxf(xa, xb), fmaxf(ya, yb)), (float)rmax);
+                int len = 0, ulo = 0, neg = 0;
+                if (lo <= hi) {
+                    int rlo = (int)ceilf(lo);
+                    int rhi = (int)floorf(hi);
+                    if (outer) {
+                        // a quadrant tile holds one side of a spoke plus at most W sqrt(2) < inner_r0 beyond the origin
+                        if (rhi >= p.inner_r0) {
+                            if (rlo <= -p.inner_r0) atomicOr(p.errflag, 16u);
+                            rlo = max(rlo, p.inner_r0);
+                        } else if (rlo <= -p.inner_r0) {
+                            rhi = min(rhi, -p.inner_r0);
+                        } else {
+                            rhi = rlo - 1;
+                        }
+                    }
+                    if (rhi >= rlo) {
+                        if (rlo <= 0 && rhi >= 0) {             // r = 0 never belongs to a tile of this kernel
+                            atomicOr(p.errflag, 32u);
+                        } else {
+                            neg = rhi < 0;
+                            ulo = neg ? -rhi : rlo;
+                            len = rhi - rlo + 1;
+                            if (len > kArcSeg) { atomicOr(p.errflag, 2u); len = kArcSeg; }
+                        }
+                    }
+                }
+                const bool wrapped = ph < wrap;
+                c_pos[k] = j + (wrapped ? p.npe : 0);
+                c_phi[k] = ph + (wrapped ? kPi : 0.f);
+                // sample of radius r on spoke pe: nudata[nchan * (nro * pe + r + nro / 2) + c]   src/tron.cu:517,519 (nro == nxos)
+                c_src[k] = (int)((unsigned)(p.nro * pe + p.nro / 2 + (neg ? -ulo : ulo)) | ((unsigned)neg << 31));
+                c_seg[k] = ulo | (len << 10);
+                c_cs[k] = neg ? make_float2(-cs.x, -cs.y) : cs;
+                if (len > 0) {
+                    lmin = min(lmin, c_pos[k]);
+                    lmax = max(lmax, c_pos[k]);
+                    lsum += len;
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lmin = min(lmin, __shfl_xor(lmin, o));
+            lmax = max(lmax, __shfl_xor(lmax, o));
+            lsum += __shfl_xor(lsum, o);
+        }
+        if (lane == 0 && lmax >= 0) {
+            atomicMin(&L.umin, lmin);
+            atomicMax(&L.umax, lmax);
+            atomicAdd(&L.total, lsum);
+        }
+    }
+    __syncthreads();
+    const int umin = L.umin, umax = L.umax, total = L.total;
+    int ns = umax >= umin ? umax - umin + 1 : 0;
+    if (ns > kArcMaxSpokes) {
+        if (tid == 0) atomicOr(p.errflag, 64u);
+        ns = kArcMaxSpokes;
+    }
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int idx = c_pos[k] - umin;
+        if (c_pos[k] >= 0 && idx >= 0 && idx < ns) {
+            L.s_a[idx] = (unsigned)c_src[k];
+            L.s_b[idx] = (unsigned)c_seg[k];
+            L.s_cs[idx] = c_cs[k];
+            L.phi[idx] = c_phi[k];
+        }
+    }
+
+    // ---- deal the run into K combs; record offsets inside each comb (an exclusive scan in comb-major order) ----------
+    int K = max(1, (total + p.nrec - 1) / p.nrec);
+    for (;;) {
+        __syncthreads();                                    // run entries written (first pass) / kfail cleared (later passes)
+        K = min(K, kArcMaxBatches);
+        const int M = (ns + K - 1) / K;                     // members of the longest comb
+        const int QT = K * M;
+        const int QPT = (QT + kArcThreads - 1) / kArcThreads;   // <= 3
+        int e_i[3], e_b[3], e_len[3], e_first[3];
+        int tsum = 0;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            const int q = tid * QPT + e;
+            e_i[e] = -1; e_b[e] = 0; e_len[e] = 0; e_first[e] = 0;
+            if (e < QPT && q < QT) {
+                const int b = q / M, m = q - b * M;
+                const int i = m * K + b;
+                e_b[e] = b;
+                e_first[e] = m == 0;
+                if (i < ns) {
+                    e_i[e] = i;
+                    e_len[e] = (int)((L.s_b[i] >> 10) & 127u);
+                }
+                tsum += e_len[e];
+            }
+        }
+        int v = tsum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(v, o);
+            if (lane >= o) v += t;
+        }
+        if (lane == 63) L.wsum[wave] = v;
+        __syncthreads();
+        int run = v - tsum;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww)
+            if (ww < wave) run += L.wsum[ww];
+        int e_excl[3];
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            e_excl[e] = run;
+            if (e_first[e]) L.bstart[e_b[e]] = run;
+            run += e_len[e];
+        }
+        if (tid == 0) L.bstart[K] = total;
+        __syncthreads();
+        bool bad = false;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            if (e_i[e] >= 0) {
+                const int off = e_excl[e] - L.bstart[e_b[e]];
+                L.s_b[e_i[e]] = (L.s_b[e_i[e]] & 0x1ffffu) | ((unsigned)off << 17);
+            }
+            if (e_first[e] && L.bstart[e_b[e] + 1] - L.bstart[e_b[e]] > p.nrec) bad = true;
+        }
+        if (bad) L.kfail = 1;
+        __syncthreads();
+        if (!L.kfail) break;
+        if (K >= kArcMaxBatches) {                          // cannot happen for npe <= kArcMaxNpe (grid_arc_supported)
+            if (tid == 0) atomicOr(p.errflag, 256u);
+            break;
+        }
+        __syncthreads();
+        if (tid == 0) L.kfail = 0;
+        ++K;                                                // a comb overflowed its share: one more comb
+    }
+
+    // ---- publish ----
+    if (tid == 0) {
+        int base = ns > 0 ? atomicAdd(p.alloc + w, ns) : 0;
+        if (base + ns > p.cap) {
+            atomicOr(p.errflag, 512u);
+            base = 0;
+            L.base = -1;
+        } else {
+            L.base = base;
+        }
+        *hdr = make_int4(L.base < 0 ? 0 : ns, K, base, total);
+    }
+    __syncthreads();
+    const int base = L.base;
+    if (base < 0) return;
+    uint4 *ent = p.ent + (size_t)w * p.cap + base;
+    float *ephi = p.ephi + (size_t)w * p.cap + base;
+    for (int i = tid; i < ns; i += kArcThreads) {
+        const float2 cs = L.s_cs[i];
+        ent[i] = make_uint4(L.s_a[i], L.s_b[i], __float_as_uint(cs.x), __float_as_uint(cs.y));
+        ephi[i] = L.phi[i];
+    }
+}
+
+hipError_t launch_arc_prep(const ArcPrepParams &p, int nwindows, hipStream_t s)
+{
+    if (p.npe > kArcMaxNpe || p.nrec < kArcSeg || (p.nxos / 2) % kArcTile != 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(arc_prep_kernel, dim3((unsigned)p.ntiles, (unsigned)nwindows), dim3(kArcThreads), 0, s, p);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+template <int CPB>
+__global__ void __launch_bounds__(kArcThreads, ArcCfg<CPB>::WAVES)
+grid_arc_kernel(const GridParams p)
+{
+    using C = ArcCfg<CPB>;
+    static_assert(CPB % 2 == 0, "the samples are copied as 16-byte coil pairs");
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    ArcLds<CPB> &L = *reinterpret_cast<ArcLds<CPB> *>(lds_raw);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int zper = p.arc_zper > 0 ? p.arc_zper : 1;
+    const int ngroups = (p.nslices + zper - 1) / zper;
+    const int zg = blockIdx.x % ngroups;
+    const int tile = p.tile_order[blockIdx.x / ngroups] & 0xffff;
+    if (tile >= p.ntiles) {
+        if (tid == 0) atomicOr(p.errflag, 128u);
+        return;
+    }
+    const int c0 = p.coil0 + blockIdx.y * CPB;
+    const int ncb = min(CPB, p.nchan - c0);
+    const int n = p.nxos;
+    const int h = n / 2;
+    const int rmax = n / 2 - 1;
+    const int x0 = (tile % p.tiles_per_row) * kArcTile - h;     // tile origin, centred coordinates
+    const int y0 = (tile / p.tiles_per_row) * kArcTile - h;
+    // the four tiles that meet at the k-space centre leave |r| < inner_r0 to the inner tile (tron_grid_binned.hip)
+    const bool outer = (x0 == 0 || x0 == -kArcTile) && (y0 == 0 || y0 == -kArcTile);
+    if (p.skip_outside) {
+        // nearest point of the tile to the k-space centre; beyond rmax + W every band is empty (src/tron.cu:498-502,512)
+        const int ax = max(max(x0, -(x0 + kArcTile - 1)), 0), ay = max(max(y0, -(y0 + kArcTile - 1)), 0);
+        const float lim = (float)rmax + p.W + 1.0f;
+        if ((float)(ax * ax + ay * ay) > lim * lim) return;
+    }
+    const int mx = 2 * (lane & 15);                             // this thread's 2x2 points, tile-relative
+    const int my = 8 * wave + 2 * (lane >> 4);
+    const int X0 = x0 + mx, Y0 = y0 + my;
+    int Rlo[4], Rhi[4];                                         // radial band per point, src/tron.cu:498-502
+    int bandlo = 1 << 20, bandhi = -1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int X = X0 + (q & 1), Y = Y0 + (q >> 1);
+        Rlo[q] = 1; Rhi[q] = 0;
+        if (X + h < n && Y + h < n) {
+            const uint32_t bnd = p.band[(size_t)(Y + h) * n + (X + h)];
+            const int lo = (int)(bnd & 0xffffu), hi = (int)(bnd >> 16);
+            if (lo <= hi) { Rlo[q] = lo; Rhi[q] = hi; bandlo = min(bandlo, lo); bandhi = max(bandhi, hi); }
+        }
+    }
+    // the bands as bit masks over u - bandlo (the four bands of a 2x2 block span at most 2W + 3 radii)
+    unsigned bmask[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        bmask[q] = 0u;
+        if (Rlo[q] <= Rhi[q] && Rhi[q] - bandlo < 31) bmask[q] = (0xffffffffu >> (31 - (Rhi[q] - Rlo[q]))) << (Rlo[q] - bandlo);
+    }
+    const int umin_tile = outer ? max(p.inner_r0, 1) : 1;
+    const bool has_work = bandlo <= bandhi && bandhi >= umin_tile;
+    const float blo_f = (float)max(bandlo, umin_tile), bhi_f = (float)bandhi;
+
+    // line angles are unwrapped at the direction perpendicular to the tile centre, like the run's (arc_prep_kernel)
+    float wrap = atan2f((float)y0 + 15.5f, (float)x0 + 15.5f) + 0.5f * kPi;
+    wrap -= floorf(wrap / kPi) * kPi;
+    const float X0f = (float)X0, X1f = (float)(X0 + 1), Y0f = (float)Y0, Y1f = (float)(Y0 + 1);
+    float tlo, thi;
+    {
+        const float Xc = X0f + 0.5f, Yc = Y0f + 0.5f;
+        float T = atan2f(Yc, Xc);
+        T -= floorf(T / kPi) * kPi;
+        if (T < wrap) T += kPi;
+        const float R = sqrtf(Xc * Xc + Yc * Yc);
+        // a spoke of direction phi reaches the block's footprint only if its line passes within (W + 1/2)(|cos phi| + |sin phi|)
+        // of the block centre; phi is within asin((W + 1/2) sqrt(2) / R) =: D0 of the block's own direction, and
+        // |cos| + |sin| changes by at most sqrt(2) D0 over that range
+        const float sd0 = (p.W + 0.52f) * 1.41421356f / R;
+        const float wcs = fminf(1.41421356f, (fabsf(Xc) + fabsf(Yc)) / R + 1.5f * sd0);
+        const float sd = (p.W + 0.52f) * wcs / R;
+        const float D = sd < 0.999f ? asinf(sd) + 2e-3f : 4.0f;
+        tlo = T - D;
+        thi = T + D;
+    }
+    const float We = p.W + 1e-3f;
+    const float xlo = X0f - We, xhi = X1f + We, ylo = Y0f - We, yhi = Y1f + We;
+
+    for (int i = tid; i < p.lut_entries; i += kArcThreads) L.lut[i] = p.kb_lut[i];
+    const unsigned lut0 = lds_addr(L.lut);
+    const unsigned dbase = lds_addr(L.d);
+    constexpr unsigned kBufBytes = (unsigned)((CPB / 2) * C::NREC * 16);
+    const float lscale = p.lut_scale;
+    const float dcf_a = p.apply_dcf ? p.dcf_a : 0.0f, dcf_b = p.apply_dcf ? p.dcf_b : 1.0f;
+
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned nchan8 = (unsigned)p.nchan * 8u;
+    const unsigned lane_step = (unsigned)lane * nchan8;
+    // output: the block's two rows as byte offsets inside a coil plane (the tile lies inside the grid, its columns are even)
+    unsigned out_off[2];
+#pragma unroll
+    for (int qy = 0; qy < 2; ++qy) {
+        const int Y = Y0 + qy;
+        const int row = p.out_shift ? (Y < 0 ? Y + n : Y) : Y + h;     // both fftshifts of src/tron.cu:631 folded in
+        const int col = p.out_shift ? (X0 < 0 ? X0 + n : X0) : X0 + h;
+        out_off[qy] = (unsigned)(row * n + col) * 8u;
+    }
+
+    APROF_DECL;
+    for (int iz = 0; iz < zper; ++iz) {
+        const int z = zg * zper + iz;
+        if (z >= p.nslices) break;
+        const size_t win = (size_t)z * p.arc_slice_stride;                              // 0 when every slice has the same angles
+        const int4 hdr = p.arc_hdr[win * p.ntiles + tile];
+        const int ns = hdr.x, K = hdr.y;
+        const uint4 *ent = p.arc_ent + win * p.arc_cap + hdr.z;
+        const float *ephi = p.arc_ephi + win * p.arc_cap + hdr.z;
+        const float2 *in = reinterpret_cast<const float2 *>(p.nudata) + (size_t)z * (size_t)p.in_slice_stride + c0;
+
+        v2f acc[4][CPB];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int c = 0; c < CPB; ++c) acc[q][c] = (v2f){0.f, 0.f};
+
+        __syncthreads();                                        // the last slice's gather has ended: run table and buffers are free
+        // ---- the tile's run -> LDS ----
+        for (int i = tid; i < ns; i += kArcThreads) {
+            const uint4 e = ent[i];
+            L.s_a[i] = e.x;
+            L.s_b[i] = e.y;
+            L.s_cs[i] = make_float2(__uint_as_float(e.z), __uint_as_float(e.w));
+            L.phi[i] = ephi[i];
+        }
+        APROF_MARK(0);                                          // tile setup, run table
+        __syncthreads();
+        APROF_MARK(1);
+
+        // samples of batch b -> buffer b & 1: one LDS-DMA instruction per member and coil pair, lane = radius.  Everything but
+        // the lane's own byte offset is wave-uniform and kept in scalar registers.
+        auto issue = [&](const int b) {
+            const int nmem = (ns - b + K - 1) / K;
+            const unsigned buf = dbase + (unsigned)(b & (C::NBUF - 1)) * kBufBytes;
+            for (int m = wave_u; m < nmem; m += 4) {
+                const int i = b + K * m;
+                const unsigned a = (unsigned)__builtin_amdgcn_readfirstlane((int)L.s_a[i]);
+                const unsigned sb = (unsigned)__builtin_amdgcn_readfirstlane((int)L.s_b[i]);
+                const int len = (int)((sb >> 10) & 127u);
+                const unsigned dst = buf + (sb >> 17) * 16u;
+                const unsigned first = (a & 0x7fffffffu) * nchan8;                     // byte offset of the first record's coil 0
+                if (lane < len) {
+                    const unsigned voff = (a >> 31) ? first - lane_step : first + lane_step;
+#pragma unroll
+                    for (int c = 0; c < CPB / 2; ++c)
+                        if (2 * c < ncb) lds_dma16_s(in + 2 * c, voff, dst + (unsigned)(c * C::NREC * 16));
+                }
+            }
+        };
+#ifndef TRON_ARC_SKIP_DMA
+        if (ns > 0 && C::NBUF == 2) issue(0);
+#endif
+        APROF_MARK(2);                                          // DMA issue
+
+        // ---- this thread's run of the list (while batch 0 flies) ----
+        int jlo = 1, jhi = 0;
+        if (has_work && ns > 0) {
+            int lo = 0, cnt = ns;
+            while (cnt > 0) {
+                const int step = cnt >> 1;
+                if (L.phi[lo + step] < tlo) { lo += step + 1; cnt -= step + 1; } else cnt = step;
+            }
+            jlo = lo;
+            lo = 0; cnt = ns;
+            while (cnt > 0) {
+                const int step = cnt >> 1;
+                if (!(thi < L.phi[lo + step])) { lo += step + 1; cnt -= step + 1; } else cnt = step;
+            }
+            jhi = lo - 1;
+        }
+        APROF_MARK(3);                                          // window search
+
+        const float rcpK = 1.0f / (float)K;
+        for (int b = 0; b < K && ns > 0; ++b) {
+            if (C::NBUF == 1) {
+                if (b > 0) lds_barrier();                       // everyone has left the buffer
+                issue(b);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's pieces of batch b have landed
+            APROF_MARK(4);                                      // DMA wait
+            lds_barrier();                                      // ... everyone's have; everyone has left batch b - 1's buffer
+            APROF_MARK(5);
+#ifndef TRON_ARC_SKIP_DMA
+            if (C::NBUF == 2 && b + 1 < K) issue(b + 1);
+#endif
+            APROF_MARK(2);
+            const unsigned buf = dbase + (unsigned)(b & (C::NBUF - 1)) * kBufBytes;
+
+            // ---- gather ----
+            int mlo = 0, mhi = -1;
+            if (jhi >= jlo && jhi >= b) {
+                mlo = jlo <= b ? 0 : (int)(((float)(jlo - b + K - 1) + 0.5f) * rcpK);
+                mhi = (int)(((float)(jhi - b) + 0.5f) * rcpK);
+            }
+#ifdef TRON_ARC_SKIP_OUTER
+            mhi = -1;
+#endif
+#ifdef TRON_ARC_FLAT
+            // One flat loop over this thread's visits of the batch: a lane whose member is exhausted moves on to its next
+            // member with samples in reach while the others keep visiting (nested member / radius loops left 55 % of the
+            // lanes idle: every wave ran the longest member count times the longest radius count).  The visit itself is
+            // unconditional -- a lane with nothing left sits on a harmless state (its own point as the sample position, record
+            // 0, band bit 31 = weight 0) -- so the accumulators are updated in place by every lane in every iteration.
+            int m = mlo - 1, rem = 0, bit = 31, inc = 0;
+            float uf = 1.f, incf = 0.f, csx = X0f, csy = Y0f;
+            unsigned addr = buf;
+            auto advance = [&]() {
+                if (rem == 0 && m <= mhi) {
+                    inc = 0; incf = 0.f; bit = 31; uf = 1.f; csx = X0f; csy = Y0f; addr = buf;     // idle unless this member has samples in reach
+                    if (m < mhi) {                              // (one member per iteration: a search loop here makes the compiler keep two copies of the accumulators)
+                        ++m;
+                        { const unsigned long long bm_ = __ballot(1); if (lane == __builtin_ctzll(bm_)) { APROF_COUNT(12, 1); APROF_COUNT(13, __popcll(bm_)); } }
+                        const int i = b + K * m;
+                        const float2 cs = L.s_cs[i];
+                        const unsigned sb = L.s_b[i];
+                        const int s_ulo = (int)(sb & 1023u), s_len = (int)((sb >> 10) & 127u);
+                        const float ic = safe_rcp(cs.x), is = safe_rcp(cs.y);
+                        // the radii whose sample lies inside the block's footprint: x0 - W < u cos < x1 + W, likewise y  (src/tron.cu:514-516)
+                        const float xa = xlo * ic, xb = xhi * ic;
+                        const float ya = ylo * is, yb = yhi * is;
+                        const float lo = fmaxf(fmaxf(fminf(xa, xb), fminf(ya, yb)), fmaxf((float)s_ulo, blo_f));
+                        const float hi = fminf(fminf(fmaxf(xa, xb), fmaxf(ya, yb)), fminf((float)(s_ulo + s_len - 1), bhi_f));
+                        const int ua = (int)ceilf(lo), ub = (int)floorf(hi);
+                        if (ua <= ub) {
+                            rem = ub - ua + 1;
+                            uf = (float)ua;
+                            bit = ua - bandlo;
+                            inc = 1; incf = 1.f;
+                            csx = cs.x; csy = cs.y;
+                            addr = buf + (unsigned)(((int)(sb >> 17) - s_ulo + ua) * 16);
+                        }
+                    } else {
+                        m = mhi + 1;                            // nothing left: this lane stays idle
+                    }
+                }
+            };
+            advance();
+            if (__ballot(rem != 0 || m <= mhi) != 0ull) do {   // (wave-uniform and bottom-tested: a top-tested loop copies every accumulator every iteration)
+#ifdef TRON_ARC_SKIP_INNER
+                acc[0][0].x += uf; rem = 0;
+                if (false) {
+#else
+                {
+                { const unsigned long long bm_ = __ballot(rem != 0); if (lane == __builtin_ctzll(bm_)) { APROF_COUNT(14, 1); APROF_COUNT(15, __popcll(bm_)); } }
+                const float kx = uf * csx, ky = uf * csy;                                     // src/tron.cu:514-515
+                // four table lookups and the samples, all asked for before the first is used (one LDS round trip per visit)
+                const float t0 = fabsf(kx - X0f) * lscale, t1 = fabsf(kx - X1f) * lscale;
+                const float t2 = fabsf(ky - Y0f) * lscale, t3 = fabsf(ky - Y1f) * lscale;
+                const v4f e0 = *(lds_f4p)(size_t)(lut0 + (unsigned)t0 * 16u), e1 = *(lds_f4p)(size_t)(lut0 + (unsigned)t1 * 16u);
+                const v4f e2 = *(lds_f4p)(size_t)(lut0 + (unsigned)t2 * 16u), e3 = *(lds_f4p)(size_t)(lut0 + (unsigned)t3 * 16u);
+                v4f dd[CPB / 2];
+#pragma unroll
+                for (int c = 0; c < CPB / 2; ++c) dd[c] = *(lds_f4p)(size_t)(addr + (unsigned)(c * C::NREC * 16));
+                const float sdc = fmaf(dcf_a, uf, dcf_b);                                     // src/tron.cu:412 (|ro - nro/2| = u)
+                const float f0 = __builtin_amdgcn_fractf(t0), f1 = __builtin_amdgcn_fractf(t1);
+                const float f2 = __builtin_amdgcn_fractf(t2), f3 = __builtin_amdgcn_fractf(t3);
+                const float wx0 = fmaf(f0, fmaf(f0, e0.z, e0.y), e0.x), wx1 = fmaf(f1, fmaf(f1, e1.z, e1.y), e1.x);
+                const float wy0 = fmaf(f2, fmaf(f2, e2.z, e2.y), e2.x) * sdc, wy1 = fmaf(f3, fmaf(f3, e3.z, e3.y), e3.x) * sdc;
+                float wq[4];
+                wq[0] = wx0 * wy0; wq[1] = wx1 * wy0; wq[2] = wx0 * wy1; wq[3] = wx1 * wy1;       // src/tron.cu:516
+#pragma unroll
+                for (int q = 0; q < 4; ++q)                                                        // src/tron.cu:512,521: bit u - bandlo of the point's band mask
+                    wq[q] = __uint_as_float(__float_as_uint(wq[q]) & (unsigned)__builtin_amdgcn_sbfe((int)bmask[q], bit, 1));
+#pragma unroll
+                for (int c = 0; c < CPB / 2; ++c) {
+                    const v4f d = dd[c];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        acc[q][2 * c].x = fmaf(d.x, wq[q], acc[q][2 * c].x);                      // src/tron.cu:519
+                        acc[q][2 * c].y = fmaf(d.y, wq[q], acc[q][2 * c].y);
+                        acc[q][2 * c + 1].x = fmaf(d.z, wq[q], acc[q][2 * c + 1].x);
+                        acc[q][2 * c + 1].y = fmaf(d.w, wq[q], acc[q][2 * c + 1].y);
+                    }
+                }
+                uf += incf;
+                addr += (unsigned)inc << 4;
+                bit += inc;
+                rem -= inc;
+                }
+#endif
+                advance();
+            } while (__ballot(rem != 0 || m <= mhi) != 0ull);
+#else
+            // member loop / radius loop (a flat loop over the visits, in which a lane moves on to its next member while the
+            // others keep visiting, was measured too -- TRON_ARC_FLAT: 27 % fewer wave iterations, but some lane needs a new
+            // member in 78 % of them and the iteration grows from 87 to 160 instructions: slower)
+            for (int m = mlo; m <= mhi; ++m) {
+                { const unsigned long long bm_ = __ballot(1); if (lane == __builtin_ctzll(bm_)) { APROF_COUNT(12, 1); APROF_COUNT(13, __popcll(bm_)); } }
+                const int i = b + K * m;
+                const float2 cs = L.s_cs[i];
+                const unsigned sb = L.s_b[i];
+                const int s_ulo = (int)(sb & 1023u), s_len = (int)((sb >> 10) & 127u);
+                const float ic = safe_rcp(cs.x), is = safe_rcp(cs.y);
+                // the radii whose sample lies inside the block's footprint: x0 - W < u cos < x1 + W, likewise y  (src/tron.cu:514-516)
+                const float xa = xlo * ic, xb = xhi * ic;
+                const float ya = ylo * is, yb = yhi * is;
+                const float lo = fmaxf(fmaxf(fminf(xa, xb), fminf(ya, yb)), fmaxf((float)s_ulo, blo_f));
+                const float hi = fminf(fminf(fmaxf(xa, xb), fmaxf(ya, yb)), fminf((float)(s_ulo + s_len - 1), bhi_f));
+                const int ua = (int)ceilf(lo), ub = (int)floorf(hi);
+                if (ua > ub) continue;
+#ifdef TRON_ARC_SKIP_INNER
+                acc[0][0].x += (float)ua; continue;
+#endif
+                unsigned addr = buf + (unsigned)(((int)(sb >> 17) - s_ulo + ua) * 16);
+                float uf = (float)ua;
+                int bit = ua - bandlo;
+                for (int u = ua; u <= ub; ++u) {
+                    { const unsigned long long bm_ = __ballot(1); if (lane == __builtin_ctzll(bm_)) { APROF_COUNT(14, 1); APROF_COUNT(15, __popcll(bm_)); } }
+                    const float kx = uf * cs.x, ky = uf * cs.y;                               // src/tron.cu:514-515
+                    // four table lookups and the samples, all asked for before the first is used (one LDS round trip per visit)
+                    const float t0 = fabsf(kx - X0f) * lscale, t1 = fabsf(kx - X1f) * lscale;
+                    const float t2 = fabsf(ky - Y0f) * lscale, t3 = fabsf(ky - Y1f) * lscale;
+                    const v4f e0 = *(lds_f4p)(size_t)(lut0 + (unsigned)t0 * 16u), e1 = *(lds_f4p)(size_t)(lut0 + (unsigned)t1 * 16u);
+                    const v4f e2 = *(lds_f4p)(size_t)(lut0 + (unsigned)t2 * 16u), e3 = *(lds_f4p)(size_t)(lut0 + (unsigned)t3 * 16u);
+                    v4f dd[CPB / 2];
+#pragma unroll
+                    for (int c = 0; c < CPB / 2; ++c) dd[c] = *(lds_f4p)(size_t)(addr + (unsigned)(c * C::NREC * 16));
+                    const float sdc = fmaf(dcf_a, uf, dcf_b);                                 // src/tron.cu:412 (|ro - nro/2| = u)
+                    const float f0 = __builtin_amdgcn_fractf(t0), f1 = __builtin_amdgcn_fractf(t1);
+                    const float f2 = __builtin_amdgcn_fractf(t2), f3 = __builtin_amdgcn_fractf(t3);
+                    const float wx0 = fmaf(f0, fmaf(f0, e0.z, e0.y), e0.x), wx1 = fmaf(f1, fmaf(f1, e1.z, e1.y), e1.x);
+                    const float wy0 = fmaf(f2, fmaf(f2, e2.z, e2.y), e2.x) * sdc, wy1 = fmaf(f3, fmaf(f3, e3.z, e3.y), e3.x) * sdc;
+                    float wq[4];
+                    wq[0] = wx0 * wy0; wq[1] = wx1 * wy0; wq[2] = wx0 * wy1; wq[3] = wx1 * wy1;   // src/tron.cu:516
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)                                                    // src/tron.cu:512,521: bit u - bandlo of the point's band mask
+                        wq[q] = __uint_as_float(__float_as_uint(wq[q]) & (unsigned)__builtin_amdgcn_sbfe((int)bmask[q], bit, 1));
+#pragma unroll
+                    for (int c = 0; c < CPB / 2; ++c) {
+                        const v4f d = dd[c];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            acc[q][2 * c].x = fmaf(d.x, wq[q], acc[q][2 * c].x);                  // src/tron.cu:519
+                            acc[q][2 * c].y = fmaf(d.y, wq[q], acc[q][2 * c].y);
+                            acc[q][2 * c + 1].x = fmaf(d.z, wq[q], acc[q][2 * c + 1].x);
+                            acc[q][2 * c + 1].y = fmaf(d.w, wq[q], acc[q][2 * c + 1].y);
+                        }
+                    }
+                    uf += 1.0f;
+                    addr += 16u;
+                    ++bit;
+                }
+            }
+#endif
+            APROF_MARK(6);                                      // gather
+        }
+
+        {
+            unsigned char *zbase = reinterpret_cast<unsigned char *>(p.udata + (size_t)z * p.out_z + (size_t)c0 * p.out_c);
+#pragma unroll
+            for (int c = 0; c < CPB; ++c)
+                if (c < ncb) {
+#pragma unroll
+                    for (int qy = 0; qy < 2; ++qy) {
+                        float4 v;
+                        v.x = acc[2 * qy][c].x * p.scale;                   // src/tron.cu:532-534
+                        v.y = acc[2 * qy][c].y * p.scale;
+                        v.z = acc[2 * qy + 1][c].x * p.scale;
+                        v.w = acc[2 * qy + 1][c].y * p.scale;
+                        *reinterpret_cast<float4 *>(zbase + (size_t)c * p.out_c * 8 + out_off[qy]) = v;
+                    }
+                }
+        }
+        APROF_MARK(7);                                          // output store
+    }
+    APROF_FLUSH;
+}
+
+#ifdef TRON_ARC_PROFILE
+extern "C" int tron_debug_arc_profile(unsigned long long *out, int n)   // reads and clears the phase clock
+{
+    static unsigned long long h[kArcProfCopies * kArcProfSlots];
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(h, HIP_SYMBOL(g_arc_prof), sizeof(h)) != hipSuccess) return 1;
+    for (int i = 0; i < n && i < kArcProfSlots; ++i) {
+        out[i] = 0;
+        for (int c = 0; c < kArcProfCopies; ++c) out[i] += h[c * kArcProfSlots + i];
+    }
+    for (size_t i = 0; i < sizeof(h) / sizeof(h[0]); ++i) h[i] = 0;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_arc_prof), h, sizeof(h)) != hipSuccess;
+}
+#endif
+
+template <int CPB>
+static hipError_t launch_arc_cpb(const GridParams &p, int first_plain, hipStream_t s)
+{
+    if (p.arc_nrec != ArcCfg<CPB>::NREC) return hipErrorInvalidValue;       // the run tables were dealt for another batch size
+    const int tpr = (p.nxos + kArcTile - 1) / kArcTile;
+    GridParams q = p;
+    q.tiles_per_row = tpr;
+    q.ntiles = tpr * tpr;
+    q.tile_order = p.tile_order + first_plain;
+    q.arc_zper = p.arc_zper > 0 ? p.arc_zper : 1;
+    const int ngroups = (p.nslices + q.arc_zper - 1) / q.arc_zper;
+    const int chunks = (p.nchan - p.coil0 + CPB - 1) / CPB;
+    dim3 grid((unsigned)((size_t)q.ntiles * ngroups), (unsigned)chunks);
+    const size_t lds = sizeof(ArcLds<CPB>);
+    if (lds > 64 * 1024) {
+        static hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(grid_arc_kernel<CPB>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ArcLds<CPB>));
+        if (once != hipSuccess) return once;
+    }
+    hipLaunchKernelGGL((grid_arc_kernel<CPB>), grid, dim3(kArcThreads), lds, s, q);
+    return hipGetLastError();
+}
+
+bool grid_arc_supported(int nchan, int nxos, int nro, int npe, float W)
+{
+    return nchan >= 2 && (nchan & 1) == 0 && nro == nxos && nxos <= 2048 && npe <= kArcMaxNpe && W <= 3.0f
+           && (nxos / 2) % kArcTile == 0 && nxos >= 4 * kArcTile && (long long)nro * npe * nchan < (1ll << 31);
+}
+
+// p.tile_order[first_plain ...] must list the 32x32 tiles (see build_tile_order(nxos, 32, ...)); p.inner_r0 > 0.
+hipError_t launch_grid_arc(const GridParams &p, int first_plain, hipStream_t s)
+{
+    if (p.out_p != 1 || p.inner_r0 <= 0 || !p.arc_hdr || !p.arc_ent || !p.arc_ephi || !p.kb_lut || p.lut_entries > kArcLutEntries || (p.coil0 & 1)
+        || !grid_arc_supported(p.nchan, p.nxos, p.nro, p.npe, p.W) || (reinterpret_cast<uintptr_t>(p.nudata) & 15) != 0)
+        return hipErrorInvalidValue;
+    const int nc = p.nchan - p.coil0;
+    if (nc >= 5) {
+        const int pad8 = (nc + 7) / 8 * 8, pad6 = (nc + 5) / 6 * 6;
+        return pad6 < pad8 ? launch_arc_cpb<6>(p, first_plain, s) : launch_arc_cpb<8>(p, first_plain, s);
+    }
+    if (nc >= 3) return launch_arc_cpb<4>(p, first_plain, s);
+    return launch_arc_cpb<2>(p, first_plain, s);
+}
+
+__global__ void warm_grid_arc_tu() {}
+
+hipError_t warm_grid_arc()   // see warm_kernels() in tron_kernels.hip
+{
+    hipLaunchKernelGGL(warm_grid_arc_tu, dim3(1), dim3(64), 0, nullptr);
+    return hipGetLastError();
+}
+
+}  // namespace tron

@@ -26,6 +26,11 @@ void build_split_tile_order(int nxos, int tile, int npe, float W, int target, in
                             std::vector<int> &order, std::vector<int> &slots);
 bool build_centre_relief_order(int nxos, int tile, int npe, float W, int max_parts, int &inner_r0, std::vector<int> &order, std::vector<int> &slots);
 float kb_beta(float kernwidth);
+// arc gridding kernel: Kaiser-Bessel table, 128 quadratic pieces over [0, W) (c0, c1, c2, 0 per entry), zero beyond; returns the
+// largest error relative to the peak
+double build_kb_lut(float kernwidth, int entries, float *coef4, float *scale);
+// arc gridding kernel: per window of npe spokes (cos_sin + 2 * stride * z), the spokes in ascending line angle (mod pi)
+void build_arc_tables(const float *cos_sin, size_t nwindows, size_t stride, int npe, unsigned short *order, float *phi);
 double kb_poly_fit(float kernwidth, float *poly, int nterms);
 void dcf_constants(int nro, int npe1work, float *a, float *b);
 float grid_scale(int nxos, int npe);

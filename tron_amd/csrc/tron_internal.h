@@ -45,6 +45,17 @@ struct GridParams {
     int inner_r0;            // binned kernel, centre relief (0: off): samples |r| < inner_r0 are gridded by the origin-centred inner tile
                              // (entry tile id == ntiles, dealt over spoke ranges; slot 0 of split_slots), the four centre tiles take |r| >= inner_r0
     int lds_pad;             // binned kernel: request at least this much LDS per workgroup (0: what it needs); leaves CU room for a second lane
+    int no_reduce;           // binned kernel: do not launch grid_reduce_parts_kernel (the caller does, after the arc kernel has stored the centre tiles)
+    // arc kernel (tron_grid_arc.hip): per (window, tile) the run of crossing spokes, dealt into batches at plan time
+    const int4 *arc_hdr;               // [window][tile] -> run length, batches, first entry, records
+    const uint4 *arc_ent;              // [window][arc_cap] -> first sample index | down << 31, ulo | len << 10 | offset << 17, cos, sin
+    const float *arc_ephi;             // [window][arc_cap] -> unwrapped line angle
+    int arc_cap, arc_nrec;             // entries per window; records per batch the runs were dealt for
+    int arc_slice_stride;              // windows between consecutive slices: 1 (golden angle) or 0 (every slice has the same angles)
+    const float4 *kb_lut;              // Kaiser-Bessel window on [i, i + 1) / lut_scale as c0 + f (c1 + f c2); zero from |x| = W on
+    int lut_entries;
+    float lut_scale;
+    int arc_zper;                      // consecutive slices one workgroup grids in turn (the table stays in LDS)
 };
 
 struct PostParams {           // crop + deapodise + (optional) root-sum-of-squares, adjoint tail
@@ -83,6 +94,29 @@ hipError_t launch_grid(const GridParams &p, int kb_mode, int half_in, hipStream_
 // TRON_KB_FAST only; p.tile_order must list 32x32 tiles (tron_grid_binned.hip)
 hipError_t launch_grid_binned(const GridParams &p, int half_in, hipStream_t s);
 constexpr int kBinnedTile = 32;
+// TRON_KB_FAST, fp32 input, even coil counts, centre relief active (tron_grid_arc.hip): the plain tiles of p.tile_order
+// (entries [first_plain, first_plain + ntiles)) are gridded by the arc kernel; the caller launches the inner tile's parts
+// (binned kernel, no_reduce) before and launch_grid_reduce after it
+hipError_t launch_grid_arc(const GridParams &p, int first_plain, hipStream_t s);
+hipError_t launch_grid_reduce(const GridParams &p, hipStream_t s);
+bool grid_arc_supported(int nchan, int nxos, int nro, int npe, float W);
+int grid_arc_nrec(int nchan);
+constexpr int kArcLutEntries = 272;    // Kaiser-Bessel table entries held in LDS (128 intervals per W, up to |x| = W + 1.05, W >= 1)
+// plan-time pass of the arc kernel: clips every window's angle-sorted spokes against every tile and deals the runs into batches
+struct ArcPrepParams {
+    const unsigned short *order;       // [window][npe] window-relative spoke index, ascending line angle (mod pi)
+    const float *phi;                  // [window][npe] that line angle in [0, pi)
+    const float2 *cs;                  // [window][npe] (cos, sin) of that spoke
+    int4 *hdr;                         // out, see GridParams::arc_hdr
+    uint4 *ent;
+    float *ephi;
+    int *alloc;                        // [window] entries handed out so far (zeroed by the caller)
+    unsigned int *errflag;
+    int nxos, nro, npe, ntiles, inner_r0, nrec, cap;
+    float W;
+};
+hipError_t launch_arc_prep(const ArcPrepParams &p, int nwindows, hipStream_t s);
+hipError_t warm_grid_arc();
 hipError_t launch_post(const PostParams &p, hipStream_t s);
 hipError_t launch_pre(const PreParams &p, hipStream_t s);
 hipError_t launch_precompensate(float2 *nudata, int nchan, int nro, int npe, float a, float b, hipStream_t s);

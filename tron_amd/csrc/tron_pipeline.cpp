@@ -221,7 +221,37 @@ int adjoint_run_raw(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, 
                     g.split_slots = p->d_split_slots;
                     g.partial = p->d_partial;
                 }
-                HIP_TRY(launch_grid_binned(g, p->cfg.input_half, st));
+                if (p->arc && p->relief_entries > 0 && vs <= 1 && (reinterpret_cast<uintptr_t>(g.nudata) & 15) == 0) {
+                    // the inner tile's parts (binned kernel), every other tile (arc kernel), then the parts are added on
+                    GridParams gi = g;
+                    gi.tile_entries = p->relief_parts;
+                    gi.no_reduce = 1;
+                    if (p->inner_beside) {
+                        HIP_TRY(hipEventRecord(p->ev_inner[0], st));             // (the reduce pass that last read the parts buffer is behind this)
+                        HIP_TRY(hipStreamWaitEvent(p->stream_inner, p->ev_inner[0], 0));
+                        HIP_TRY(launch_grid_binned(gi, 0, p->stream_inner));
+                        HIP_TRY(hipEventRecord(p->ev_inner[1], p->stream_inner));
+                    } else {
+                        HIP_TRY(launch_grid_binned(gi, 0, st));
+                    }
+                    const size_t win0 = golden ? (size_t)(zfirst + z0) : 0;
+                    g.arc_hdr = p->d_arc_hdr + win0 * (size_t)(d.nxos / kBinnedTile) * (d.nxos / kBinnedTile);
+                    g.arc_ent = p->d_arc_ent + win0 * p->arc_cap;
+                    g.arc_ephi = p->d_arc_ephi + win0 * p->arc_cap;
+                    g.arc_cap = p->arc_cap;
+                    g.arc_nrec = p->arc_nrec;
+                    g.arc_slice_stride = golden ? 1 : 0;
+                    g.kb_lut = p->d_kb_lut;
+                    g.lut_entries = kArcLutEntries;
+                    g.lut_scale = p->lut_scale;
+                    // slices one workgroup grids in turn (tile geometry and the window table are set up once per workgroup)
+                    g.arc_zper = p->arc_zper > 0 ? p->arc_zper : (cz >= 64 ? 4 : (cz >= 32 ? 2 : 1));
+                    HIP_TRY(launch_grid_arc(g, p->relief_parts, st));
+                    if (p->inner_beside) HIP_TRY(hipStreamWaitEvent(st, p->ev_inner[1], 0));
+                    HIP_TRY(launch_grid_reduce(g, st));
+                } else {
+                    HIP_TRY(launch_grid_binned(g, p->cfg.input_half, st));
+                }
             } else {
                 HIP_TRY(launch_grid(g, p->kb_mode, p->cfg.input_half, st));
             }

@@ -71,6 +71,7 @@ extern "C" int tron_plan_create(tron_plan **out, const tron_config *cfg, const t
     // make every code object resident before anything is queued on a non-blocking stream
     HIP_TRY(warm_kernels());
     HIP_TRY(warm_grid_binned());
+    HIP_TRY(warm_grid_arc());
     HIP_TRY(warm_fft512());
     HIP_TRY(warm_degrid_tile());
     HIP_TRY(warm_cgnr());
@@ -153,6 +154,80 @@ extern "C" int tron_plan_create(tron_plan **out, const tron_config *cfg, const t
                 if ((rc = upload(&p->d_tile_order32_relief, rorder.data(), rorder.size() * sizeof(int)))) return bail(rc);
                 if ((rc = upload(&p->d_relief_slots, rslots.data(), rslots.size() * sizeof(int)))) return bail(rc);
             }
+            // arc kernel: everything but the inner tile, when the trajectory and the sample layout allow it
+            p->arc = p->relief_entries > 0 && !cfg->input_half && grid_arc_supported(p->nchan, d.nxos, d.nro, d.npe1work, cfg->kernwidth);
+            if (const char *gk = getenv("TRON_GRID_KERNEL")) p->arc = p->arc && strcmp(gk, "binned") != 0;
+            if (p->arc) {
+                // plan-time pass: every window's spokes sorted by line angle (host), clipped against every tile and dealt
+                // into batches (arc_prep_kernel); the sorted lists are scratch
+                const size_t nwin = cfg->golden_angle ? (size_t)std::max(d.nz, 1) : 1;
+                const int npe = d.npe1work, nt32 = (d.nxos / kBinnedTile) * (d.nxos / kBinnedTile);
+                std::vector<float> trig(2 * p->ntrig);
+                build_trig_table(*cfg, d, trig.data(), p->ntrig);
+                std::vector<unsigned short> order(nwin * npe);
+                std::vector<float> phi(nwin * npe);
+                build_arc_tables(trig.data(), nwin, (size_t)d.prof_slide, npe, order.data(), phi.data());
+                std::vector<float> scs(2 * order.size());
+                for (size_t w = 0; w < nwin; ++w)
+                    for (int k = 0; k < npe; ++k) {
+                        const size_t src = (cfg->golden_angle ? w * (size_t)d.prof_slide : 0) + order[w * npe + k];
+                        scs[2 * (w * npe + k)] = trig[2 * src];
+                        scs[2 * (w * npe + k) + 1] = trig[2 * src + 1];
+                    }
+                unsigned short *d_order = nullptr;
+                float *d_phi = nullptr, *d_scs = nullptr;
+                int *d_alloc = nullptr;
+                auto drop = [&]() { hipFree(d_order); hipFree(d_phi); hipFree(d_scs); hipFree(d_alloc); };
+                // a spoke crosses at most 2 * nxos / 32 + 3 tiles (+ their halos): 56 run entries per spoke bound every window
+                p->arc_cap = npe * (2 * (d.nxos / kBinnedTile) + 24);
+                p->arc_nrec = grid_arc_nrec(p->nchan);
+                rc = upload(&d_order, order.data(), order.size() * sizeof(unsigned short));
+                if (!rc) rc = upload(&d_phi, phi.data(), phi.size() * sizeof(float));
+                if (!rc) rc = upload(&d_scs, scs.data(), scs.size() * sizeof(float));
+                if (!rc && hipMalloc(reinterpret_cast<void **>(&d_alloc), nwin * sizeof(int)) != hipSuccess) rc = fail(TRON_ERR_NOMEM, "arc tables");
+                if (!rc && (hipMalloc(reinterpret_cast<void **>(&p->d_arc_hdr), nwin * nt32 * sizeof(int4)) != hipSuccess ||
+                            hipMalloc(reinterpret_cast<void **>(&p->d_arc_ent), nwin * p->arc_cap * sizeof(uint4)) != hipSuccess ||
+                            hipMalloc(reinterpret_cast<void **>(&p->d_arc_ephi), nwin * p->arc_cap * sizeof(float)) != hipSuccess))
+                    rc = fail(TRON_ERR_NOMEM, "cannot allocate the arc kernel's run tables");
+                if (rc) { drop(); return bail(rc); }
+                unsigned int zero = 0;
+                if ((rc = upload(&p->d_errflag, &zero, sizeof(zero)))) { drop(); return bail(rc); }
+                hipMemset(d_alloc, 0, nwin * sizeof(int));
+                ArcPrepParams ap;
+                ap.order = d_order; ap.phi = d_phi; ap.cs = reinterpret_cast<const float2 *>(d_scs);
+                ap.hdr = p->d_arc_hdr; ap.ent = p->d_arc_ent; ap.ephi = p->d_arc_ephi; ap.alloc = d_alloc; ap.errflag = p->d_errflag;
+                ap.nxos = d.nxos; ap.nro = d.nro; ap.npe = npe; ap.ntiles = nt32; ap.inner_r0 = p->relief_r0; ap.nrec = p->arc_nrec;
+                ap.cap = p->arc_cap; ap.W = cfg->kernwidth;
+                hipError_t he = launch_arc_prep(ap, (int)nwin, p->stream);
+                if (he == hipSuccess) he = hipStreamSynchronize(p->stream);
+                unsigned int flag = 0;
+                if (he == hipSuccess) he = hipMemcpy(&flag, p->d_errflag, sizeof(flag), hipMemcpyDeviceToHost);
+                drop();
+                if (he != hipSuccess) return bail(fail(TRON_ERR_HIP, "arc_prep_kernel failed: %s", hipGetErrorString(he)));
+                if (flag) {   // a trajectory the arc kernel's tables cannot hold: the binned kernel takes all tiles
+                    hipMemset(p->d_errflag, 0, sizeof(flag));
+                    hipFree(p->d_arc_hdr); hipFree(p->d_arc_ent); hipFree(p->d_arc_ephi);
+                    p->d_arc_hdr = nullptr; p->d_arc_ent = nullptr; p->d_arc_ephi = nullptr;
+                    p->arc = false;
+                    if (cfg->verbose) printf("tronhip: arc tables overflowed (flag %u): binned gridding kernel\n", flag);
+                }
+            }
+            if (p->arc) {
+                std::vector<float> lut(4 * (size_t)kArcLutEntries);
+                p->lut_err = build_kb_lut(cfg->kernwidth, kArcLutEntries, lut.data(), &p->lut_scale);
+                if ((rc = upload(&p->d_kb_lut, lut.data(), lut.size() * sizeof(float)))) return bail(rc);
+                p->arc_zper = 0;                                    // 0: by launch size (tron_pipeline.cpp)
+                // the inner tile's workgroups are few and slow (every spoke passes the k-space centre): on a stream of their own,
+                // most urgent, they run beside the arc kernel instead of in front of it
+                if (const char *e = getenv("TRON_ARC_INNER_STREAM")) p->inner_beside = atoi(e) != 0;
+                int lo = 0, hi = 0;
+                hipDeviceGetStreamPriorityRange(&lo, &hi);
+                if (hipStreamCreateWithPriority(&p->stream_inner, hipStreamNonBlocking, hi) != hipSuccess ||
+                    hipEventCreateWithFlags(&p->ev_inner[0], hipEventDisableTiming) != hipSuccess ||
+                    hipEventCreateWithFlags(&p->ev_inner[1], hipEventDisableTiming) != hipSuccess)
+                    return bail(fail(TRON_ERR_HIP, "cannot create the inner-tile stream"));
+                if (const char *e = getenv("TRON_ARC_ZPER")) p->arc_zper = std::max(0, atoi(e));
+            }
         }
         std::vector<float> dea((size_t)d.nx * d.nx);
         build_deapod_table(d.nx, cfg->kernwidth, cfg->gridos, dea.data());        // src/tron.cu:635
@@ -178,7 +253,7 @@ extern "C" int tron_plan_create(tron_plan **out, const tron_config *cfg, const t
         if ((rc = upload(&p->d_deapod, dea.data(), dea.size() * sizeof(float)))) return bail(rc);
     }
     unsigned int zero = 0;
-    if ((rc = upload(&p->d_errflag, &zero, sizeof(zero)))) return bail(rc);
+    if (!p->d_errflag && (rc = upload(&p->d_errflag, &zero, sizeof(zero)))) return bail(rc);
     p->poison = getenv("TRON_POISON_GRID") != nullptr;   // tests: NaN-fill the work grid so a read of a never-written point shows up
     if (d.nxos == 512 && d.nx == 256 && d.nyos == 512 && d.ny == 256) {
         p->fft512 = true;
@@ -278,6 +353,10 @@ extern "C" int tron_plan_destroy(tron_plan *p)
     hipFree(p->d_trig_fwd);
     hipFree(p->d_cg_r); hipFree(p->d_cg_v); hipFree(p->d_cg_zt); hipFree(p->d_cg_pt); hipFree(p->d_cg_x);
     hipFree(p->d_cg_partial); hipFree(p->d_cg_num); hipFree(p->d_cg_coef);
+    hipFree(p->d_arc_hdr);
+    hipFree(p->d_arc_ent);
+    hipFree(p->d_arc_ephi);
+    hipFree(p->d_kb_lut);
     hipFree(p->d_tile_order32_split);
     hipFree(p->d_split_slots);
     hipFree(p->d_partial);
@@ -301,6 +380,9 @@ extern "C" int tron_plan_destroy(tron_plan *p)
     if (p->stream_up) hipStreamDestroy(p->stream_up);
     if (p->stream_down) hipStreamDestroy(p->stream_down);
     if (p->stream2) hipStreamDestroy(p->stream2);
+    if (p->stream_inner) { hipStreamSynchronize(p->stream_inner); hipStreamDestroy(p->stream_inner); }
+    for (int i = 0; i < 2; ++i)
+        if (p->ev_inner[i]) hipEventDestroy(p->ev_inner[i]);
     if (p->stream) hipStreamDestroy(p->stream);
     delete p;
     return TRON_OK;

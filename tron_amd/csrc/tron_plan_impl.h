@@ -78,6 +78,18 @@ struct tron_plan {
     float2 *d_relief_partial = nullptr;
     size_t relief_slices = 0;
     size_t partial_slices = 0;
+    // arc gridding kernel (tron_grid_arc.hip): per (window, tile) run tables built at plan creation, Kaiser-Bessel table
+    bool arc = false;
+    int4 *d_arc_hdr = nullptr;
+    uint4 *d_arc_ent = nullptr;
+    float *d_arc_ephi = nullptr;
+    float4 *d_kb_lut = nullptr;
+    int arc_cap = 0, arc_nrec = 0, arc_zper = 1;
+    float lut_scale = 0;
+    double lut_err = 0;
+    hipStream_t stream_inner = nullptr;   // the inner tile's parts (binned kernel) run beside the arc kernel
+    hipEvent_t ev_inner[2] = {nullptr, nullptr};
+    bool inner_beside = true;             // TRON_ARC_INNER_STREAM=0 (A/B): the inner tile's launch in front of the arc kernel, same stream
     float *d_deapod = nullptr;
     unsigned int *d_errflag = nullptr;
     int ntiles = 0, tiles_per_row = 0;
