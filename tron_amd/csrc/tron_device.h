@@ -137,6 +137,14 @@ __device__ __forceinline__ void lds_dma16_s(const void *sbase, unsigned voff, un
                  : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
 
+// 4 bytes per lane (lane l's bytes land at lds_dst + 4 l): one coil's real or imaginary parts
+__device__ __forceinline__ void lds_dma4_s(const void *sbase, unsigned voff, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+
 __device__ __forceinline__ float safe_rcp(float c)
 {
     return fabsf(c) > 1e-12f ? 1.0f / c : copysignf(1e12f, c);

@@ -38,7 +38,7 @@ namespace tron {
 
 constexpr int kArcTile = 32;
 constexpr int kArcThreads = 256;
-constexpr int kArcMaxNpe = 768;        // spokes per window (prep: thread = spoke, three per thread)
+constexpr int kArcMaxNpe = 1024;       // spokes per window (prep: thread = spoke, four per thread)
 constexpr int kArcMaxSpokes = 512;     // spokes of one tile's run
 constexpr int kArcMaxBatches = 96;
 constexpr int kArcSeg = 64;            // longest spoke segment through tile + halo: (32 + 2 * 3) sqrt(2) = 54
@@ -53,7 +53,7 @@ struct ArcCfg {
 #ifdef TRON_ARC_NREC
     static constexpr int NREC = TRON_ARC_NREC;
 #else
-    static constexpr int NREC = CPB >= 8 ? 608 : (CPB >= 6 ? 800 : (CPB >= 4 ? 800 : 1600));
+    static constexpr int NREC = CPB >= 8 ? 608 : (CPB >= 6 ? 800 : (CPB >= 4 ? 800 : (CPB >= 2 ? 1600 : 3072)));
 #endif
     static constexpr int WAVES = CPB >= 6 ? 3 : 4;
 #ifdef TRON_ARC_DOUBLE_BUFFER
@@ -63,6 +63,10 @@ struct ArcCfg {
 #endif
 };
 
+// samples in LDS: [coil pair][record] float4 for even coil counts, [re | im][record] float for one coil
+template <int CPB>
+constexpr int arc_rec_bytes() { return CPB * 8; }
+
 template <int CPB>
 struct ArcLds {
     float4 lut[kArcLutEntries];            // Kaiser-Bessel window on [i, i + 1) / scale: c0 + f (c1 + f c2)
@@ -70,16 +74,17 @@ struct ArcLds {
     unsigned s_b[kArcMaxSpokes];           //            ulo | len << 10 | record offset inside its batch << 17
     float2 s_cs[kArcMaxSpokes];            //            (cos, sin) of the (flipped) direction
     float phi[kArcMaxSpokes];              //            line angle, unwrapped
-    float4 d[ArcCfg<CPB>::NBUF * (CPB / 2) * ArcCfg<CPB>::NREC];   // samples [buffer][coil pair][record]
+    float4 d[ArcCfg<CPB>::NBUF * ArcCfg<CPB>::NREC * CPB / 2];   // samples [buffer][coil pair][record] (one coil: [buffer][re | im][record] floats)
 };
 
-int grid_arc_nrec(int nchan)               // records per batch for a plan of nchan channels (must match launch_grid_arc's choice of CPB)
+int grid_arc_nrec(int nchan, int half_in)  // records per batch for a plan of nchan channels (must match launch_grid_arc's choice of CPB)
 {
+    if (half_in) return nchan >= 5 ? ArcCfg<8>::NREC : ArcCfg<4>::NREC;
     if (nchan >= 5) {
         const int pad8 = (nchan + 7) / 8 * 8, pad6 = (nchan + 5) / 6 * 6;
         return pad6 < pad8 ? ArcCfg<6>::NREC : ArcCfg<8>::NREC;
     }
-    return nchan >= 3 ? ArcCfg<4>::NREC : ArcCfg<2>::NREC;
+    return nchan >= 3 ? ArcCfg<4>::NREC : (nchan >= 2 ? ArcCfg<2>::NREC : ArcCfg<1>::NREC);
 }
 
 // Phase clock of tools/arcprof.py (-DTRON_ARC_PROFILE builds only): shader-clock cycles per wave and phase plus loop
@@ -99,6 +104,7 @@ __device__ unsigned long long g_arc_prof[kArcProfCopies * kArcProfSlots];
 #endif
 
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(3))) v4f *lds_f4p;
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -335,12 +341,16 @@ hipError_t launch_arc_prep(const ArcPrepParams &p, int nwindows, hipStream_t s)
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
-template <int CPB>
+// HALF: k-space stored as complex-half.  The copy brings the halves into the upper half of each record's fp32 slots (four
+// coils per 16 bytes) and one pass over the records converts them in place -- each thread reads all of a record's halves,
+// then writes its floats, so no record is touched by two threads -- and the gather is the fp32 one.
+template <int CPB, bool HALF>
 __global__ void __launch_bounds__(kArcThreads, ArcCfg<CPB>::WAVES)
 grid_arc_kernel(const GridParams p)
 {
     using C = ArcCfg<CPB>;
-    static_assert(CPB % 2 == 0, "the samples are copied as 16-byte coil pairs");
+    static_assert(CPB == 1 || CPB % 2 == 0, "the samples are copied as 16-byte coil pairs (or one coil as two 4-byte planes)");
+    static_assert(!HALF || CPB % 4 == 0, "complex-half samples are copied four coils at a time");
     extern __shared__ __align__(16) unsigned char lds_raw[];
     ArcLds<CPB> &L = *reinterpret_cast<ArcLds<CPB> *>(lds_raw);
 
@@ -423,12 +433,13 @@ grid_arc_kernel(const GridParams p)
     for (int i = tid; i < p.lut_entries; i += kArcThreads) L.lut[i] = p.kb_lut[i];
     const unsigned lut0 = lds_addr(L.lut);
     const unsigned dbase = lds_addr(L.d);
-    constexpr unsigned kBufBytes = (unsigned)((CPB / 2) * C::NREC * 16);
+    constexpr unsigned kBufBytes = (unsigned)(C::NREC * CPB * 8);
+    constexpr unsigned kRecStep = CPB == 1 ? 4u : 16u;              // bytes between consecutive records of one plane
     const float lscale = p.lut_scale;
     const float dcf_a = p.apply_dcf ? p.dcf_a : 0.0f, dcf_b = p.apply_dcf ? p.dcf_b : 1.0f;
 
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const unsigned nchan8 = (unsigned)p.nchan * 8u;
+    const unsigned nchan8 = (unsigned)p.nchan * (HALF ? 4u : 8u);       // bytes per sample (all coils)
     const unsigned lane_step = (unsigned)lane * nchan8;
     // output: the block's two rows as byte offsets inside a coil plane (the tile lies inside the grid, its columns are even)
     unsigned out_off[2];
@@ -449,7 +460,7 @@ grid_arc_kernel(const GridParams p)
         const int ns = hdr.x, K = hdr.y;
         const uint4 *ent = p.arc_ent + win * p.arc_cap + hdr.z;
         const float *ephi = p.arc_ephi + win * p.arc_cap + hdr.z;
-        const float2 *in = reinterpret_cast<const float2 *>(p.nudata) + (size_t)z * (size_t)p.in_slice_stride + c0;
+        const unsigned char *in = reinterpret_cast<const unsigned char *>(p.nudata) + ((size_t)z * (size_t)p.in_slice_stride + c0) * (HALF ? 4 : 8);
 
         v2f acc[4][CPB];
 #pragma unroll
@@ -480,13 +491,22 @@ grid_arc_kernel(const GridParams p)
                 const unsigned a = (unsigned)__builtin_amdgcn_readfirstlane((int)L.s_a[i]);
                 const unsigned sb = (unsigned)__builtin_amdgcn_readfirstlane((int)L.s_b[i]);
                 const int len = (int)((sb >> 10) & 127u);
-                const unsigned dst = buf + (sb >> 17) * 16u;
+                const unsigned dst = buf + (sb >> 17) * kRecStep;
                 const unsigned first = (a & 0x7fffffffu) * nchan8;                     // byte offset of the first record's coil 0
                 if (lane < len) {
                     const unsigned voff = (a >> 31) ? first - lane_step : first + lane_step;
+                    if constexpr (CPB == 1) {
+                        lds_dma4_s(in, voff, dst);                                     // real parts, imaginary parts
+                        lds_dma4_s(in + 4, voff, dst + (unsigned)(C::NREC * 4));
+                    } else if constexpr (HALF) {
 #pragma unroll
-                    for (int c = 0; c < CPB / 2; ++c)
-                        if (2 * c < ncb) lds_dma16_s(in + 2 * c, voff, dst + (unsigned)(c * C::NREC * 16));
+                        for (int hq = 0; hq < CPB / 4; ++hq)                           // four coils per piece, parked in coil-pair planes CPB/4 ...
+                            if (4 * hq < ncb) lds_dma16_s(in + 16 * hq, voff, dst + (unsigned)((CPB / 4 + hq) * C::NREC * 16));
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < CPB / 2; ++c)
+                            if (2 * c < ncb) lds_dma16_s(in + 16 * c, voff, dst + (unsigned)(c * C::NREC * 16));
+                    }
                 }
             }
         };
@@ -522,6 +542,29 @@ grid_arc_kernel(const GridParams p)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's pieces of batch b have landed
             APROF_MARK(4);                                      // DMA wait
             lds_barrier();                                      // ... everyone's have; everyone has left batch b - 1's buffer
+            if constexpr (HALF) {
+                // complex-half -> fp32 in place, record by record (slots beyond the batch's records hold stale bits: never read)
+                const unsigned cbuf = dbase + (unsigned)(b & (C::NBUF - 1)) * kBufBytes;
+                for (int rec = tid; rec < C::NREC; rec += kArcThreads) {
+                    v4u hv[CPB / 4];
+#pragma unroll
+                    for (int hq = 0; hq < CPB / 4; ++hq)
+                        hv[hq] = *(const __attribute__((address_space(3))) v4u *)(size_t)(cbuf + (unsigned)((CPB / 4 + hq) * C::NREC * 16 + rec * 16));
+#pragma unroll
+                    for (int hq = 0; hq < CPB / 4; ++hq) {
+                        const unsigned w[4] = {hv[hq].x, hv[hq].y, hv[hq].z, hv[hq].w};
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) {
+                            __half2 h0, h1;
+                            __builtin_memcpy(&h0, &w[2 * k], 4);
+                            __builtin_memcpy(&h1, &w[2 * k + 1], 4);
+                            const float2 f0 = __half22float2(h0), f1 = __half22float2(h1);
+                            *(__attribute__((address_space(3))) v4f *)(size_t)(cbuf + (unsigned)((2 * hq + k) * C::NREC * 16 + rec * 16)) = (v4f){f0.x, f0.y, f1.x, f1.y};
+                        }
+                    }
+                }
+                lds_barrier();
+            }
             APROF_MARK(5);
 #ifndef TRON_ARC_SKIP_DMA
             if (C::NBUF == 2 && b + 1 < K) issue(b + 1);
@@ -538,94 +581,8 @@ grid_arc_kernel(const GridParams p)
 #ifdef TRON_ARC_SKIP_OUTER
             mhi = -1;
 #endif
-#ifdef TRON_ARC_FLAT
-            // One flat loop over this thread's visits of the batch: a lane whose member is exhausted moves on to its next
-            // member with samples in reach while the others keep visiting (nested member / radius loops left 55 % of the
-            // lanes idle: every wave ran the longest member count times the longest radius count).  The visit itself is
-            // unconditional -- a lane with nothing left sits on a harmless state (its own point as the sample position, record
-            // 0, band bit 31 = weight 0) -- so the accumulators are updated in place by every lane in every iteration.
-            int m = mlo - 1, rem = 0, bit = 31, inc = 0;
-            float uf = 1.f, incf = 0.f, csx = X0f, csy = Y0f;
-            unsigned addr = buf;
-            auto advance = [&]() {
-                if (rem == 0 && m <= mhi) {
-                    inc = 0; incf = 0.f; bit = 31; uf = 1.f; csx = X0f; csy = Y0f; addr = buf;     // idle unless this member has samples in reach
-                    if (m < mhi) {                              // (one member per iteration: a search loop here makes the compiler keep two copies of the accumulators)
-                        ++m;
-                        { const unsigned long long bm_ = __ballot(1); if (lane == __builtin_ctzll(bm_)) { APROF_COUNT(12, 1); APROF_COUNT(13, __popcll(bm_)); } }
-                        const int i = b + K * m;
-                        const float2 cs = L.s_cs[i];
-                        const unsigned sb = L.s_b[i];
-                        const int s_ulo = (int)(sb & 1023u), s_len = (int)((sb >> 10) & 127u);
-                        const float ic = safe_rcp(cs.x), is = safe_rcp(cs.y);
-                        // the radii whose sample lies inside the block's footprint: x0 - W < u cos < x1 + W, likewise y  (src/tron.cu:514-516)
-                        const float xa = xlo * ic, xb = xhi * ic;
-                        const float ya = ylo * is, yb = yhi * is;
-                        const float lo = fmaxf(fmaxf(fminf(xa, xb), fminf(ya, yb)), fmaxf((float)s_ulo, blo_f));
-                        const float hi = fminf(fminf(fmaxf(xa, xb), fmaxf(ya, yb)), fminf((float)(s_ulo + s_len - 1), bhi_f));
-                        const int ua = (int)ceilf(lo), ub = (int)floorf(hi);
-                        if (ua <= ub) {
-                            rem = ub - ua + 1;
-                            uf = (float)ua;
-                            bit = ua - bandlo;
-                            inc = 1; incf = 1.f;
-                            csx = cs.x; csy = cs.y;
-                            addr = buf + (unsigned)(((int)(sb >> 17) - s_ulo + ua) * 16);
-                        }
-                    } else {
-                        m = mhi + 1;                            // nothing left: this lane stays idle
-                    }
-                }
-            };
-            advance();
-            if (__ballot(rem != 0 || m <= mhi) != 0ull) do {   // (wave-uniform and bottom-tested: a top-tested loop copies every accumulator every iteration)
-#ifdef TRON_ARC_SKIP_INNER
-                acc[0][0].x += uf; rem = 0;
-                if (false) {
-#else
-                {
-                { const unsigned long long bm_ = __ballot(rem != 0); if (lane == __builtin_ctzll(bm_)) { APROF_COUNT(14, 1); APROF_COUNT(15, __popcll(bm_)); } }
-                const float kx = uf * csx, ky = uf * csy;                                     // src/tron.cu:514-515
-                // four table lookups and the samples, all asked for before the first is used (one LDS round trip per visit)
-                const float t0 = fabsf(kx - X0f) * lscale, t1 = fabsf(kx - X1f) * lscale;
-                const float t2 = fabsf(ky - Y0f) * lscale, t3 = fabsf(ky - Y1f) * lscale;
-                const v4f e0 = *(lds_f4p)(size_t)(lut0 + (unsigned)t0 * 16u), e1 = *(lds_f4p)(size_t)(lut0 + (unsigned)t1 * 16u);
-                const v4f e2 = *(lds_f4p)(size_t)(lut0 + (unsigned)t2 * 16u), e3 = *(lds_f4p)(size_t)(lut0 + (unsigned)t3 * 16u);
-                v4f dd[CPB / 2];
-#pragma unroll
-                for (int c = 0; c < CPB / 2; ++c) dd[c] = *(lds_f4p)(size_t)(addr + (unsigned)(c * C::NREC * 16));
-                const float sdc = fmaf(dcf_a, uf, dcf_b);                                     // src/tron.cu:412 (|ro - nro/2| = u)
-                const float f0 = __builtin_amdgcn_fractf(t0), f1 = __builtin_amdgcn_fractf(t1);
-                const float f2 = __builtin_amdgcn_fractf(t2), f3 = __builtin_amdgcn_fractf(t3);
-                const float wx0 = fmaf(f0, fmaf(f0, e0.z, e0.y), e0.x), wx1 = fmaf(f1, fmaf(f1, e1.z, e1.y), e1.x);
-                const float wy0 = fmaf(f2, fmaf(f2, e2.z, e2.y), e2.x) * sdc, wy1 = fmaf(f3, fmaf(f3, e3.z, e3.y), e3.x) * sdc;
-                float wq[4];
-                wq[0] = wx0 * wy0; wq[1] = wx1 * wy0; wq[2] = wx0 * wy1; wq[3] = wx1 * wy1;       // src/tron.cu:516
-#pragma unroll
-                for (int q = 0; q < 4; ++q)                                                        // src/tron.cu:512,521: bit u - bandlo of the point's band mask
-                    wq[q] = __uint_as_float(__float_as_uint(wq[q]) & (unsigned)__builtin_amdgcn_sbfe((int)bmask[q], bit, 1));
-#pragma unroll
-                for (int c = 0; c < CPB / 2; ++c) {
-                    const v4f d = dd[c];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        acc[q][2 * c].x = fmaf(d.x, wq[q], acc[q][2 * c].x);                      // src/tron.cu:519
-                        acc[q][2 * c].y = fmaf(d.y, wq[q], acc[q][2 * c].y);
-                        acc[q][2 * c + 1].x = fmaf(d.z, wq[q], acc[q][2 * c + 1].x);
-                        acc[q][2 * c + 1].y = fmaf(d.w, wq[q], acc[q][2 * c + 1].y);
-                    }
-                }
-                uf += incf;
-                addr += (unsigned)inc << 4;
-                bit += inc;
-                rem -= inc;
-                }
-#endif
-                advance();
-            } while (__ballot(rem != 0 || m <= mhi) != 0ull);
-#else
             // member loop / radius loop (a flat loop over the visits, in which a lane moves on to its next member while the
-            // others keep visiting, was measured too -- TRON_ARC_FLAT: 27 % fewer wave iterations, but some lane needs a new
+            // others keep visiting, was measured too: 27 % fewer wave iterations, but some lane needs a new
             // member in 78 % of them and the iteration grows from 87 to 160 instructions: slower)
             for (int m = mlo; m <= mhi; ++m) {
                 { const unsigned long long bm_ = __ballot(1); if (lane == __builtin_ctzll(bm_)) { APROF_COUNT(12, 1); APROF_COUNT(13, __popcll(bm_)); } }
@@ -644,7 +601,7 @@ grid_arc_kernel(const GridParams p)
 #ifdef TRON_ARC_SKIP_INNER
                 acc[0][0].x += (float)ua; continue;
 #endif
-                unsigned addr = buf + (unsigned)(((int)(sb >> 17) - s_ulo + ua) * 16);
+                unsigned addr = buf + (unsigned)((int)(sb >> 17) - s_ulo + ua) * kRecStep;
                 float uf = (float)ua;
                 int bit = ua - bandlo;
                 for (int u = ua; u <= ub; ++u) {
@@ -655,9 +612,15 @@ grid_arc_kernel(const GridParams p)
                     const float t2 = fabsf(ky - Y0f) * lscale, t3 = fabsf(ky - Y1f) * lscale;
                     const v4f e0 = *(lds_f4p)(size_t)(lut0 + (unsigned)t0 * 16u), e1 = *(lds_f4p)(size_t)(lut0 + (unsigned)t1 * 16u);
                     const v4f e2 = *(lds_f4p)(size_t)(lut0 + (unsigned)t2 * 16u), e3 = *(lds_f4p)(size_t)(lut0 + (unsigned)t3 * 16u);
-                    v4f dd[CPB / 2];
+                    v4f dd[CPB / 2 > 0 ? CPB / 2 : 1];
+                    v2f d1 = {0.f, 0.f};
+                    if constexpr (CPB == 1) {
+                        d1.x = *(const __attribute__((address_space(3))) float *)(size_t)addr;
+                        d1.y = *(const __attribute__((address_space(3))) float *)(size_t)(addr + (unsigned)(C::NREC * 4));
+                    } else {
 #pragma unroll
-                    for (int c = 0; c < CPB / 2; ++c) dd[c] = *(lds_f4p)(size_t)(addr + (unsigned)(c * C::NREC * 16));
+                        for (int c = 0; c < CPB / 2; ++c) dd[c] = *(lds_f4p)(size_t)(addr + (unsigned)(c * C::NREC * 16));
+                    }
                     const float sdc = fmaf(dcf_a, uf, dcf_b);                                 // src/tron.cu:412 (|ro - nro/2| = u)
                     const float f0 = __builtin_amdgcn_fractf(t0), f1 = __builtin_amdgcn_fractf(t1);
                     const float f2 = __builtin_amdgcn_fractf(t2), f3 = __builtin_amdgcn_fractf(t3);
@@ -668,6 +631,13 @@ grid_arc_kernel(const GridParams p)
 #pragma unroll
                     for (int q = 0; q < 4; ++q)                                                    // src/tron.cu:512,521: bit u - bandlo of the point's band mask
                         wq[q] = __uint_as_float(__float_as_uint(wq[q]) & (unsigned)__builtin_amdgcn_sbfe((int)bmask[q], bit, 1));
+                    if constexpr (CPB == 1) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            acc[q][0].x = fmaf(d1.x, wq[q], acc[q][0].x);                          // src/tron.cu:519
+                            acc[q][0].y = fmaf(d1.y, wq[q], acc[q][0].y);
+                        }
+                    }
 #pragma unroll
                     for (int c = 0; c < CPB / 2; ++c) {
                         const v4f d = dd[c];
@@ -680,11 +650,10 @@ grid_arc_kernel(const GridParams p)
                         }
                     }
                     uf += 1.0f;
-                    addr += 16u;
+                    addr += kRecStep;
                     ++bit;
                 }
             }
-#endif
             APROF_MARK(6);                                      // gather
         }
 
@@ -723,7 +692,7 @@ extern "C" int tron_debug_arc_profile(unsigned long long *out, int n)   // reads
 }
 #endif
 
-template <int CPB>
+template <int CPB, bool HALF>
 static hipError_t launch_arc_cpb(const GridParams &p, int first_plain, hipStream_t s)
 {
     if (p.arc_nrec != ArcCfg<CPB>::NREC) return hipErrorInvalidValue;       // the run tables were dealt for another batch size
@@ -738,33 +707,38 @@ static hipError_t launch_arc_cpb(const GridParams &p, int first_plain, hipStream
     dim3 grid((unsigned)((size_t)q.ntiles * ngroups), (unsigned)chunks);
     const size_t lds = sizeof(ArcLds<CPB>);
     if (lds > 64 * 1024) {
-        static hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(grid_arc_kernel<CPB>),
+        static hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(grid_arc_kernel<CPB, HALF>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ArcLds<CPB>));
         if (once != hipSuccess) return once;
     }
-    hipLaunchKernelGGL((grid_arc_kernel<CPB>), grid, dim3(kArcThreads), lds, s, q);
+    hipLaunchKernelGGL((grid_arc_kernel<CPB, HALF>), grid, dim3(kArcThreads), lds, s, q);
     return hipGetLastError();
 }
 
-bool grid_arc_supported(int nchan, int nxos, int nro, int npe, float W)
+// fp32 k-space: one coil or an even coil count (16-byte coil pairs); complex-half: a multiple of four coils (16 bytes)
+bool grid_arc_supported(int nchan, int nxos, int nro, int npe, float W, int half_in)
 {
-    return nchan >= 2 && (nchan & 1) == 0 && nro == nxos && nxos <= 2048 && npe <= kArcMaxNpe && W <= 3.0f
-           && (nxos / 2) % kArcTile == 0 && nxos >= 4 * kArcTile && (long long)nro * npe * nchan < (1ll << 31);
+    const bool coils = half_in ? (nchan >= 4 && (nchan & 3) == 0) : (nchan == 1 || (nchan & 1) == 0);
+    return nchan >= 1 && coils && nro == nxos && nxos <= 2048 && npe <= kArcMaxNpe && W <= 3.0f
+           && (nxos / 2) % kArcTile == 0 && nxos >= 4 * kArcTile && (long long)nro * npe * nchan < (1ll << 28);
 }
 
 // p.tile_order[first_plain ...] must list the 32x32 tiles (see build_tile_order(nxos, 32, ...)); p.inner_r0 > 0.
-hipError_t launch_grid_arc(const GridParams &p, int first_plain, hipStream_t s)
+hipError_t launch_grid_arc(const GridParams &p, int half_in, int first_plain, hipStream_t s)
 {
-    if (p.out_p != 1 || p.inner_r0 <= 0 || !p.arc_hdr || !p.arc_ent || !p.arc_ephi || !p.kb_lut || p.lut_entries > kArcLutEntries || (p.coil0 & 1)
-        || !grid_arc_supported(p.nchan, p.nxos, p.nro, p.npe, p.W) || (reinterpret_cast<uintptr_t>(p.nudata) & 15) != 0)
+    const int gran = half_in ? 3 : (p.nchan == 1 ? 0 : 1);
+    if (p.out_p != 1 || p.inner_r0 <= 0 || !p.arc_hdr || !p.arc_ent || !p.arc_ephi || !p.kb_lut || p.lut_entries > kArcLutEntries || (p.coil0 & gran)
+        || !grid_arc_supported(p.nchan, p.nxos, p.nro, p.npe, p.W, half_in) || (reinterpret_cast<uintptr_t>(p.nudata) & 15) != 0)
         return hipErrorInvalidValue;
     const int nc = p.nchan - p.coil0;
+    if (half_in) return nc >= 5 ? launch_arc_cpb<8, true>(p, first_plain, s) : launch_arc_cpb<4, true>(p, first_plain, s);
     if (nc >= 5) {
         const int pad8 = (nc + 7) / 8 * 8, pad6 = (nc + 5) / 6 * 6;
-        return pad6 < pad8 ? launch_arc_cpb<6>(p, first_plain, s) : launch_arc_cpb<8>(p, first_plain, s);
+        return pad6 < pad8 ? launch_arc_cpb<6, false>(p, first_plain, s) : launch_arc_cpb<8, false>(p, first_plain, s);
     }
-    if (nc >= 3) return launch_arc_cpb<4>(p, first_plain, s);
-    return launch_arc_cpb<2>(p, first_plain, s);
+    if (nc >= 3) return launch_arc_cpb<4, false>(p, first_plain, s);
+    if (nc >= 2) return launch_arc_cpb<2, false>(p, first_plain, s);
+    return launch_arc_cpb<1, false>(p, first_plain, s);
 }
 
 __global__ void warm_grid_arc_tu() {}

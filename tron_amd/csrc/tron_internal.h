@@ -97,10 +97,10 @@ constexpr int kBinnedTile = 32;
 // TRON_KB_FAST, fp32 input, even coil counts, centre relief active (tron_grid_arc.hip): the plain tiles of p.tile_order
 // (entries [first_plain, first_plain + ntiles)) are gridded by the arc kernel; the caller launches the inner tile's parts
 // (binned kernel, no_reduce) before and launch_grid_reduce after it
-hipError_t launch_grid_arc(const GridParams &p, int first_plain, hipStream_t s);
+hipError_t launch_grid_arc(const GridParams &p, int half_in, int first_plain, hipStream_t s);
 hipError_t launch_grid_reduce(const GridParams &p, hipStream_t s);
-bool grid_arc_supported(int nchan, int nxos, int nro, int npe, float W);
-int grid_arc_nrec(int nchan);
+bool grid_arc_supported(int nchan, int nxos, int nro, int npe, float W, int half_in);
+int grid_arc_nrec(int nchan, int half_in);
 constexpr int kArcLutEntries = 272;    // Kaiser-Bessel table entries held in LDS (128 intervals per W, up to |x| = W + 1.05, W >= 1)
 // plan-time pass of the arc kernel: clips every window's angle-sorted spokes against every tile and deals the runs into batches
 struct ArcPrepParams {

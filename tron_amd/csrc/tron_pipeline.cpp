@@ -229,10 +229,10 @@ int adjoint_run_raw(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, 
                     if (p->inner_beside) {
                         HIP_TRY(hipEventRecord(p->ev_inner[0], st));             // (the reduce pass that last read the parts buffer is behind this)
                         HIP_TRY(hipStreamWaitEvent(p->stream_inner, p->ev_inner[0], 0));
-                        HIP_TRY(launch_grid_binned(gi, 0, p->stream_inner));
+                        HIP_TRY(launch_grid_binned(gi, p->cfg.input_half, p->stream_inner));
                         HIP_TRY(hipEventRecord(p->ev_inner[1], p->stream_inner));
                     } else {
-                        HIP_TRY(launch_grid_binned(gi, 0, st));
+                        HIP_TRY(launch_grid_binned(gi, p->cfg.input_half, st));
                     }
                     const size_t win0 = golden ? (size_t)(zfirst + z0) : 0;
                     g.arc_hdr = p->d_arc_hdr + win0 * (size_t)(d.nxos / kBinnedTile) * (d.nxos / kBinnedTile);
@@ -246,7 +246,7 @@ int adjoint_run_raw(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, 
                     g.lut_scale = p->lut_scale;
                     // slices one workgroup grids in turn (tile geometry and the window table are set up once per workgroup)
                     g.arc_zper = p->arc_zper > 0 ? p->arc_zper : (cz >= 64 ? 4 : (cz >= 32 ? 2 : 1));
-                    HIP_TRY(launch_grid_arc(g, p->relief_parts, st));
+                    HIP_TRY(launch_grid_arc(g, p->cfg.input_half, p->relief_parts, st));
                     if (p->inner_beside) HIP_TRY(hipStreamWaitEvent(st, p->ev_inner[1], 0));
                     HIP_TRY(launch_grid_reduce(g, st));
                 } else {

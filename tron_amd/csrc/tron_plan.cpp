@@ -94,7 +94,7 @@ extern "C" int tron_plan_create(tron_plan **out, const tron_config *cfg, const t
     // The heaviest tile (the k-space centre, crossed by every spoke) is one wave's serial work, so a
     // launch needs enough slices in flight to cover that critical path: batch up to 1 GiB of grid.
     // ... or 64 slices when the coils are many (still at most 6 GiB of grid: 288 GB of HBM make that cheap)
-    size_t auto_chunk = std::max<size_t>(1, ((size_t)1 << 30) / per_unit);
+    size_t auto_chunk = std::max<size_t>(1, ((size_t)2 << 30) / per_unit);   // (2 GiB: 128 slices x 8 coils; +5 % over 64-slice launches with the arc kernel)
     if (auto_chunk < 64) auto_chunk = std::max<size_t>(auto_chunk, std::min<size_t>(64, ((size_t)6 << 30) / per_unit));
     int chunk = cfg->chunk_slices > 0 ? cfg->chunk_slices : (int)std::max<size_t>(1, auto_chunk);
     if (const char *env = getenv("TRON_CHUNK_SLICES")) chunk = std::max(1, atoi(env));
@@ -155,7 +155,7 @@ extern "C" int tron_plan_create(tron_plan **out, const tron_config *cfg, const t
                 if ((rc = upload(&p->d_relief_slots, rslots.data(), rslots.size() * sizeof(int)))) return bail(rc);
             }
             // arc kernel: everything but the inner tile, when the trajectory and the sample layout allow it
-            p->arc = p->relief_entries > 0 && !cfg->input_half && grid_arc_supported(p->nchan, d.nxos, d.nro, d.npe1work, cfg->kernwidth);
+            p->arc = p->relief_entries > 0 && grid_arc_supported(p->nchan, d.nxos, d.nro, d.npe1work, cfg->kernwidth, cfg->input_half);
             if (const char *gk = getenv("TRON_GRID_KERNEL")) p->arc = p->arc && strcmp(gk, "binned") != 0;
             if (p->arc) {
                 // plan-time pass: every window's spokes sorted by line angle (host), clipped against every tile and dealt
@@ -180,7 +180,7 @@ extern "C" int tron_plan_create(tron_plan **out, const tron_config *cfg, const t
                 auto drop = [&]() { hipFree(d_order); hipFree(d_phi); hipFree(d_scs); hipFree(d_alloc); };
                 // a spoke crosses at most 2 * nxos / 32 + 3 tiles (+ their halos): 56 run entries per spoke bound every window
                 p->arc_cap = npe * (2 * (d.nxos / kBinnedTile) + 24);
-                p->arc_nrec = grid_arc_nrec(p->nchan);
+                p->arc_nrec = grid_arc_nrec(p->nchan, cfg->input_half);
                 rc = upload(&d_order, order.data(), order.size() * sizeof(unsigned short));
                 if (!rc) rc = upload(&d_phi, phi.data(), phi.size() * sizeof(float));
                 if (!rc) rc = upload(&d_scs, scs.data(), scs.size() * sizeof(float));
