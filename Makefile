@@ -7,7 +7,7 @@ ROCM      ?= /opt/rocm
 ARCH      ?= gfx950
 # -ffp-contract=off: every fused multiply-add in the kernels is an explicit fmaf(); host tables
 # must round exactly like an IEEE host build of the reference.
-CXXFLAGS  := -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-result -Wno-unused-value -Iinclude
+CXXFLAGS  := -O3 -std=c++17 -fPIC -fvisibility=hidden -ffp-contract=off -Wall -Wno-unused-result -Wno-unused-value -Iinclude
 HIPFLAGS  := $(CXXFLAGS) --offload-arch=$(ARCH)
 LDFLAGS   := -L$(ROCM)/lib -lrocfft -lamdhip64 -Wl,-rpath,$(ROCM)/lib
 
@@ -28,7 +28,7 @@ $(OBJ)/%.o: $(SRC)/%.hip $(wildcard $(SRC)/*.h) $(wildcard include/*.h)
 
 $(LIB): $(OBJ)/tron_kernels.o $(OBJ)/tron_grid_binned.o $(OBJ)/tron_grid_arc.o $(OBJ)/tron_fft512.o $(OBJ)/tron_degrid_tile.o $(OBJ)/tron_cgnr.o $(OBJ)/tron_plan.o $(OBJ)/tron_pipeline.o $(OBJ)/tron_hostio.o $(OBJ)/tron_hostmath.o $(OBJ)/rawarray.o
 	@mkdir -p tron_amd/lib
-	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) $^ -o $@ $(LDFLAGS)
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) $^ -o $@ $(LDFLAGS) -Wl,--version-script=$(SRC)/exports.map
 
 $(BIN): $(OBJ)/tron_main.o $(LIB)
 	@mkdir -p tron_amd/bin

@@ -132,6 +132,8 @@ def forward_bench(args, rank, local_rank, world, torch, group, lib):
         ms, n = stages["degrid"]
         alg = 8 * NXOS * NXOS + 8 * nro * npe                    # degridding alone: grid read + sample write
         achieved = alg * nc * nimg * reps / n / (ms / n * 1e-3) / 1e9
+        fwd_units = nc * nimg * reps / n
+        ftraffic, fstale, fnote = traffic_capture(workload_key(args), ("degrid_tile_kernel", "degrid_kernel"), fwd_units)
         err = None
         if not args.no_check:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -151,7 +153,8 @@ def forward_bench(args, rank, local_rank, world, torch, group, lib):
             "algorithmic_gbps_per_gpu": round(gbps, 1), "algorithmic_frac_of_peak": round(gbps / HBM_PEAK_GBPS, 4),
             "parity_rel_l2_vs_oracle": err,
             "roofline": {"bound": "hbm", "kernel": "degrid_tile_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "launch_ms": round(ms / n, 4),
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": ftraffic, "traffic_stale": fstale, "traffic_source": fnote,
+                         "bytes_per_launch": int(alg * fwd_units), "units_per_launch": fwd_units, "launch_ms": round(ms / n, 4),
                          "stage_share": {k: round(v[0] / sum(x[0] for x in stages.values()), 3) for k, v in stages.items()}},
             "cpu_baseline": None,
         }
@@ -205,28 +208,39 @@ def launch_ranks(args):
     return 0
 
 
-def traffic_capture(kernel_prefix, units_per_launch_now):
-    """HBM bytes per launch of the dominant kernel from the PMC capture under profiles/ -- used only when that
-    capture was taken on THESE kernel sources (tools/traffic.sh stamps it with buildinfo.kernel_source_hash()).
-    Returns (bytes_per_launch or None, stale flag, note)."""
+GRID_STAGE_KERNELS = ("grid_arc_kernel", "grid_binned_kernel", "grid_tile_kernel", "grid_reduce_parts_kernel")
+
+
+def workload_key(args):
+    """Names the capture file of a workload: profiles/traffic_<key>.json (tools/traffic.sh <key> [bench.py arguments])."""
+    if args.forward:
+        return f"forward_nc{args.coils}"
+    return (f"nc{args.coils}_npe{args.spokes}_nz{args.slices}" + ("_half" if args.half else "") + ("_linear" if args.linear else "")
+            + ("_exact" if args.kb == "exact" else ""))
+
+
+def traffic_capture(key, kernel_prefixes, units_per_launch_now):
+    """HBM bytes per launch of a stage (all its kernels) from the PMC capture of THIS workload under profiles/ -- used only
+    when the capture was taken on THESE kernel sources (tools/traffic.sh stamps it with buildinfo.kernel_source_hash()) and
+    with launches of THIS size.  Returns (bytes_per_launch or None, stale flag, note)."""
     from tron_amd.buildinfo import kernel_source_hash
-    path = os.path.join(ROOT, "profiles", "traffic_current.json")
+    path = os.path.join(ROOT, "profiles", f"traffic_{key}.json")
     try:
         tj = json.load(open(path))
     except Exception:
-        return None, True, "no capture"
+        return None, True, f"no capture for this workload (tools/traffic.sh {key} ...)"
     if tj.get("source_hash") != kernel_source_hash():
         return None, True, f"capture {tj.get('source_hash')} != sources {kernel_source_hash()}"
-    # the gridding stage is grid_binned_kernel plus the pass that adds the inner tile's parts (one launch each per batch)
-    prefixes = (kernel_prefix, "grid_reduce_parts_kernel") if kernel_prefix == "grid_binned_kernel" else (kernel_prefix,)
+    if abs(float(tj.get("units_per_launch", -1)) - float(units_per_launch_now)) > 0.5:
+        return None, True, f"capture has {tj.get('units_per_launch')} units per launch, this run {units_per_launch_now}"
     per_launch = 0.0
     for name, c in tj.get("kernels", {}).items():
-        if name.startswith(prefixes) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        if name.startswith(kernel_prefixes) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            # per launch of the STAGE: a stage launches each of its kernels once, so sum the per-dispatch means
             per_launch += (2.0 * c["FETCH_SIZE"]["kib"] / c["FETCH_SIZE"]["dispatches"]
                            + c["WRITE_SIZE"]["kib"] / c["WRITE_SIZE"]["dispatches"]) * 1024.0
     if per_launch > 0.0:
-        scale = units_per_launch_now / float(tj.get("coil_slices_per_launch", units_per_launch_now))
-        return int(per_launch * scale), False, tj.get("command", "")
+        return int(per_launch), False, tj.get("command", "")
     return None, True, "kernel not in capture"
 
 
@@ -352,17 +366,17 @@ def main():
         alg = {"grid": ab["grid"], "fft": ab["fft"] + (ab["post"] if "post" not in stages else 0), "post": ab["post"]}[dom]
         bytes_per_launch = alg * units_per_launch
         achieved = bytes_per_launch / (ms / n * 1e-3) / 1e9
-        kname = {"grid": "grid_binned_kernel" if args.kb == "fast" else "grid_tile_kernel",
+        kname = {"grid": plan.grid_kernel_name(),
                  "fft": "fft512_rows_kernel + fft512_cols_post_kernel" if "post" not in stages else "rocFFT 512x512 C2C inverse (batched)",
                  "post": "post_kernel"}[dom]
         # HBM bytes the dominant kernel actually moved: rocprofv3 PMC capture of THIS build (FETCH_SIZE x2 + WRITE_SIZE,
         # separate passes, MI355X_MICROARCH.md HBM section), else null + traffic_stale
-        traffic, stale, note = (None, True, "not the default workload")
-        if dom == "grid" and args.kb == "fast" and nc == 8 and NPE == 402 and not args.half:
-            traffic, stale, note = traffic_capture("grid_binned_kernel", units_per_launch)
+        traffic, stale, note = (None, True, "the dominant stage is not gridding")
+        if dom == "grid":
+            traffic, stale, note = traffic_capture(workload_key(args), GRID_STAGE_KERNELS, units_per_launch)
         roofline = dict(bound="hbm", kernel=kname, achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
                         frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=traffic, traffic_stale=stale, traffic_source=note,
-                        bytes_per_launch=int(bytes_per_launch),
+                        bytes_per_launch=int(bytes_per_launch), units_per_launch=units_per_launch,
                         launch_ms=round(ms / n, 4), stage_share={k: round(v[0] / tot, 3) for k, v in stages.items()},
                         two_lanes=two_lanes,
                         launch_ms_overlapped=overlapped if two_lanes else None,

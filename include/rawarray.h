@@ -21,6 +21,9 @@
 
 #include <stdint.h>
 
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)   /* the library is built with -fvisibility=hidden: this header IS its export list */
+#endif
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -65,6 +68,13 @@ int ra_diff(const ra_t *a, const ra_t *b);                                  /* 0
 /* Header only (no data read); dims is malloc'ed. */
 int ra_read_header(ra_t *a, const char *path);
 
+/* Streaming (not in the reference): the header alone -- the file is created or truncated to it -- and byte ranges of the
+   payload, counted from its first byte; data_offset = ra_data_offset().  Each call opens the file itself (thread-safe). */
+uint64_t ra_data_offset(const ra_t *a);
+int ra_write_header(const ra_t *a, const char *path);
+int ra_read_range(const char *path, uint64_t data_offset, uint64_t first, uint64_t count, void *dst);
+int ra_write_range(const char *path, uint64_t data_offset, uint64_t first, uint64_t count, const void *src);
+
 /* IEEE binary16 conversions with round-to-nearest-even, the semantics of src/float16.cu:42-324. */
 uint16_t ra_float_to_half_bits(uint32_t f);
 uint32_t ra_half_to_float_bits(uint16_t h);
@@ -73,5 +83,8 @@ uint64_t ra_half_to_double_bits(uint16_t h);
 
 #ifdef __cplusplus
 }
+#endif
+#if defined(__GNUC__)
+#pragma GCC visibility pop
 #endif
 #endif /* RAWARRAY_H */

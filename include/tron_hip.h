@@ -29,6 +29,9 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)   /* the library is built with -fvisibility=hidden: this header IS its export list */
+#endif
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -183,6 +186,8 @@ int tron_plan_sync(tron_plan *plan);
    kernel then runs alone, which is what a per-kernel duration should be measured on -- enable = 1 restores the plan's
    default.  *had_two_lanes (may be NULL) reports whether the plan has a second lane at all. */
 int tron_plan_two_lanes(tron_plan *plan, int enable, int *had_two_lanes);
+/* Names the gridding kernel(s) the plan's adjoint launches (measurement tooling); a static string. */
+const char *tron_plan_grid_kernel_name(const tron_plan *plan);
 
 /* Per-stage device timing with hipEvents on the plan's stream (off by default; costs one
    event pair per launch).  stage: 0 grid, 1 fft, 2 post (crop+deapod+SoS), 3 pre
@@ -202,6 +207,9 @@ int tron_plan_timing_reset(tron_plan *plan);
 int tron_host_trig_table(const tron_config *cfg, const tron_dims *dims, float *cos_sin, size_t n);
 int tron_host_band_table(int nxos, float kernwidth, uint32_t *band);
 int tron_host_deapod_table(int n, float kernwidth, float sigma, float *inv_weight);
+/* CPUs of the NUMA node of a PCI function ("0000:c1:00.0") read from a sysfs tree rooted at sysroot ("/sys"): what
+   tron_recon_radial2d_multi binds each per-GPU worker thread to.  Returns the count, 0 if the node is unknown, -1 on bad input. */
+int tron_host_numa_cpulist(const char *sysroot, const char *pci_bus_id, int *cpus, int max_cpus);
 
 /* Small device-memory helpers so a host language without HIP bindings can drive the
    device-resident entry points. */
@@ -216,5 +224,8 @@ const char *tron_version(void);
 
 #ifdef __cplusplus
 }
+#endif
+#if defined(__GNUC__)
+#pragma GCC visibility pop
 #endif
 #endif /* TRON_HIP_H */

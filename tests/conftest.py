@@ -3,6 +3,9 @@ import sys
 
 import pytest
 
+# the library reads its tuning / debugging switches (TRON_FFT, TRON_CENTRE_RELIEF, ...) only under TRON_TUNING=1; the tests use them
+os.environ.setdefault("TRON_TUNING", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

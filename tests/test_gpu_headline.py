@@ -10,6 +10,9 @@ point) against the CPU oracle on more than one slice of a launch-sized batch:
 
 Tolerance: north_star's 1e-5 relative L2 per slice (src/tron.cu:465-536, 540-577 via the oracle).
 """
+import os
+import subprocess
+
 import numpy as np
 import pytest
 
@@ -21,6 +24,7 @@ pytestmark = pytest.mark.gpu
 
 TOL = 1e-5
 NRO = 512
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _check_slices(oracle, data, got, slices, **oflags):
@@ -104,3 +108,25 @@ def test_cgnr_at_the_metric_shape(oracle):
     assert (dims.nz, dims.npe1work, dims.nxos) == (2, 402, 512) and p.nz == 2
     for z in range(2):
         assert rel_l2(got[..., z], want[..., z]) <= TOL, z
+
+
+@pytest.mark.timeout(900)
+def test_config3_whole_body_at_full_size_through_the_cli(oracle, tmp_path):
+    """BASELINE config 3 at its real size: a synthetic [6, 1, 512, 20271, 1] complex64 stream (498 180 184 bytes with the
+    header, what the reference's LFS pointer for ex_whole_body.ra declares) through `tron -v -u 0.4 -d 21 -a -G`
+    (src/RUNME3_tron_grid_all.sh:10): 956 sliding windows of 204 spokes -> [1, 1, 256, 256, 956]; the first, the middle and
+    the last slice against the oracle."""
+    from tron_amd import ra
+    nc, nro, npe1 = 6, 512, 20271
+    data = synth.kspace(nc, nro, npe1, seed=synth.SEED_BASE + 3)
+    inp, outp = str(tmp_path / "wb_in.ra"), str(tmp_path / "wb_out.ra")
+    ra.write(inp, data)
+    assert os.path.getsize(inp) == 498180184
+    r = subprocess.run([os.path.join(ROOT, "tron_amd", "bin", "tron"), "-v", "-u", "0.4", "-d", "21", "-a", "-G", inp, outp],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = ra.read(outp)
+    assert got.shape == (1, 1, 256, 256, 956)
+    for z in (0, 478, 955):
+        want, _ = oracle.recon(data, adjoint=1, zfirst=z, zcount=1, golden=1, data_undersamp=0.4, prof_slide=21)
+        assert rel_l2(got[..., z], want[..., z]) <= 1e-5

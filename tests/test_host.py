@@ -304,3 +304,32 @@ def test_headers_are_plain_c99_and_the_c_example_links(tmp_path):
     if shutil.which("gcc") is None:
         pytest.skip("needs gcc")
     _build_c_example(tmp_path)
+
+
+def test_numa_cpulist_from_a_fake_sysfs_tree(tmp_path):
+    """tron_recon_radial2d_multi binds each per-GPU worker thread to the CPUs of its GPU's NUMA node (the reference has no
+    affinity handling): PCI bus id -> numa_node -> cpulist, here against a fake sysfs tree."""
+    import ctypes
+    L = lib.load()
+    dev = tmp_path / "bus" / "pci" / "devices" / "0000:c1:00.0"
+    dev.mkdir(parents=True)
+    (dev / "numa_node").write_text("1\n")
+    node = tmp_path / "devices" / "system" / "node" / "node1"
+    node.mkdir(parents=True)
+    (node / "cpulist").write_text("32-35,96-97\n")
+    buf = (ctypes.c_int * 64)()
+    n = L.tron_host_numa_cpulist(str(tmp_path).encode(), b"0000:C1:00.0", buf, 64)       # HIP reports upper-case hex
+    assert n == 6 and list(buf[:6]) == [32, 33, 34, 35, 96, 97]
+    assert L.tron_host_numa_cpulist(str(tmp_path).encode(), b"0000:c1:00.0", buf, 3) == 3  # truncated, not overrun
+    (dev / "numa_node").write_text("-1\n")                                               # single-node host / VM
+    assert L.tron_host_numa_cpulist(str(tmp_path).encode(), b"0000:c1:00.0", buf, 64) == 0
+    assert L.tron_host_numa_cpulist(str(tmp_path).encode(), b"0000:ff:00.0", buf, 64) == 0  # unknown device
+    (dev / "numa_node").write_text("1\n")
+    (node / "cpulist").write_text("3-1\n")
+    assert L.tron_host_numa_cpulist(str(tmp_path).encode(), b"0000:c1:00.0", buf, 64) == -1
+
+
+def test_recon_multi_rejects_a_complex64_array_flagged_as_half():
+    import numpy as np
+    with pytest.raises(ValueError):
+        lib.recon_multi(np.zeros((2, 1, 16, 8, 1), np.complex64), adjoint=True, input_half=1)

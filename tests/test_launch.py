@@ -85,3 +85,29 @@ def test_spawn_ranks_does_not_wait_for_a_rendezvous_that_cannot_happen(tmp_path)
     t0 = time.monotonic()
     code, out = launch.spawn_ranks([child], 2, timeout=100)
     assert code == 3 and time.monotonic() - t0 < 60
+
+
+def test_spawn_ranks_retries_on_a_taken_port(tmp_path, monkeypatch):
+    """free_port() closes its probe socket before rank 0 binds the port, so another process can take it; a run whose rank 0
+    dies with "address already in use" is started again on a fresh port."""
+    marker = tmp_path / "tried"
+    child = _child(tmp_path, """
+        marker = %r
+        if os.environ["RANK"] == "0" and not os.path.exists(marker):
+            open(marker, "w").write("x")
+            sys.stderr.write("RuntimeError: The server socket has failed to listen on any local network address. "
+                             "EADDRINUSE: address already in use\\n")
+            sys.exit(1)
+        if os.environ["RANK"] == "0":
+            print('{"metric": "x", "n_gpus": 2}')
+    """ % str(marker))
+    ports = []
+    real = launch.free_port
+    monkeypatch.setattr(launch, "free_port", lambda: ports.append(real()) or ports[-1])
+    code, out = launch.spawn_ranks([child], 2, timeout=120)
+    assert code == 0 and '"n_gpus": 2' in out and len(ports) == 2
+
+
+def test_spawn_ranks_has_a_finite_default_timeout():
+    import inspect
+    assert inspect.signature(launch.spawn_ranks).parameters["timeout"].default == launch.DEFAULT_TIMEOUT_S < 3600

@@ -1,3 +1,4 @@
+export TRON_TUNING=1   # the library reads TRON_* switches only under TRON_TUNING=1
 for i in 1 2; do
 echo "== arc default"; python tools/gridbench.py 8 64 fast 5 2>&1 | tail -1
 echo "== inner in front"; TRON_ARC_INNER_STREAM=0 python tools/gridbench.py 8 64 fast 5 2>&1 | tail -1

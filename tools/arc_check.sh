@@ -1,4 +1,5 @@
 # usage (GPU box): bash tools/arc_check.sh  -- arc kernel vs binned kernel: timing (gridbench) and headline parity tests
+export TRON_TUNING=1   # the library reads TRON_* switches only under TRON_TUNING=1
 export TRON_ARC_DEBUG=1
 echo "== gridbench arc"; python tools/gridbench.py 8 64 fast 5 2>&1 | tail -1
 echo "== gridbench binned"; TRON_GRID_KERNEL=binned python tools/gridbench.py 8 64 fast 5 2>&1 | tail -1

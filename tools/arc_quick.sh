@@ -1,4 +1,5 @@
 # usage (GPU box): bash tools/arc_quick.sh  -- arc kernel: timing at 8 and 2 coils (+ binned for reference), phase clock, headline parity
+export TRON_TUNING=1   # the library reads TRON_* switches only under TRON_TUNING=1
 for i in 1 2; do
 echo "== arc 8";  python tools/gridbench.py 8 64 fast 5 2>&1 | tail -1
 echo "== binned 8"; TRON_GRID_KERNEL=binned python tools/gridbench.py 8 64 fast 5 2>&1 | tail -1

@@ -1,4 +1,5 @@
 # usage (GPU box): bash tools/arc_skip.sh -- VALU instructions and time of the arc kernel with phases compiled out (variants skipi/skipo/skipd)
+export TRON_TUNING=1   # the library reads TRON_* switches only under TRON_TUNING=1
 cp tron_amd/lib/libtronhip.so /tmp/orig.so
 for v in orig skipi skipo skipd; do
   if [ $v = orig ]; then cp /tmp/orig.so tron_amd/lib/libtronhip.so; else cp tron_amd/lib/libtronhip_$v.so tron_amd/lib/libtronhip.so; fi

@@ -1,5 +1,6 @@
 """Stage timing of the forward (degridding) direction: nimg images of 256^2 -> 512 ro x 512 spokes (tooling)."""
 import os, sys, time
+os_env_ = __import__("os").environ; os_env_.setdefault("TRON_TUNING", "1")   # the library reads TRON_* switches only under TRON_TUNING=1
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tron_amd import lib

@@ -1,6 +1,7 @@
 """Stage timing of the adjoint on the metric shape (tooling for kernel work).
 usage: python tools/gridbench.py [coils] [slices] [kb fast|exact] [reps]"""
 import ctypes, os, sys, time
+os_env_ = __import__("os").environ; os_env_.setdefault("TRON_TUNING", "1")   # the library reads TRON_* switches only under TRON_TUNING=1
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tron_amd import lib

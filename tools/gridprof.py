@@ -5,6 +5,7 @@ Needs a -DTRON_BIN_PROFILE build of the gridding kernel copied over tron_amd/lib
 Prints shader-clock cycles per wave and phase (tron_grid_binned.hip: PROF_MARK slots), TRON_DUAL_STREAM=0 so that the
 gridding kernel runs alone."""
 import ctypes, os, sys
+os_env_ = __import__("os").environ; os_env_.setdefault("TRON_TUNING", "1")   # the library reads TRON_* switches only under TRON_TUNING=1
 import numpy as np
 os.environ.setdefault("TRON_DUAL_STREAM", "0")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -2,6 +2,7 @@
 upload of the spoke stream + gridding recon + download of the images, pageable host memory as the `tron` binary uses.
 usage: python tools/hostbench.py [coils] [slices]"""
 import os, sys, time
+os_env_ = __import__("os").environ; os_env_.setdefault("TRON_TUNING", "1")   # the library reads TRON_* switches only under TRON_TUNING=1
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tron_amd import lib

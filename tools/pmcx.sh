@@ -1,6 +1,7 @@
 #!/bin/bash
 # usage (on the GPU box): tools/pmcx.sh <outdir> "<counters of pass 1>" ["<counters of pass 2>" ...] -- <python script + args...>
 # ad-hoc counter passes (one rocprofv3 --pmc run each) with per-kernel sums; `rocprofv3 --list-avail` names the counters
+export TRON_TUNING=1   # the library reads TRON_* switches only under TRON_TUNING=1
 R=$GRAFT_REPO_ROOT; out=$R/gpurun_out/$1; shift; mkdir -p $out; cd /tmp; export TMPDIR=/tmp
 passes=(); while [ "$1" != "--" ]; do passes+=("$1"); shift; done; shift
 i=0

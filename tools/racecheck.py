@@ -1,6 +1,7 @@
 """Determinism / race screen for the gridding kernels (tooling): runs the adjoint several times on the
 metric shape and compares output bits between runs and against the order-preserving gather kernel."""
 import ctypes, hashlib, os, sys
+os_env_ = __import__("os").environ; os_env_.setdefault("TRON_TUNING", "1")   # the library reads TRON_* switches only under TRON_TUNING=1
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tron_amd import lib

@@ -1,5 +1,6 @@
 #!/bin/bash
 # prints VGPR / SGPR / scratch / occupancy per kernel of a HIP source (tooling)
+export TRON_TUNING=1   # the library reads TRON_* switches only under TRON_TUNING=1
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude --offload-arch=gfx950 -Rpass-analysis=kernel-resource-usage -c "$1" -o /tmp/resusage.o 2>&1 \
  | grep -E "Function Name|VGPRs:|ScratchSize|Occupancy|LDS Size|TotalSGPRs" \
  | sed -E 's/^.*remark: +//; s/ \[-Rpass.*$//' \

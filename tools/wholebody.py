@@ -2,6 +2,7 @@
 (498 180 184 B incl. header, the size the reference's LFS pointer declares), `tron -v -u 0.4 -d 21 -a -G`
 (src/RUNME3_tron_grid_all.sh:10) -> 956 slices.  Prints file sizes and wall times (tooling)."""
 import os, subprocess, sys, time
+os_env_ = __import__("os").environ; os_env_.setdefault("TRON_TUNING", "1")   # the library reads TRON_* switches only under TRON_TUNING=1
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -210,6 +210,71 @@ extern "C" int ra_write(ra_t *a, const char *path)
     return rc;
 }
 
+// Streaming: the header alone (the file is created / truncated to it), then ranges of the payload at their own offsets --
+// what the `tron` driver uses to read spokes while the GPU plan is built and to write images while later slices are computed.
+extern "C" uint64_t ra_data_offset(const ra_t *a)
+{
+    return (6 + a->ndims) * sizeof(uint64_t);
+}
+
+extern "C" int ra_write_header(const ra_t *a, const char *path)
+{
+    const int fd = open(path, O_WRONLY | O_TRUNC | O_CREAT, 0644);
+    if (fd == -1) {
+        fprintf(stderr, "unable to open %s for writing: %s\n", path, strerror(errno));
+        return errno ? errno : EX_CANTCREAT;
+    }
+    const uint64_t head[6] = {RA_MAGIC_NUMBER, a->flags, a->eltype, a->elbyte, a->size, a->ndims};
+    int rc = write_all(fd, head, sizeof(head));
+    if (!rc) rc = write_all(fd, a->dims, a->ndims * sizeof(uint64_t));
+    if (close(fd) != 0 && !rc) rc = errno;
+    if (rc) fprintf(stderr, "RawArray: short write to %s: %s\n", path, strerror(rc));
+    return rc;
+}
+
+extern "C" int ra_read_range(const char *path, uint64_t data_offset, uint64_t first, uint64_t count, void *dst)
+{
+    const int fd = open(path, O_RDONLY);
+    if (fd == -1) {
+        fprintf(stderr, "unable to open %s for reading: %s\n", path, strerror(errno));
+        return errno ? errno : EX_NOINPUT;
+    }
+    int rc = 0;
+    uint8_t *q = static_cast<uint8_t *>(dst);
+    uint64_t done = 0;
+    while (done < count && !rc) {
+        const uint64_t want = count - done < RA_MAX_BYTES ? count - done : RA_MAX_BYTES;
+        const ssize_t n = pread(fd, q + done, want, (off_t)(data_offset + first + done));
+        if (n < 0) { if (errno == EINTR) continue; rc = errno; }
+        else if (n == 0) rc = EX_IOERR;
+        else done += (uint64_t)n;
+    }
+    close(fd);
+    if (rc) fprintf(stderr, "RawArray: cannot read %llu bytes at offset %llu of %s\n", (unsigned long long)count, (unsigned long long)first, path);
+    return rc;
+}
+
+extern "C" int ra_write_range(const char *path, uint64_t data_offset, uint64_t first, uint64_t count, const void *src)
+{
+    const int fd = open(path, O_WRONLY);
+    if (fd == -1) {
+        fprintf(stderr, "unable to open %s for writing: %s\n", path, strerror(errno));
+        return errno ? errno : EX_CANTCREAT;
+    }
+    int rc = 0;
+    const uint8_t *q = static_cast<const uint8_t *>(src);
+    uint64_t done = 0;
+    while (done < count && !rc) {
+        const uint64_t want = count - done < RA_MAX_BYTES ? count - done : RA_MAX_BYTES;
+        const ssize_t n = pwrite(fd, q + done, want, (off_t)(data_offset + first + done));
+        if (n < 0) { if (errno == EINTR) continue; rc = errno; }
+        else done += (uint64_t)n;
+    }
+    if (close(fd) != 0 && !rc) rc = errno;
+    if (rc) fprintf(stderr, "RawArray: short write to %s: %s\n", path, strerror(rc));
+    return rc;
+}
+
 extern "C" void ra_free(ra_t *a)
 {
     if (!a) return;

@@ -350,7 +350,7 @@ static hipError_t launch_degrid_tile_cpb(const DegridParams &p, int kb_mode, hip
 template <int CW>
 static hipError_t launch_degrid_tile_cw(const DegridParams &p, int kb_mode, hipStream_t s)
 {
-    static const int force = getenv("TRON_DEGRID_CPB") ? atoi(getenv("TRON_DEGRID_CPB")) : 0;   // tuning knob
+    static const int force = tuning_env("TRON_DEGRID_CPB") ? atoi(tuning_env("TRON_DEGRID_CPB")) : 0;   // tuning knob
     if (force == 2) return launch_degrid_tile_cpb<2, CW>(p, kb_mode, s);
     if (force == 1) return launch_degrid_tile_cpb<1, CW>(p, kb_mode, s);
     if (p.nrep >= 4) return launch_degrid_tile_cpb<4, CW>(p, kb_mode, s);

@@ -679,7 +679,7 @@ grid_arc_kernel(const GridParams p)
 }
 
 #ifdef TRON_ARC_PROFILE
-extern "C" int tron_debug_arc_profile(unsigned long long *out, int n)   // reads and clears the phase clock
+extern "C" __attribute__((visibility("default"))) int tron_debug_arc_profile(unsigned long long *out, int n)   // reads and clears the phase clock
 {
     static unsigned long long h[kArcProfCopies * kArcProfSlots];
     if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(h, HIP_SYMBOL(g_arc_prof), sizeof(h)) != hipSuccess) return 1;

@@ -781,7 +781,7 @@ static hipError_t launch_binned_cw(const GridParams &p, int half_in, hipStream_t
         return launch_binned_cpb<2, CW>(p, half_in, s);
     }
     const int nc = p.nchan - p.coil0;
-    static const int force = getenv("TRON_GRID_CPB") ? atoi(getenv("TRON_GRID_CPB")) : 0;   // tuning knob
+    static const int force = tuning_env("TRON_GRID_CPB") ? atoi(tuning_env("TRON_GRID_CPB")) : 0;   // tuning knob
     if (force == 8) return launch_binned_cpb<8, CW>(p, half_in, s);
     if (force == 6) return launch_binned_cpb<6, CW>(p, half_in, s);
     if (force == 4) return launch_binned_cpb<4, CW>(p, half_in, s);
@@ -825,7 +825,7 @@ hipError_t launch_grid_reduce(const GridParams &p, hipStream_t s)
 }
 
 #ifdef TRON_BIN_PROFILE
-extern "C" int tron_debug_grid_profile(unsigned long long *out, int n)   // reads and clears the phase clock
+extern "C" __attribute__((visibility("default"))) int tron_debug_grid_profile(unsigned long long *out, int n)   // reads and clears the phase clock
 {
     static unsigned long long h[kProfCopies * kProfSlots];
     if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(h, HIP_SYMBOL(g_bin_prof), sizeof(h)) != hipSuccess) return 1;

@@ -13,6 +13,10 @@ namespace tron {
 // records a printf-style message as the calling thread's last error and returns `code`
 int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 
+// Tuning / debugging switches of the library are read from the environment ONLY when TRON_TUNING=1 is set
+// as well: a library caller's behaviour does not depend on stray TRON_* variables.
+const char *tuning_env(const char *name);
+
 float grid_spoke_angle(int pe, int npe, int skip, int golden);
 float degrid_spoke_angle(int pe, int npe, int skip, int golden);
 size_t trig_table_size(const tron_config &cfg, const tron_dims &d);

@@ -3,6 +3,9 @@
 // compiled-out MULTI_GPU branch, src/tron.cu:582-597,735-736).
 #include "tron_plan_impl.h"
 
+#include <pthread.h>
+#include <sched.h>
+
 using namespace tron;
 
 // Adjoint of slices [zfirst, zfirst+zcount) from host memory: h_in_block points at the first spoke of slice zfirst's
@@ -30,11 +33,13 @@ static int adjoint_block(tron_plan *p, tron_float2 *h_out_block, const void *h_i
     if (!p->stream_down) HIP_TRY(hipStreamCreateWithFlags(&p->stream_down, hipStreamNonBlocking));
     const unsigned char *src = reinterpret_cast<const unsigned char *>(h_in_block);
     tron_float2 *dst = h_out_block;
-    // Pinning the caller's buffers makes the copies truly asynchronous (and the two directions concurrent); it
-    // costs a page walk of the whole range, so it is opt-in (cfg.pin_host / TRON_PIN_HOST=1): pageable copies are
-    // staged by the runtime at the same PCIe rate and still overlap the kernels of the previous chunk.
+    // Pinning the caller's buffers makes the copies truly asynchronous (and the two directions concurrent): the default
+    // (cfg.pin_host = 1, as the reference pins its output, src/tron.cu:967; TRON_PIN_HOST=0 under TRON_TUNING=1 turns it off).
+    // It costs a page walk of the whole range per call, so calls that move less than kPinThreshold bytes skip it:
+    // pageable copies are staged by the runtime at the same PCIe rate and still overlap the kernels of the previous chunk.
+    constexpr size_t kPinThreshold = (size_t)8 << 20;
     bool pinned_in = false, pinned_out = false;
-    if (p->pin_host) {
+    if (p->pin_host && in_bytes + out_bytes >= kPinThreshold) {
         pinned_in = hipHostRegister(const_cast<unsigned char *>(src), in_bytes, hipHostRegisterDefault) == hipSuccess;
         pinned_out = hipHostRegister(dst, out_bytes, hipHostRegisterDefault) == hipSuccess;
         (void)hipGetLastError();
@@ -139,6 +144,22 @@ extern "C" int tron_recon_radial2d_block(tron_plan *p, tron_float2 *h_out_block,
     return adjoint_block(p, h_out_block, h_in_block, zfirst, zcount);
 }
 
+// NUMA: binds the calling thread to the CPUs of the NUMA node the device hangs off (sysfs: the PCI function's numa_node, the
+// node's cpulist).  Best effort: no node information (or a single-node host) leaves the thread where it is.
+static void pin_thread_near_device(int device)
+{
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess) { (void)hipGetLastError(); return; }
+    int cpus[4096];
+    const int n = tron_host_numa_cpulist("/sys", bus, cpus, 4096);
+    if (n <= 0) return;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    for (int i = 0; i < n; ++i)
+        if (cpus[i] >= 0 && cpus[i] < CPU_SETSIZE) CPU_SET(cpus[i], &set);
+    (void)pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
+}
+
 // One host worker thread and one plan per device, contiguous slice blocks written straight into the caller's output:
 // the reference's compiled-out MULTI_GPU round-robin (src/tron.cu:582-597,735-736) made contiguous; no inter-GPU traffic.
 extern "C" int tron_recon_radial2d_multi(const tron_config *cfg, const tron_dims *dims, const int *devices, int n_devices,
@@ -158,7 +179,8 @@ extern "C" int tron_recon_radial2d_multi(const tron_config *cfg, const tron_dims
     const int workers = (cfg->adjoint && nz > 1) ? std::min(n_devices, nz) : 1;   // a forward run is one image
     std::vector<int> rcs(workers, TRON_OK);
     std::vector<std::string> msgs(workers);
-    // the workers' slice blocks share spokes (windows overlap) and pages: pin both buffers ONCE, visible to every device
+    // the workers' slice blocks share spokes (windows overlap) and pages: pin both buffers ONCE -- hipHostRegisterPortable makes
+    // the registration visible to every device's context, whichever device is current here
     bool pinned_in = false, pinned_out = false;
     const size_t in_bytes = (size_t)dims->in_elems * (cfg->input_half ? 4 : 8);
     if (cfg->pin_host && workers > 1) {
@@ -171,12 +193,12 @@ extern "C" int tron_recon_radial2d_multi(const tron_config *cfg, const tron_dims
         tron_config c = *cfg;
         c.device = devs[g];
         if (workers > 1) c.pin_host = 0;
+        if (workers > 1) pin_thread_near_device(devs[g]);        // the worker feeds its GPU from the host buffer: run on that GPU's socket
+        const int z0 = (int)((long long)g * nz / workers), z1 = (int)((long long)(g + 1) * nz / workers);
         tron_plan *plan = nullptr;
-        int rc = tron_plan_create(&plan, &c, dims);
-        if (rc == TRON_OK) {
-            const int z0 = (int)((long long)g * nz / workers), z1 = (int)((long long)(g + 1) * nz / workers);
-            rc = tron_recon_radial2d_range(plan, h_out, h_in, z0, z1 - z0);
-        }
+        // a plan for this worker's block only: batches, work buffers and run tables sized for z1 - z0 slices
+        int rc = plan_create_share(&plan, &c, dims, c.adjoint ? z0 : 0, c.adjoint ? z1 - z0 : std::max(nz, 1));
+        if (rc == TRON_OK) rc = tron_recon_radial2d_range(plan, h_out, h_in, z0, z1 - z0);
         if (rc != TRON_OK) msgs[g] = tron_last_error();          // the message lives in this worker's thread-local slot
         tron_plan_destroy(plan);
         rcs[g] = rc;

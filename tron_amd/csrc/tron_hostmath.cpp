@@ -7,10 +7,13 @@
 // Build with -ffp-contract=off and without fast-math.
 #include <math.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <ctype.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
+#include <string>
 #include <vector>
 
 #include "../../include/tron_hip.h"
@@ -147,6 +150,12 @@ void build_deapod_table_rect(int rows, int cols, float kernwidth, float sigma, f
         float wgt = kb_hat(x * (1.f / rows / sigma), kernwidth) * kb_hat(y * (1.f / cols / sigma), kernwidth);
         inv_weight[id] = 1.0f / (wgt > 0.f ? wgt : 1.f);
     }
+}
+
+const char *tuning_env(const char *name)
+{
+    static const bool on = [] { const char *t = getenv("TRON_TUNING"); return t && atoi(t) != 0; }();
+    return on ? getenv(name) : nullptr;
 }
 
 // Density compensation constants, src/tron.cu:408-409
@@ -464,6 +473,46 @@ extern "C" int tron_host_trig_table(const tron_config *cfg, const tron_dims *dim
     if (n > trig_table_size(*cfg, *dims)) return tron::fail(TRON_ERR_INVALID, "tron_host_trig_table: table has only %zu entries", trig_table_size(*cfg, *dims));
     build_trig_table(*cfg, *dims, cos_sin, n);
     return TRON_OK;
+}
+
+// CPUs of the NUMA node a PCI function sits on, from a sysfs tree: <sysroot>/bus/pci/devices/<bus id>/numa_node names the
+// node, <sysroot>/devices/system/node/node<N>/cpulist its CPUs ("0-31,64-95").  Returns how many CPUs were written, 0 when
+// the node is unknown (-1 in numa_node: single-node hosts, VMs), -1 on malformed input.  (tron_recon_radial2d_multi pins each
+// per-GPU worker thread with it; a separate entry point so that the parsing is testable against a fake tree.)
+extern "C" int tron_host_numa_cpulist(const char *sysroot, const char *pci_bus_id, int *cpus, int max_cpus)
+{
+    if (!sysroot || !pci_bus_id || !cpus || max_cpus < 1) return -1;
+    std::string id(pci_bus_id);
+    for (char &ch : id) ch = (char)tolower((unsigned char)ch);     // sysfs spells the bus id in lower case
+    auto slurp = [](const std::string &path, std::string &out) {
+        FILE *f = fopen(path.c_str(), "r");
+        if (!f) return false;
+        char buf[4096];
+        const size_t n = fread(buf, 1, sizeof(buf) - 1, f);
+        fclose(f);
+        buf[n] = 0;
+        out = buf;
+        return true;
+    };
+    std::string text;
+    if (!slurp(std::string(sysroot) + "/bus/pci/devices/" + id + "/numa_node", text)) return 0;
+    const int node = atoi(text.c_str());
+    if (node < 0) return 0;
+    if (!slurp(std::string(sysroot) + "/devices/system/node/node" + std::to_string(node) + "/cpulist", text)) return 0;
+    int n = 0;
+    const char *q = text.c_str();
+    while (*q) {
+        while (*q == ',' || *q == ' ' || *q == '\n') ++q;
+        if (!*q) break;
+        if (*q < '0' || *q > '9') return -1;
+        char *end = nullptr;
+        long a = strtol(q, &end, 10), b = a;
+        q = end;
+        if (*q == '-') { b = strtol(q + 1, &end, 10); if (end == q + 1) return -1; q = end; }
+        if (b < a) return -1;
+        for (long c = a; c <= b && n < max_cpus; ++c) cpus[n++] = (int)c;
+    }
+    return n;
 }
 
 extern "C" int tron_host_band_table(int nxos, float kernwidth, uint32_t *band)

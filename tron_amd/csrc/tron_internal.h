@@ -5,6 +5,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include "tron_host.h"
+
 namespace tron {
 
 constexpr int kTile = 16;          // Cartesian tile edge owned by one workgroup (gridding)

@@ -17,6 +17,8 @@
 #include <time.h>
 #include <unistd.h>
 
+#include <algorithm>
+#include <atomic>
 #include <thread>
 #include <vector>
 
@@ -107,8 +109,6 @@ int main(int argc, char *argv[])
 
 #define VPRINT(...) do { if (cfg.verbose) printf(__VA_ARGS__); } while (0)
 
-    // The header decides every dimension, so the payload is read by a helper thread while this thread brings up
-    // the GPU (runtime initialisation + plan: work buffers, tables) -- the two cost about the same.
     VPRINT("Reading %s\n", infile);
     ra_t hdr;
     if (ra_read_header(&hdr, infile) != 0) return 1;
@@ -143,16 +143,50 @@ int main(int argc, char *argv[])
 
     struct timespec t0, t1, tp;
     clock_gettime(CLOCK_MONOTONIC, &t0);
+    auto since = [](const struct timespec &a) {
+        struct timespec b;
+        clock_gettime(CLOCK_MONOTONIC, &b);
+        return (b.tv_sec - a.tv_sec) + 1e-9 * (b.tv_nsec - a.tv_nsec);
+    };
+    const uint64_t in_off = (6 + 5) * sizeof(uint64_t);                        // header of a 5-dimensional array
+    const uint64_t in_bytes = dims.in_elems * (cfg.input_half ? 4 : 8);
     ra_t in;
-    int read_rc = 0;
+    memset(&in, 0, sizeof(in));
+    in.eltype = RA_TYPE_COMPLEX;
+    in.elbyte = cfg.input_half ? 4 : 8;
+    in.ndims = 5;
+    in.size = in_bytes;
+    in.dims = static_cast<uint64_t *>(malloc(5 * sizeof(uint64_t)));
+    in.data = static_cast<uint8_t *>(malloc(in_bytes ? in_bytes : 1));
+    if (!in.dims || !in.data) {
+        fprintf(stderr, "unable to allocate memory for data\n");
+        return 1;
+    }
+    memcpy(in.dims, hdr_dims, 5 * sizeof(uint64_t));
+    // The payload is read by a helper thread in pieces, in file order, while this thread brings up the GPU (runtime
+    // initialisation + plan: work buffers, tables); `ready` = bytes of the payload that are in memory.  The adjoint then
+    // runs block by block as soon as a block's spokes are in, and a second helper writes each finished block of images
+    // while the next one is computed (src/tron.cu:890, 967-982 read everything, compute everything, write everything).
+    std::atomic<uint64_t> ready(0);
+    std::atomic<int> read_rc(0);
     double read_s = 0.0;
     std::thread reader([&]() {
-        struct timespec a0, a1;
+        struct timespec a0;
         clock_gettime(CLOCK_MONOTONIC, &a0);
-        read_rc = ra_read(&in, infile);
-        clock_gettime(CLOCK_MONOTONIC, &a1);
-        read_s = (a1.tv_sec - a0.tv_sec) + 1e-9 * (a1.tv_nsec - a0.tv_nsec);
+        const uint64_t piece = (uint64_t)32 << 20;
+        for (uint64_t done = 0; done < in_bytes;) {
+            const uint64_t n = std::min(piece, in_bytes - done);
+            const int rc = ra_read_range(infile, in_off, done, n, in.data + done);
+            if (rc) { read_rc = rc; break; }
+            done += n;
+            ready.store(done, std::memory_order_release);
+        }
+        read_s = since(a0);
     });
+    auto wait_for = [&](uint64_t bytes) {
+        while (ready.load(std::memory_order_acquire) < bytes && read_rc.load() == 0) usleep(200);
+        return read_rc.load() == 0;
+    };
 
     ra_t out;
     memset(&out, 0, sizeof(out));
@@ -168,30 +202,21 @@ int main(int argc, char *argv[])
     if (!(out.dims && out.data)) rc = TRON_ERR_NOMEM;
     else if (!multi_gpu) rc = tron_plan_create(&plan, &cfg, &dims);        // multi-GPU: every worker creates its own plan
     clock_gettime(CLOCK_MONOTONIC, &tp);
-    reader.join();
+    const double plan_s = (tp.tv_sec - t0.tv_sec) + 1e-9 * (tp.tv_nsec - t0.tv_nsec);
     if (!out.dims || !out.data) {
+        reader.join();
         fprintf(stderr, "tron: cannot allocate %llu bytes for the output\n", (unsigned long long)dims.out_bytes);
         return 1;
     }
-    if (read_rc != 0) {
+    memcpy(out.dims, dims.out_dims, 5 * sizeof(uint64_t));
+    if (!wait_for(std::min<uint64_t>(in_bytes, 16))) {
+        reader.join();
         tron_plan_destroy(plan);
+        ra_free(&in);
         ra_free(&out);
         return 1;
     }
-    {   // the file was opened a second time by the reader thread: it must still be the array the header promised
-        bool same = in.ndims == 5 && in.eltype == RA_TYPE_COMPLEX && in.elbyte == (cfg.input_half ? 4u : 8u)
-                    && in.size / (cfg.input_half ? 4 : 8) >= dims.in_elems;
-        for (int i = 0; same && i < 5; ++i) same = in.dims[i] == hdr_dims[i];
-        if (!same) {
-            fprintf(stderr, "tron: %s changed between reading its header and its payload\n", infile);
-            tron_plan_destroy(plan);
-            ra_free(&in);
-            ra_free(&out);
-            return 1;
-        }
-    }
-    memcpy(out.dims, dims.out_dims, 5 * sizeof(uint64_t));
-    VPRINT("Read time: %.3f s (overlapped with) plan time: %.3f s\n", read_s, (tp.tv_sec - t0.tv_sec) + 1e-9 * (tp.tv_nsec - t0.tv_nsec));
+    VPRINT("Plan time: %.3f s (the payload is being read meanwhile)\n", plan_s);
     if (!cfg.input_half) {
         const float *f = reinterpret_cast<const float *>(in.data);
         VPRINT("Sanity check: indata[0] = %f + %f i\n", f[0], f[1]);
@@ -201,28 +226,83 @@ int main(int argc, char *argv[])
     VPRINT("WARNING: Assuming square Cartesian dimensions for now.\n");
 
     VPRINT("Running reconstruction ...\n ");
-    if (rc == TRON_OK && multi_gpu)
-        rc = tron_recon_radial2d_multi(&cfg, &dims, gpu_list.empty() ? nullptr : gpu_list.data(), (int)gpu_list.size(),
-                                       reinterpret_cast<tron_float2 *>(out.data), reinterpret_cast<const tron_float2 *>(in.data));
-    else if (rc == TRON_OK)
-        rc = tron_recon_radial2d(plan, reinterpret_cast<tron_float2 *>(out.data), reinterpret_cast<const tron_float2 *>(in.data));
+    double write_s = 0.0;
+    bool streamed = false;
+    int wrc = 0;
+    if (rc == TRON_OK && !multi_gpu && cfg.adjoint && dims.nz > 1) {
+        // ---- streamed: blocks of slices, each started when its spokes have been read, each written when it is done ----
+        streamed = true;
+        const uint64_t out_off = ra_data_offset(&out);
+        wrc = ra_write_header(&out, outfile);
+        const size_t spoke_bytes = (size_t)dims.nro * dims.nc * dims.nt * (cfg.input_half ? 4 : 8);
+        const size_t img_bytes = (size_t)dims.nt * dims.nx * dims.ny * sizeof(tron_float2);
+        const int nblocks = std::max(1, std::min(16, dims.nz / 48));
+        std::atomic<int> blocks_done(0);
+        std::atomic<bool> stop(false);
+        std::thread writer([&]() {
+            struct timespec w0;
+            for (int k = 0; k < nblocks && wrc == 0; ++k) {
+                while (blocks_done.load(std::memory_order_acquire) <= k && !stop.load()) usleep(200);
+                if (blocks_done.load(std::memory_order_acquire) <= k) break;
+                clock_gettime(CLOCK_MONOTONIC, &w0);
+                const int z0 = (int)((long long)k * dims.nz / nblocks), z1 = (int)((long long)(k + 1) * dims.nz / nblocks);
+                wrc = ra_write_range(outfile, out_off, (uint64_t)z0 * img_bytes, (uint64_t)(z1 - z0) * img_bytes, out.data + (size_t)z0 * img_bytes);
+                write_s += since(w0);
+            }
+        });
+        for (int k = 0; k < nblocks && rc == TRON_OK; ++k) {
+            const int z0 = (int)((long long)k * dims.nz / nblocks), z1 = (int)((long long)(k + 1) * dims.nz / nblocks);
+            const uint64_t need = ((uint64_t)(z1 - 1) * dims.prof_slide + dims.npe1work) * spoke_bytes;
+            if (need > in_bytes) {     // the library reports the out-of-range window with the reference's wording
+                rc = tron_recon_radial2d(plan, reinterpret_cast<tron_float2 *>(out.data), reinterpret_cast<const tron_float2 *>(in.data));
+                break;
+            }
+            if (!wait_for(need)) { rc = TRON_ERR_INVALID; break; }
+            rc = tron_recon_radial2d_block(plan, reinterpret_cast<tron_float2 *>(out.data + (size_t)z0 * img_bytes),
+                                           in.data + (size_t)z0 * dims.prof_slide * spoke_bytes, z0, z1 - z0);
+            if (rc == TRON_OK) blocks_done.store(k + 1, std::memory_order_release);
+        }
+        stop = true;
+        writer.join();
+        reader.join();
+    } else {
+        reader.join();
+        if (read_rc.load() != 0) rc = rc == TRON_OK ? TRON_ERR_INVALID : rc;
+        if (rc == TRON_OK && multi_gpu)
+            rc = tron_recon_radial2d_multi(&cfg, &dims, gpu_list.empty() ? nullptr : gpu_list.data(), (int)gpu_list.size(),
+                                           reinterpret_cast<tron_float2 *>(out.data), reinterpret_cast<const tron_float2 *>(in.data));
+        else if (rc == TRON_OK)
+            rc = tron_recon_radial2d(plan, reinterpret_cast<tron_float2 *>(out.data), reinterpret_cast<const tron_float2 *>(in.data));
+    }
+    if (read_rc.load() != 0) {
+        tron_plan_destroy(plan);
+        ra_free(&in);
+        ra_free(&out);
+        return 1;
+    }
     if (rc != TRON_OK) {
         fprintf(stderr, "tron: %s\n", tron_last_error());
         tron_plan_destroy(plan);
         ra_free(&in);
         ra_free(&out);
+        if (streamed) unlink(outfile);
         return rc == TRON_ERR_UNSUPPORTED ? 2 : 1;
     }
     tron_plan_destroy(plan);
     clock_gettime(CLOCK_MONOTONIC, &t1);
+    VPRINT("Read time: %.3f s (beside the plan and the first blocks)\n", read_s);
     VPRINT("Elapsed time: %.2f s\n", (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec));
 
     VPRINT("Saving result to %s\n", outfile);
-    struct timespec tr0, tr1;
-    clock_gettime(CLOCK_MONOTONIC, &tr0);
-    rc = ra_write(&out, outfile);
-    clock_gettime(CLOCK_MONOTONIC, &tr1);
-    VPRINT("Write time: %.3f s\n", (tr1.tv_sec - tr0.tv_sec) + 1e-9 * (tr1.tv_nsec - tr0.tv_nsec));
+    if (streamed) {
+        rc = wrc;
+        VPRINT("Write time: %.3f s (beside the reconstruction, block by block)\n", write_s);
+    } else {
+        struct timespec tr0;
+        clock_gettime(CLOCK_MONOTONIC, &tr0);
+        rc = ra_write(&out, outfile);
+        VPRINT("Write time: %.3f s\n", since(tr0));
+    }
     VPRINT("Cleaning up.\n");
     ra_free(&in);
     ra_free(&out);

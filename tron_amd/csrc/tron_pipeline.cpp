@@ -28,6 +28,7 @@ int get_fft(tron_plan *p, int batch, int inverse, FftPlan **out)
     auto key = std::make_pair(batch, inverse);
     auto it = p->fft.find(key);
     if (it == p->fft.end()) {
+        std::call_once(g_fft_once, [] { rocfft_setup(); });
         FftPlan f;
         const size_t lengths[2] = {(size_t)p->d.nxos, (size_t)p->d.nyos};      // fastest (columns) first; square except non-square forward plans
         // cufftPlan2d / cufftPlanMany of src/tron.cu:205-220: unnormalised C2C; CUFFT_INVERSE (+i)
@@ -221,7 +222,8 @@ int adjoint_run_raw(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, 
                     g.split_slots = p->d_split_slots;
                     g.partial = p->d_partial;
                 }
-                if (p->arc && p->relief_entries > 0 && vs <= 1 && (reinterpret_cast<uintptr_t>(g.nudata) & 15) == 0) {
+                if (p->arc && p->relief_entries > 0 && vs <= 1 && (reinterpret_cast<uintptr_t>(g.nudata) & 15) == 0
+                    && (!golden || (zfirst + z0 >= p->share_z0 && zfirst + z0 + cz <= p->share_z0 + p->share_nz))) {
                     // the inner tile's parts (binned kernel), every other tile (arc kernel), then the parts are added on
                     GridParams gi = g;
                     gi.tile_entries = p->relief_parts;
@@ -234,7 +236,7 @@ int adjoint_run_raw(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, 
                     } else {
                         HIP_TRY(launch_grid_binned(gi, p->cfg.input_half, st));
                     }
-                    const size_t win0 = golden ? (size_t)(zfirst + z0) : 0;
+                    const size_t win0 = golden ? (size_t)(zfirst + z0 - p->share_z0) : 0;     // the run tables start at the plan's first slice
                     g.arc_hdr = p->d_arc_hdr + win0 * (size_t)(d.nxos / kBinnedTile) * (d.nxos / kBinnedTile);
                     g.arc_ent = p->d_arc_ent + win0 * p->arc_cap;
                     g.arc_ephi = p->d_arc_ephi + win0 * p->arc_cap;
@@ -305,8 +307,6 @@ int adjoint_run_raw(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, 
 // coilcombinesos / coilcombinewalsh (src/tron.cu:764,766) of `cz` slices of coil images [z][nchan*id + c]
 int combine_coils(tron_plan *p, float2 *d_out, const float2 *d_coil, int cz)
 {
-    if (p->cfg.coil_combine == 1 && p->d.nc > 16)
-        return fail(TRON_ERR_UNSUPPORTED, "Walsh coil combination handles up to 16 coils (nc=%d)", p->d.nc);
     HIP_TRY(launch_coil_combine(d_out, d_coil, p->d.nx, p->d.nc, p->d.nt, p->cfg.coil_combine == 1 ? 1 : 0,
                                 std::max(0, p->cfg.walsh_patch), cz, p->stream));
     return TRON_OK;

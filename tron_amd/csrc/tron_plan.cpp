@@ -13,6 +13,8 @@
 // (The pipelines themselves live in tron_pipeline.cpp, the host-buffer entry points in tron_hostio.cpp.)
 #include "tron_plan_impl.h"
 
+#include <time.h>
+
 namespace tron {
 
 static thread_local std::string g_last_error;
@@ -31,9 +33,9 @@ int fail(int code, const char *fmt, ...)
 
 using namespace tron;
 
-namespace {
-std::once_flag g_fft_once;
-}  // namespace
+namespace tron {
+std::once_flag g_fft_once;   // rocfft_setup() on the first rocFFT plan (get_fft): the fused 512 / 256 path never pays for it
+}  // namespace tron
 
 extern "C" const char *tron_last_error(void) { return g_last_error.c_str(); }
 
@@ -42,8 +44,22 @@ extern "C" const char *tron_version(void) { return "tronhip 0.1 (gfx950)"; }
 extern "C" int tron_plan_create(tron_plan **out, const tron_config *cfg, const tron_dims *dims)
 {
     if (!out || !cfg || !dims) return fail(TRON_ERR_INVALID, "tron_plan_create: null argument");
+    return tron::plan_create_share(out, cfg, dims, 0, dims->nz);
+}
+
+int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_dims *dims, int share_z0, int share_nz)
+{
+    if (!out || !cfg || !dims) return fail(TRON_ERR_INVALID, "tron_plan_create: null argument");
     *out = nullptr;
     const tron_dims &d = *dims;
+    if (share_z0 < 0 || share_nz < 0 || share_z0 + share_nz > std::max(d.nz, 1))
+        return fail(TRON_ERR_INVALID, "slice share [%d,%d) outside [0,%d)", share_z0, share_z0 + share_nz, d.nz);
+    // coil combination (src/tron.cu:764-766): fail here, not after the first batch has been queued
+    if (cfg->coil_combine != 0 && cfg->coil_combine != 1)
+        return fail(TRON_ERR_INVALID, "coil_combine %d: 0 (root sum of squares) or 1 (Walsh)", cfg->coil_combine);
+    if (cfg->coil_combine == 1 && (d.nc > 16 || cfg->walsh_patch < 0 || cfg->walsh_patch > 16))
+        return fail(TRON_ERR_UNSUPPORTED, "Walsh coil combination handles up to 16 coils and patch half-widths 0..16 (nc=%d, walsh_patch=%d)",
+                    d.nc, cfg->walsh_patch);
     if (cfg->niter < 0 || (cfg->niter > 0 && cfg->input_half))
         return fail(TRON_ERR_UNSUPPORTED, "-i %d: CGNR needs niter >= 0 and complex64 k-space", cfg->niter);
     if (d.nt < 1 || d.nc < 1 || (long long)d.nc * d.nt > 4096)
@@ -61,13 +77,19 @@ extern "C" int tron_plan_create(tron_plan **out, const tron_config *cfg, const t
         return fail(TRON_ERR_INVALID, "readout index would leave the spoke (nro=%d nxos=%d)", d.nro, d.nxos);
     if (cfg->input_half && !cfg->adjoint)
         return fail(TRON_ERR_UNSUPPORTED, "half-precision input is only defined for the adjoint (k-space) direction");
+    struct timespec pt0;
+    clock_gettime(CLOCK_MONOTONIC, &pt0);
+    auto since = [&pt0]() {
+        struct timespec b;
+        clock_gettime(CLOCK_MONOTONIC, &b);
+        return (b.tv_sec - pt0.tv_sec) + 1e-9 * (b.tv_nsec - pt0.tv_nsec);
+    };
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (cfg->device < 0 || cfg->device >= ndev)
         return fail(TRON_ERR_HIP, "device %d requested but %d HIP device(s) present", cfg->device, ndev);
     HIP_TRY(hipSetDevice(cfg->device));
     (void)hipGetLastError();       // a stale error of an earlier, failed call must not be reported by this one
-    std::call_once(g_fft_once, [] { rocfft_setup(); });
     // make every code object resident before anything is queued on a non-blocking stream
     HIP_TRY(warm_kernels());
     HIP_TRY(warm_grid_binned());
@@ -76,10 +98,13 @@ extern "C" int tron_plan_create(tron_plan **out, const tron_config *cfg, const t
     HIP_TRY(warm_degrid_tile());
     HIP_TRY(warm_cgnr());
     HIP_TRY(hipDeviceSynchronize());
+    const double t_runtime = since();                // HIP runtime + code objects (the first plan of a process pays for both)
 
     tron_plan *p = new tron_plan();
     p->cfg = *cfg;
     p->d = d;
+    p->share_z0 = share_z0;
+    p->share_nz = cfg->adjoint ? std::max(share_nz, 1) : 1;
     p->nchan = d.nc * d.nt;
     p->beta = kb_beta(cfg->kernwidth);
     p->kb_mode = cfg->kb_mode == TRON_KB_FAST ? TRON_KB_FAST : TRON_KB_EXACT;
@@ -90,19 +115,20 @@ extern "C" int tron_plan_create(tron_plan **out, const tron_config *cfg, const t
 
     const size_t n2 = (size_t)d.nxos * d.nyos;
     const size_t per_unit = (size_t)p->nchan * n2 * sizeof(float2);
-    int units = cfg->adjoint ? d.nz : 1;
+    int units = cfg->adjoint ? p->share_nz : 1;
     // The heaviest tile (the k-space centre, crossed by every spoke) is one wave's serial work, so a
     // launch needs enough slices in flight to cover that critical path: batch up to 1 GiB of grid.
     // ... or 64 slices when the coils are many (still at most 6 GiB of grid: 288 GB of HBM make that cheap)
     size_t auto_chunk = std::max<size_t>(1, ((size_t)2 << 30) / per_unit);   // (2 GiB: 128 slices x 8 coils; +5 % over 64-slice launches with the arc kernel)
     if (auto_chunk < 64) auto_chunk = std::max<size_t>(auto_chunk, std::min<size_t>(64, ((size_t)6 << 30) / per_unit));
     int chunk = cfg->chunk_slices > 0 ? cfg->chunk_slices : (int)std::max<size_t>(1, auto_chunk);
-    if (const char *env = getenv("TRON_CHUNK_SLICES")) chunk = std::max(1, atoi(env));
+    if (const char *env = tuning_env("TRON_CHUNK_SLICES")) chunk = std::max(1, atoi(env));
     p->chunk = std::max(1, std::min(chunk, std::max(units, 1)));
     p->chunk_cap = std::max(p->chunk, std::min(std::max(units, 1), p->chunk + p->chunk / 2));
     if (!cfg->adjoint) p->chunk = p->chunk_cap = std::max(1, chunk);
 
     int rc = TRON_OK;
+    double t_arc0 = 0.0, t_arc1 = 0.0;
     auto bail = [&](int code) { tron_plan_destroy(p); return code; };
     if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess)
         return bail(fail(TRON_ERR_HIP, "hipStreamCreate failed"));
@@ -128,17 +154,17 @@ extern "C" int tron_plan_create(tron_plan **out, const tron_config *cfg, const t
         p->ntiles = (int)order.size();
         if ((rc = upload(&p->d_tile_order, order.data(), order.size() * sizeof(int)))) return bail(rc);
         p->binned = p->kb_mode == TRON_KB_FAST && cfg->kernwidth <= 3.f;
-        if (const char *gk = getenv("TRON_GRID_KERNEL")) p->binned = p->binned && strcmp(gk, "gather") != 0;
+        if (const char *gk = tuning_env("TRON_GRID_KERNEL")) p->binned = p->binned && strcmp(gk, "gather") != 0;
         if (p->binned) {
             std::vector<int> sorder, slots;
             int target = 2500;                                            // records per workgroup and image
-            if (const char *e = getenv("TRON_SPLIT_TARGET")) target = std::max(64, atoi(e));
+            if (const char *e = tuning_env("TRON_SPLIT_TARGET")) target = std::max(64, atoi(e));
             p->max_parts = 8;
             build_split_tile_order(d.nxos, kBinnedTile, d.npe1work, cfg->kernwidth, target, p->max_parts, sorder, slots);
             p->split_entries = (int)sorder.size();
             p->nsplit_slots = (int)slots.size();
             p->split_below = 64;                                          // launches of fewer slices use the split list
-            if (const char *e = getenv("TRON_SPLIT_BELOW")) p->split_below = atoi(e);
+            if (const char *e = tuning_env("TRON_SPLIT_BELOW")) p->split_below = atoi(e);
             if (p->nsplit_slots > 0) {
                 if ((rc = upload(&p->d_tile_order32_split, sorder.data(), sorder.size() * sizeof(int)))) return bail(rc);
                 if ((rc = upload(&p->d_split_slots, slots.data(), slots.size() * sizeof(int)))) return bail(rc);
@@ -146,7 +172,7 @@ extern "C" int tron_plan_create(tron_plan **out, const tron_config *cfg, const t
             // centre relief: the samples next to the k-space centre get workgroups of their own (tron_grid_binned.hip)
             std::vector<int> rorder, rslots;
             int r0 = 0;
-            const char *re = getenv("TRON_CENTRE_RELIEF");
+            const char *re = tuning_env("TRON_CENTRE_RELIEF");
             if (!(re && atoi(re) == 0) && build_centre_relief_order(d.nxos, kBinnedTile, d.npe1work, cfg->kernwidth, 8, r0, rorder, rslots)) {
                 p->relief_entries = (int)rorder.size();
                 p->relief_parts = (rslots[0] >> 20) & 15;
@@ -154,23 +180,26 @@ extern "C" int tron_plan_create(tron_plan **out, const tron_config *cfg, const t
                 if ((rc = upload(&p->d_tile_order32_relief, rorder.data(), rorder.size() * sizeof(int)))) return bail(rc);
                 if ((rc = upload(&p->d_relief_slots, rslots.data(), rslots.size() * sizeof(int)))) return bail(rc);
             }
+            t_arc0 = since();
+            t_arc1 = t_arc0;
             // arc kernel: everything but the inner tile, when the trajectory and the sample layout allow it
             p->arc = p->relief_entries > 0 && grid_arc_supported(p->nchan, d.nxos, d.nro, d.npe1work, cfg->kernwidth, cfg->input_half);
-            if (const char *gk = getenv("TRON_GRID_KERNEL")) p->arc = p->arc && strcmp(gk, "binned") != 0;
+            if (const char *gk = tuning_env("TRON_GRID_KERNEL")) p->arc = p->arc && strcmp(gk, "binned") != 0;
             if (p->arc) {
                 // plan-time pass: every window's spokes sorted by line angle (host), clipped against every tile and dealt
                 // into batches (arc_prep_kernel); the sorted lists are scratch
-                const size_t nwin = cfg->golden_angle ? (size_t)std::max(d.nz, 1) : 1;
+                const size_t nwin = cfg->golden_angle ? (size_t)p->share_nz : 1;
+                const size_t win_first = cfg->golden_angle ? (size_t)p->share_z0 : 0;
                 const int npe = d.npe1work, nt32 = (d.nxos / kBinnedTile) * (d.nxos / kBinnedTile);
                 std::vector<float> trig(2 * p->ntrig);
                 build_trig_table(*cfg, d, trig.data(), p->ntrig);
                 std::vector<unsigned short> order(nwin * npe);
                 std::vector<float> phi(nwin * npe);
-                build_arc_tables(trig.data(), nwin, (size_t)d.prof_slide, npe, order.data(), phi.data());
+                build_arc_tables(trig.data() + 2 * win_first * (size_t)d.prof_slide, nwin, (size_t)d.prof_slide, npe, order.data(), phi.data());
                 std::vector<float> scs(2 * order.size());
                 for (size_t w = 0; w < nwin; ++w)
                     for (int k = 0; k < npe; ++k) {
-                        const size_t src = (cfg->golden_angle ? w * (size_t)d.prof_slide : 0) + order[w * npe + k];
+                        const size_t src = (cfg->golden_angle ? (win_first + w) * (size_t)d.prof_slide : 0) + order[w * npe + k];
                         scs[2 * (w * npe + k)] = trig[2 * src];
                         scs[2 * (w * npe + k) + 1] = trig[2 * src + 1];
                     }
@@ -219,16 +248,17 @@ extern "C" int tron_plan_create(tron_plan **out, const tron_config *cfg, const t
                 p->arc_zper = 0;                                    // 0: by launch size (tron_pipeline.cpp)
                 // the inner tile's workgroups are few and slow (every spoke passes the k-space centre): on a stream of their own,
                 // most urgent, they run beside the arc kernel instead of in front of it
-                if (const char *e = getenv("TRON_ARC_INNER_STREAM")) p->inner_beside = atoi(e) != 0;
+                if (const char *e = tuning_env("TRON_ARC_INNER_STREAM")) p->inner_beside = atoi(e) != 0;
                 int lo = 0, hi = 0;
                 hipDeviceGetStreamPriorityRange(&lo, &hi);
                 if (hipStreamCreateWithPriority(&p->stream_inner, hipStreamNonBlocking, hi) != hipSuccess ||
                     hipEventCreateWithFlags(&p->ev_inner[0], hipEventDisableTiming) != hipSuccess ||
                     hipEventCreateWithFlags(&p->ev_inner[1], hipEventDisableTiming) != hipSuccess)
                     return bail(fail(TRON_ERR_HIP, "cannot create the inner-tile stream"));
-                if (const char *e = getenv("TRON_ARC_ZPER")) p->arc_zper = std::max(0, atoi(e));
+                if (const char *e = tuning_env("TRON_ARC_ZPER")) p->arc_zper = std::max(0, atoi(e));
             }
         }
+        if (p->binned) t_arc1 = since();
         std::vector<float> dea((size_t)d.nx * d.nx);
         build_deapod_table(d.nx, cfg->kernwidth, cfg->gridos, dea.data());        // src/tron.cu:635
         if ((rc = upload(&p->d_deapod, dea.data(), dea.size() * sizeof(float)))) return bail(rc);
@@ -254,10 +284,10 @@ extern "C" int tron_plan_create(tron_plan **out, const tron_config *cfg, const t
     }
     unsigned int zero = 0;
     if (!p->d_errflag && (rc = upload(&p->d_errflag, &zero, sizeof(zero)))) return bail(rc);
-    p->poison = getenv("TRON_POISON_GRID") != nullptr;   // tests: NaN-fill the work grid so a read of a never-written point shows up
+    p->poison = tuning_env("TRON_POISON_GRID") != nullptr;   // tests: NaN-fill the work grid so a read of a never-written point shows up
     if (d.nxos == 512 && d.nx == 256 && d.nyos == 512 && d.ny == 256) {
         p->fft512 = true;
-        if (const char *ff = getenv("TRON_FFT")) p->fft512 = strcmp(ff, "rocfft") != 0;
+        if (const char *ff = tuning_env("TRON_FFT")) p->fft512 = strcmp(ff, "rocfft") != 0;
     }
     if (p->fft512) {
         std::vector<float> tw(2 * 512);
@@ -269,13 +299,13 @@ extern "C" int tron_plan_create(tron_plan **out, const tron_config *cfg, const t
         // Two lanes (gridding on `stream`, FFT passes on `stream2`, two Cartesian buffers): round 1 measured +2 % and left
         // it off; with the round-2 FFT passes it is +4.9 % at 8 coils x 256 slices (+2.7 % at 6 coils, +2 % at 4, 0 at 1),
         // so adjoint plans with at least two full batches and more than one channel have it on.  TRON_DUAL_STREAM=0/1 overrides.
-        p->dual = cfg->adjoint && p->nchan > 1 && d.nz >= 2 * p->chunk;
-        if (const char *ds = getenv("TRON_DUAL_STREAM")) p->dual = d.nz > 1 && atoi(ds) != 0;
+        p->dual = cfg->adjoint && p->nchan > 1 && p->share_nz >= 2 * p->chunk;
+        if (const char *ds = tuning_env("TRON_DUAL_STREAM")) p->dual = d.nz > 1 && atoi(ds) != 0;
         if (p->dual) {
             // TRON_CU_SPLIT=k: give the (HBM-bound) FFT lane every k-th CU and the (VALU/LDS-bound) gridding lane
             // the rest, so the two overlap in space instead of queueing behind each other
             int split = 0;
-            if (const char *cs = getenv("TRON_CU_SPLIT")) split = atoi(cs);
+            if (const char *cs = tuning_env("TRON_CU_SPLIT")) split = atoi(cs);
             if (split >= 2) {
                 uint32_t mask_fft[8], mask_grid[8];
                 for (int w = 0; w < 8; ++w) { mask_fft[w] = 0; mask_grid[w] = 0; }
@@ -294,7 +324,7 @@ extern "C" int tron_plan_create(tron_plan **out, const tron_config *cfg, const t
                 // gridding lane frees instead of queueing behind its backlog (TRON_FFT_PRIO: 0 = same priority)
                 int lo = 0, hi = 0, prio = 0;
                 hipDeviceGetStreamPriorityRange(&lo, &hi);          // lo = least urgent (numerically greatest), hi = most urgent
-                const char *fp = getenv("TRON_FFT_PRIO");
+                const char *fp = tuning_env("TRON_FFT_PRIO");
                 const int want = fp ? atoi(fp) : -1;                // -1: most urgent, +1: least urgent
                 prio = want < 0 ? hi : (want > 0 ? lo : 0);
                 if (hipStreamCreateWithPriority(&p->stream2, hipStreamNonBlocking, prio) != hipSuccess)
@@ -306,8 +336,10 @@ extern "C" int tron_plan_create(tron_plan **out, const tron_config *cfg, const t
                     return bail(fail(TRON_ERR_HIP, "cannot create pipeline events"));
         }
     }
+    const double t_tables = since();
     // adjoint: the whole batch now (an out-of-memory plan fails here, not mid-run); forward: on first use, sized by the call
     if (cfg->adjoint && (rc = ensure_work(p, p->chunk_cap))) return bail(rc);
+    const double t_work = since();
     if (!p->fft512) {   // rocFFT plans for the batch sizes this plan will certainly see: no plan creation (and device
         FftPlan *f = nullptr;       // synchronisation) in the middle of the first pipeline
         if ((rc = get_fft(p, (cfg->adjoint ? std::min(p->chunk, std::max(d.nz, 1)) : 1) * p->nchan, cfg->adjoint ? 1 : 0, &f))) return bail(rc);
@@ -317,16 +349,19 @@ extern "C" int tron_plan_create(tron_plan **out, const tron_config *cfg, const t
                cfg->device, cfg->adjoint ? "adjoint" : "forward", p->nchan, d.nxos, d.nx, d.npe1work, p->chunk,
                p->kb_mode == TRON_KB_FAST ? "fast" : "exact");
         printf("tronhip: fast Kaiser-Bessel polynomial max relative error %.2e\n", p->kb_poly_err);
+        printf("tronhip: gridding kernel: %s\n", tron_plan_grid_kernel_name(p));
+        printf("tronhip: plan %.3f s = HIP runtime + code objects %.3f, tables %.3f (of which the arc kernel's run tables %.3f), work buffers %.3f\n",
+               since(), t_runtime, t_tables - t_runtime, t_arc1 - t_arc0, t_work - t_tables);
     }
-    if (const char *se = getenv("TRON_SYNC_EACH")) p->sync_each = atoi(se) != 0;
+    if (const char *se = tuning_env("TRON_SYNC_EACH")) p->sync_each = atoi(se) != 0;
     p->debug_skip = 0;
-    if (const char *dbg = getenv("TRON_DEBUG_SKIP")) p->debug_skip = atoi(dbg);
-    p->degrid_simple = getenv("TRON_DEGRID_SIMPLE") != nullptr;
-    if (const char *sp = getenv("TRON_SLICES_PER_PASS")) p->slices_per_pass = atoi(sp) != 0;
-    if (const char *lp = getenv("TRON_GRID_LDS_PAD")) p->grid_lds_pad = atoi(lp);
-    p->no_disc = getenv("TRON_NO_DISC") != nullptr;
+    if (const char *dbg = tuning_env("TRON_DEBUG_SKIP")) p->debug_skip = atoi(dbg);
+    p->degrid_simple = tuning_env("TRON_DEGRID_SIMPLE") != nullptr;
+    if (const char *sp = tuning_env("TRON_SLICES_PER_PASS")) p->slices_per_pass = atoi(sp) != 0;
+    if (const char *lp = tuning_env("TRON_GRID_LDS_PAD")) p->grid_lds_pad = atoi(lp);
+    p->no_disc = tuning_env("TRON_NO_DISC") != nullptr;
     p->pin_host = cfg->pin_host != 0;
-    if (const char *ph = getenv("TRON_PIN_HOST")) p->pin_host = atoi(ph) != 0;
+    if (const char *ph = tuning_env("TRON_PIN_HOST")) p->pin_host = atoi(ph) != 0;
     *out = p;
     return TRON_OK;
 }
@@ -386,6 +421,14 @@ extern "C" int tron_plan_destroy(tron_plan *p)
     if (p->stream) hipStreamDestroy(p->stream);
     delete p;
     return TRON_OK;
+}
+
+extern "C" const char *tron_plan_grid_kernel_name(const tron_plan *p)
+{
+    if (!p || !p->cfg.adjoint) return "";
+    if (p->arc) return "grid_arc_kernel (+ grid_binned_kernel on the inner tile, grid_reduce_parts_kernel)";
+    if (p->binned) return p->relief_entries > 0 ? "grid_binned_kernel (+ grid_reduce_parts_kernel)" : "grid_binned_kernel";
+    return "grid_tile_kernel";
 }
 
 extern "C" int tron_plan_sync(tron_plan *p)

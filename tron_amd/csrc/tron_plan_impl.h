@@ -25,6 +25,8 @@
 
 namespace tron {
 
+extern std::once_flag g_fft_once;
+
 #define HIP_TRY(expr)                                                                           \
     do {                                                                                        \
         hipError_t e_ = (expr);                                                                 \
@@ -54,6 +56,7 @@ struct tron_plan {
     tron_config cfg;
     tron_dims d;
     int nchan = 0;
+    int share_z0 = 0, share_nz = 0;   // the slices this plan will be asked for (a per-GPU worker's block; the whole volume otherwise)
     int kb_mode = TRON_KB_EXACT;
     int chunk = 1;                 // slices (adjoint) or images (forward) per batch
     hipStream_t stream = nullptr;
@@ -166,6 +169,10 @@ int upload(T **dptr, const void *host, size_t bytes)
     if (bytes) HIP_TRY(hipMemcpy(*dptr, host, bytes, hipMemcpyHostToDevice));
     return TRON_OK;
 }
+
+// tron_plan.cpp: a plan that will only ever run slices [z0, z0 + zcount) (tron_recon_radial2d_multi's per-GPU workers):
+// batch sizes, work buffers and the arc kernel's run tables are sized for that block
+int plan_create_share(tron_plan **out, const tron_config *cfg, const tron_dims *dims, int z0, int zcount);
 
 // tron_pipeline.cpp
 int drain_timers(tron_plan *p);

@@ -32,20 +32,39 @@ def rank_env(rank: int, world: int, port: int, base=None) -> dict:
     return env
 
 
-def spawn_ranks(argv, world: int, timeout=None):
+DEFAULT_TIMEOUT_S = 1800.0   # a run that has not finished by then is ended (gloo's own rendezvous timeout is 30 minutes too)
+
+
+def spawn_ranks(argv, world: int, timeout=DEFAULT_TIMEOUT_S, attempts=3):
     """Starts `world` children running ``python argv...`` with RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set.
     Returns (exit_code, rank0_stdout): exit_code is 0 only if EVERY rank exited 0; rank 0's stdout is
-    captured (not forwarded) so the caller can decide to print it only for a complete run."""
+    captured (not forwarded) so the caller can decide to print it only for a complete run.
+    The rendezvous port is picked by binding and closing a socket, so another process can take it before rank 0 binds it:
+    a run whose rank 0 dies with "address already in use" is started again on a fresh port (up to `attempts` times)."""
+    code, out = 1, ""
+    for _ in range(max(1, attempts)):
+        code, out, err0 = _spawn_once(argv, world, timeout)
+        if code == 0 or not any(t in err0 for t in ("EADDRINUSE", "Address already in use", "address already in use")):
+            if err0:
+                sys.stderr.write(err0)
+            break
+    return code, out
+
+
+def _spawn_once(argv, world: int, timeout):
     port = free_port()
     procs = []
     for r in range(world):
         procs.append(subprocess.Popen([sys.executable] + list(argv), env=rank_env(r, world, port),
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
+                                      stderr=subprocess.PIPE if r == 0 else None, text=True))
     import threading
     import time
-    out0_parts = []
+    out0_parts, err0_parts = [], []
     reader = threading.Thread(target=lambda: out0_parts.append(procs[0].stdout.read()), daemon=True)
     reader.start()
+    ereader = threading.Thread(target=lambda: err0_parts.append(procs[0].stderr.read()), daemon=True)
+    ereader.start()
     code = 0
     deadline = None if timeout is None else time.monotonic() + timeout
     try:
@@ -69,7 +88,8 @@ def spawn_ranks(argv, world: int, timeout=None):
                 p.kill()
             p.wait()
     reader.join(timeout=10)
-    return code, (out0_parts[0] if out0_parts else "")
+    ereader.join(timeout=10)
+    return code, (out0_parts[0] if out0_parts else ""), (err0_parts[0] if err0_parts else "")
 
 
 class HostGroup:

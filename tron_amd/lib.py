@@ -55,11 +55,11 @@ EXPORTS = [
     "tron_config_default", "tron_derive_dims", "tron_plan_create", "tron_plan_destroy",
     "tron_recon_radial2d", "tron_recon_radial2d_range", "tron_recon_radial2d_block", "tron_recon_radial2d_multi", "tron_nufft_adj_radial2d", "tron_cgnr_radial2d", "tron_nufft_radial2d",
     "tron_precompensate", "tron_gridradial2d", "tron_degridradial2d", "tron_plan_sync",
-    "tron_plan_timing", "tron_plan_timing_get", "tron_plan_timing_reset", "tron_plan_two_lanes",
-    "tron_host_trig_table", "tron_host_band_table", "tron_host_deapod_table",
+    "tron_plan_timing", "tron_plan_timing_get", "tron_plan_timing_reset", "tron_plan_two_lanes", "tron_plan_grid_kernel_name",
+    "tron_host_trig_table", "tron_host_band_table", "tron_host_deapod_table", "tron_host_numa_cpulist",
     "tron_device_count", "tron_device_malloc", "tron_device_free", "tron_memcpy_h2d", "tron_memcpy_d2h",
     "tron_last_error", "tron_version",
-    "ra_read", "ra_write", "ra_free", "ra_query", "ra_reshape", "ra_convert", "ra_squash", "ra_diff", "ra_read_header",
+    "ra_read", "ra_write", "ra_free", "ra_query", "ra_reshape", "ra_convert", "ra_squash", "ra_diff", "ra_read_header", "ra_data_offset", "ra_write_header", "ra_read_range", "ra_write_range",
     "ra_float_to_half_bits", "ra_half_to_float_bits", "ra_double_to_half_bits", "ra_half_to_double_bits",
 ]
 
@@ -101,6 +101,8 @@ def load():
     sig("tron_degridradial2d", i, [p, p, p])
     sig("tron_plan_sync", i, [p])
     sig("tron_plan_two_lanes", i, [p, i, ctypes.POINTER(i)])
+    sig("tron_plan_grid_kernel_name", ctypes.c_char_p, [p])
+    sig("tron_host_numa_cpulist", i, [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(i), i])
     sig("tron_plan_timing", i, [p, i])
     sig("tron_plan_timing_get", i, [p, i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)])
     sig("tron_plan_timing_reset", i, [p])
@@ -269,6 +271,10 @@ class Plan:
     def sync(self):
         check(load().tron_plan_sync(self._h))
 
+    def grid_kernel_name(self) -> str:
+        """Which gridding kernels this plan launches (bench.py's roofline line, the traffic captures)."""
+        return load().tron_plan_grid_kernel_name(self._h).decode()
+
     def two_lanes(self, enable=True) -> bool:
         """Serialise (False) or restore (True) the gridding || FFT overlap; returns whether the plan has a second lane."""
         had = ctypes.c_int(0)
@@ -288,11 +294,20 @@ class Plan:
 
 
 def recon_multi(data: np.ndarray, adjoint: bool, devices=None, n_devices=0, **flags):
-    """``recon`` over several GPUs inside this process (= tron_recon_radial2d_multi): one worker thread + plan per device."""
-    data = np.asfortranarray(data, dtype=np.complex64)
-    flat = data.reshape(-1, order="F")
-    cfg = default_config(adjoint=int(adjoint), **flags)
-    dims = derive_dims(cfg, data.shape)
+    """``recon`` over several GPUs inside this process (= tron_recon_radial2d_multi): one worker thread + plan per device.
+    input_half=1 takes a float16 array shaped (2, nc, nt, nro, npe1, npe2) like ``recon``."""
+    half = flags.pop("input_half", 0)
+    if half:
+        if data.dtype != np.float16 or data.shape[0] != 2:
+            raise ValueError("input_half=1 needs a float16 array whose first axis is (re, im)")
+        shape = data.shape[1:]
+        flat = np.asfortranarray(data).reshape(-1, order="F")
+    else:
+        data = np.asfortranarray(data, dtype=np.complex64)
+        shape = data.shape
+        flat = data.reshape(-1, order="F")
+    cfg = default_config(adjoint=int(adjoint), input_half=int(half), **flags)
+    dims = derive_dims(cfg, shape)
     out = np.zeros(dims.out_bytes // 8, np.complex64)
     devs = None
     if devices is not None:
