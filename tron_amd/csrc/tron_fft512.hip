@@ -107,6 +107,10 @@ struct Fft512Params {
     const float *inv_deapod; // 256*256
     int nchan, nslices;
     int rzero2;              // pass 1: elements with X^2 + Y^2 > rzero2 are known zeros and are not loaded (<= 0: load all)
+    // uncombined output (CGNR, Walsh, nt > 1): pass 2 runs per coil image and writes out[slice][nchan * (row * 256 + col) + c],
+    // times `scale`; `partial` (may be null): [slice][nchan * column blocks] sums of |out|^2, one per workgroup
+    float scale;
+    double *partial;
 };
 
 // cropped index of kept output k (k < 128 or k >= 384), cf. post_kernel: mr = (row + w - n/2 + n) % n
@@ -265,9 +269,13 @@ __global__ void __launch_bounds__(256) fft512_rows_kernel(const Fft512Params p)
 // LPW = columns per wave (4 LPW per workgroup).  A 64-slice launch has 16 x 64 = 1 024 workgroups of 16 columns = exactly
 // the 4 per CU that fit; launches of fewer slices use 8 or 4 columns per workgroup so that the chip is still full (a
 // 32-slice launch at 16 columns left half of it idle: 7 % of `bench.py --slices 32`).
-template <bool SINGLE, int LPW>
+// COILS: one coil image per workgroup (grid.x = column blocks x coils), complex output interleaved by coil.  The coils of one
+// column block get workgroup ids 8 apart -- the same XCD, close in time -- so that XCD's L2 merges their 8-byte pieces of a
+// pixel's nchan * 8 bytes before they reach HBM.
+template <bool SINGLE, int LPW, bool COILS = false>
 __global__ void __launch_bounds__(256, 4) fft512_cols_post_kernel(const Fft512Params p)
 {
+    static_assert(!COILS || SINGLE, "uncombined output keeps the complex value");
     constexpr int kCols = 4 * LPW;
     constexpr int kTileElems = kFKeep * (kCols + 1);       // [kept row][col in block], +1 pad
     constexpr int kLdsElems = kTileElems > 4 * kXch + 4 * kF ? kTileElems : 4 * kXch + 4 * kF;
@@ -275,7 +283,11 @@ __global__ void __launch_bounds__(256, 4) fft512_cols_post_kernel(const Fft512Pa
     __shared__ float2 s_tw[kF];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int z = blockIdx.y;
-    const int col0 = blockIdx.x * kCols;
+    // COILS: blockIdx.x = (column block & 7) | coil << 3 | (column block >> 3) * 8 nchan
+    const int coil = COILS ? (int)((blockIdx.x >> 3) % (unsigned)p.nchan) : 0;
+    const int cblk = COILS ? (int)((blockIdx.x & 7u) + 8u * (blockIdx.x / (8u * (unsigned)p.nchan))) : (int)blockIdx.x;
+    const int col0 = cblk * kCols;
+    const int nloop = COILS ? 1 : p.nchan;
     float2 *xch = s_t + wave * kXch;
     float2 *lbuf = s_t + 4 * kXch + wave * kF;
     float val[LPW][4];
@@ -287,7 +299,7 @@ __global__ void __launch_bounds__(256, 4) fft512_cols_post_kernel(const Fft512Pa
             val[j][jj] = 0.f;
             if (SINGLE) single[j][jj] = make_float2(0.f, 0.f);
         }
-    const float2 *base = p.in + (size_t)z * p.nchan * (size_t)kFKeep * kF + (size_t)(col0 + wave * LPW) * kF;
+    const float2 *base = p.in + ((size_t)z * p.nchan + coil) * (size_t)kFKeep * kF + (size_t)(col0 + wave * LPW) * kF;
     auto copy_line = [&](const float2 *line) {
         // the intermediate is written once by pass 1 and read once here: streaming (non-temporal) accesses on both sides
 #pragma unroll
@@ -302,7 +314,7 @@ __global__ void __launch_bounds__(256, 4) fft512_cols_post_kernel(const Fft512Pa
     copy_line(base);
     for (int i = threadIdx.x; i < kF; i += 256) s_tw[i] = p.tw[i];
     __syncthreads();
-    for (int c = 0; c < p.nchan; ++c) {
+    for (int c = 0; c < nloop; ++c) {
 #pragma unroll
         for (int j = 0; j < LPW; ++j) {
             float2 v[8];
@@ -311,7 +323,7 @@ __global__ void __launch_bounds__(256, 4) fft512_cols_post_kernel(const Fft512Pa
             for (int q = 0; q < 8; ++q) v[q] = lbuf[q * 64 + lane];
             {
                 const int jn = (j + 1) % LPW, cn = c + (j == LPW - 1 ? 1 : 0);
-                if (cn < p.nchan) {
+                if (cn < nloop) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the buffer has been read
                     copy_line(base + (size_t)cn * kFKeep * kF + (size_t)jn * kF);
                 }
@@ -327,18 +339,39 @@ __global__ void __launch_bounds__(256, 4) fft512_cols_post_kernel(const Fft512Pa
         }
     }
     __syncthreads();                                       // every wave is done with its exchange region and line buffer
+    double nrm = 0.0;
 #pragma unroll
     for (int j = 0; j < LPW; ++j)
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
             const int j2 = jj < 2 ? jj : jj + 4;
             const int rowc = crop_index(lane + 64 * j2);
-            const float inv = p.inv_deapod[rowc * kFKeep + col0 + wave * LPW + j];   // src/tron.cu:398-400
+            float inv = p.inv_deapod[rowc * kFKeep + col0 + wave * LPW + j];         // src/tron.cu:398-400
+            if (COILS) inv *= p.scale;
             const float2 o = SINGLE ? make_float2(single[j][jj].x * inv, single[j][jj].y * inv)     // src/tron.cu:259-266
                                     : make_float2(sqrtf(val[j][jj]) * inv, 0.f);
+            if (COILS) nrm += (double)o.x * o.x + (double)o.y * o.y;
             s_t[rowc * (kCols + 1) + wave * LPW + j] = o;
         }
     __syncthreads();
+    if (COILS) {
+        float2 *dst = p.out + (size_t)z * kFKeep * kFKeep * p.nchan + coil;
+        for (int e = threadIdx.x; e < kFKeep * kCols; e += 256) {
+            const int row = e / kCols, cc = e % kCols;
+            dst[((size_t)row * kFKeep + col0 + cc) * p.nchan] = s_t[row * (kCols + 1) + cc];
+        }
+        if (p.partial) {                                   // |out|^2 of this workgroup's share, summed in a fixed order
+            __syncthreads();
+            double *sm = reinterpret_cast<double *>(s_t);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) nrm += __shfl_down(nrm, o);
+            if (lane == 0) sm[wave] = nrm;
+            __syncthreads();
+            if (threadIdx.x == 0)
+                p.partial[((size_t)z * p.nchan + coil) * (kFKeep / kCols) + cblk] = ((sm[0] + sm[1]) + sm[2]) + sm[3];
+        }
+        return;
+    }
     float2 *dst = p.out + (size_t)z * kFKeep * kFKeep;
     for (int e = threadIdx.x; e < kFKeep * kCols; e += 256) {
         const int row = e / kCols, cc = e % kCols;
@@ -427,6 +460,7 @@ hipError_t launch_fft512_adjoint(const float2 *grid, float2 *tmp, float2 *out, c
     Fft512Params p;
     p.rzero2 = rzero > 0 ? rzero * rzero : 0;
     p.in = grid; p.tmp = tmp; p.out = out; p.tw = tw; p.inv_deapod = inv_deapod; p.nchan = nchan; p.nslices = nslices;
+    p.scale = 1.f; p.partial = nullptr;
     hipLaunchKernelGGL(fft512_rows_kernel, dim3(kF / kLinesPerWg, nslices * nchan), dim3(256), 0, s, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
@@ -448,6 +482,37 @@ hipError_t launch_fft512_adjoint(const float2 *grid, float2 *tmp, float2 *out, c
         else hipLaunchKernelGGL((fft512_cols_post_kernel<false, 1>), grid_c, dim3(256), 0, s, p);
     }
     return hipGetLastError();
+}
+
+// Uncombined variant: out[slice][nchan * (row * 256 + col) + c] = deapodised coil images times `scale`; partial (may be null)
+// receives fft512_coils_partials(nslices) sums of |out|^2 per slice, one per workgroup (CGNR's |ztilde|^2, src/tron.cu:695).
+int fft512_coils_partials(int nslices)
+{
+    const int lpw = nslices >= 64 ? 4 : (nslices >= 32 ? 2 : 1);
+    return kFKeep / (4 * lpw);                             // per coil
+}
+
+hipError_t launch_fft512_adjoint_coils(const float2 *grid, float2 *tmp, float2 *out, const float2 *tw, const float *inv_deapod, int rzero,
+                                       int nchan, int nslices, float scale, double *partial, hipStream_t s)
+{
+#ifdef TRON_FFT_COLS_NO_DMA
+    return hipErrorNotSupported;
+#else
+    Fft512Params p;
+    p.rzero2 = rzero > 0 ? rzero * rzero : 0;
+    p.in = grid; p.tmp = tmp; p.out = out; p.tw = tw; p.inv_deapod = inv_deapod; p.nchan = nchan; p.nslices = nslices;
+    p.scale = scale; p.partial = partial;
+    hipLaunchKernelGGL(fft512_rows_kernel, dim3(kF / kLinesPerWg, nslices * nchan), dim3(256), 0, s, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    p.in = tmp;
+    const int lpw = nslices >= 64 ? 4 : (nslices >= 32 ? 2 : 1);
+    const dim3 grid_c((kFKeep / (4 * lpw)) * nchan, nslices);       // column blocks (a multiple of 8) x coils
+    if (lpw == 4) hipLaunchKernelGGL((fft512_cols_post_kernel<true, 4, true>), grid_c, dim3(256), 0, s, p);
+    else if (lpw == 2) hipLaunchKernelGGL((fft512_cols_post_kernel<true, 2, true>), grid_c, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((fft512_cols_post_kernel<true, 1, true>), grid_c, dim3(256), 0, s, p);
+    return hipGetLastError();
+#endif
 }
 
 // ------------------------------------------------------------------------------------ forward head

@@ -131,10 +131,12 @@ hipError_t warm_degrid_tile();   // ... and of tron_degrid_tile.hip
 hipError_t warm_cgnr();          // ... and of tron_cgnr.hip
 // CGNR vector kernels (tron_cgnr.hip), batched over slices; per-slice scalars live on the device
 hipError_t launch_cg_scale_norm2(float2 *x, size_t n, int nslices, float scale, double *partial, hipStream_t s);
-hipError_t launch_cg_wnorm2(const float2 *v, size_t n, int nslices, int nchan, int nro, float a, float b, double *partial, hipStream_t s);
-hipError_t launch_cg_finish(const double *partial, double *num, float *coef, int mode, int nslices, hipStream_t s);
+hipError_t launch_cg_wnorm2(const float2 *v, size_t n, int nslices, int nchan, int nro, float a, float b, double *partial, int parts_cap,
+                            int *nparts, hipStream_t s);
+hipError_t launch_cg_windows(float2 *r, const float2 *y, size_t n, size_t hop, int nslices, hipStream_t s);
+hipError_t launch_cg_finish(const double *partial, int nparts, double *num, float *coef, int mode, int nslices, hipStream_t s);
 hipError_t launch_cg_axpy(float2 *y, const float2 *x, const float *coef, float sign, size_t n, int nslices, hipStream_t s);
-hipError_t launch_cg_xpby(float2 *pt, const float2 *zt, const float *coef, size_t n, int nslices, hipStream_t s);
+hipError_t launch_cg_update(float2 *x, float2 *pt, const float2 *zt, const float *alpha, const float *beta, size_t n, int nslices, int last, hipStream_t s);
 hipError_t launch_coil_combine(float2 *out, const float2 *coil, int nimg, int nc, int nt, int mode, int npatch, int nslices, hipStream_t s);
 constexpr int kCgPartials = 64;  // = kCgBlocks
 // tiled degridding (tron_degrid_tile.hip), W <= 3
@@ -143,6 +145,11 @@ hipError_t launch_degrid_tile(const DegridParams &p, int kb_mode, hipStream_t s)
 // rzero: grid points at integer radius > rzero hold zeros by construction and are not read (0 = read everything)
 hipError_t launch_fft512_adjoint(const float2 *grid, float2 *tmp, float2 *out, const float2 *tw, const float *inv_deapod, int rzero,
                                  int nchan, int nslices, hipStream_t s);
+// the same without coil combination: out[slice][nchan * (row * 256 + col) + c] = coil images * scale; partial (may be null):
+// fft512_coils_partials(nslices) * nchan sums of |out|^2 per slice (one per workgroup; summed in index order by cg_finish)
+hipError_t launch_fft512_adjoint_coils(const float2 *grid, float2 *tmp, float2 *out, const float2 *tw, const float *inv_deapod, int rzero,
+                                       int nchan, int nslices, float scale, double *partial, hipStream_t s);
+int fft512_coils_partials(int nslices);
 // fused pad + deapodise + shift + pruned forward FFT for nx = 256, nxos = 512 (tron_fft512.hip)
 hipError_t launch_fft512_forward(const float2 *img, float2 *tmp, float2 *out, const float2 *tw, const float *inv_deapod,
                                  int nchan, int nimg, hipStream_t s);

@@ -125,7 +125,7 @@ int ensure_work(tron_plan *p, int units)
 // defer_join: leave the FFT lane running when the call returns (device-resident entry point: the caller synchronises with
 // tron_plan_sync); the next call's first gridding launches then overlap this call's last FFT passes.
 int adjoint_run_raw(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, int zcount, int combine, int in_stride_spokes,
-                    bool defer_join)
+                    bool defer_join, float out_scale = 1.f, double *norm_partial = nullptr, int *norm_parts = nullptr)
 {
     const tron_dims &d = p->d;
     const size_t n2 = (size_t)d.nxos * d.nxos;
@@ -174,7 +174,7 @@ int adjoint_run_raw(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, 
         g.out_p = 1;
         g.out_shift = 1;
         // the fused FFT never reads beyond the sampled disc, so the gridding kernel need not store zeros there
-        const int rzero = (p->fft512 && combine && !p->no_disc) ? (int)floorf((float)(d.nxos / 2 - 1) + p->cfg.kernwidth) + 1 : 0;
+        const int rzero = (p->fft512 && !p->no_disc) ? (int)floorf((float)(d.nxos / 2 - 1) + p->cfg.kernwidth) + 1 : 0;
         g.skip_outside = rzero > 0 ? 1 : 0;
         {
             StageTimer t(p, STAGE_GRID, st);
@@ -278,6 +278,17 @@ int adjoint_run_raw(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, 
             if ((rc = stage_check(p, "fft512"))) return rc;
             continue;
         }
+        if (p->fft512) {
+            // fused, uncombined: pruned inverse FFT + crop + deapodise per coil image, interleaved by coil (CGNR, Walsh, nt > 1)
+            StageTimer t(p, STAGE_FFT, st_fft);
+            const int parts = fft512_coils_partials(cz) * p->nchan;
+            if (norm_parts) *norm_parts = parts;
+            HIP_TRY(launch_fft512_adjoint_coils(grid_buf, tmp_buf, static_cast<float2 *>(d_out) + (size_t)z0 * d.nx * d.nx * p->nchan,
+                                                p->d_tw512, p->d_deapod, rzero, p->nchan, cz, out_scale,
+                                                norm_partial ? norm_partial + (size_t)z0 * parts : nullptr, st_fft));
+            if ((rc = stage_check(p, "fft512 coils"))) return rc;
+            continue;
+        }
         rc = run_fft(p, p->d_grid, cz * p->nchan, 1);
         if (rc) return rc;
         if ((rc = stage_check(p, "fft"))) return rc;
@@ -316,10 +327,10 @@ int combine_coils(tron_plan *p, float2 *d_out, const float2 *d_coil, int cz)
 // tail; Walsh's adaptive combination and nt > 1 (channel = coil + nc*repetition) run it uncombined into a scratch
 // buffer and combine from there.
 int adjoint_run(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, int zcount, int combine, int in_stride_spokes,
-                bool defer_join)
+                bool defer_join, float out_scale, double *norm_partial, int *norm_parts)
 {
     if (!combine || (p->d.nt == 1 && p->cfg.coil_combine != 1))
-        return adjoint_run_raw(p, d_out, d_in_z0, zfirst, zcount, combine, in_stride_spokes, defer_join);
+        return adjoint_run_raw(p, d_out, d_in_z0, zfirst, zcount, combine, in_stride_spokes, defer_join, out_scale, norm_partial, norm_parts);
     const tron_dims &d = p->d;
     const size_t N = (size_t)p->nchan * d.nx * d.ny, elem = p->cfg.input_half ? 4 : 8;
     const int step = std::max(1, std::min(p->chunk, zcount));
@@ -420,7 +431,9 @@ int cgnr_run(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, int zco
     const size_t N = (size_t)p->nchan * d.nx * d.ny;                 // image-space elements per slice (F2)
     const size_t spoke_bytes = (size_t)d.nro * p->nchan * sizeof(float2);
     const int step = std::max(1, std::min(p->chunk, zcount));
-    if (p->cg_slices < step) {
+    // partial sums per slice: kCgPartials from the norm kernels, up to 64 column blocks x nchan from the fused FFT tail
+    const int parts_cap = std::max(kCgPartials, 64 * p->nchan);
+    if (p->cg_slices < step || p->cg_parts < parts_cap) {
         HIP_TRY(hipStreamSynchronize(p->stream));
         for (void *q : {(void *)p->d_cg_r, (void *)p->d_cg_v, (void *)p->d_cg_zt, (void *)p->d_cg_pt, (void *)p->d_cg_x,
                         (void *)p->d_cg_partial, (void *)p->d_cg_num, (void *)p->d_cg_coef})
@@ -432,26 +445,37 @@ int cgnr_run(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, int zco
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_cg_zt), step * N * sizeof(float2)));
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_cg_pt), step * N * sizeof(float2)));
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_cg_x), step * N * sizeof(float2)));
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_cg_partial), (size_t)step * kCgPartials * sizeof(double)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_cg_partial), (size_t)step * parts_cap * sizeof(double)));
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_cg_num), step * sizeof(double)));
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_cg_coef), step * sizeof(float)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_cg_coef), 2 * (size_t)step * sizeof(float)));
         p->cg_slices = step;
+        p->cg_parts = parts_cap;
     }
     const float unscale = (float)d.nxos * (float)d.npe1work;          // F3: the gridding kernel's 1/nxos/npe (src/tron.cu:532) divided out
     const int golden = p->cfg.golden_angle;
     hipStream_t st = p->stream;
+    float *alpha = p->d_cg_coef, *beta = p->d_cg_coef + p->cg_slices;
     int rc;
+    // ztilde = A^H W r, times `unscale`, and its squared norm per slice (mode 0: stored; mode 2: beta, :709).  On the fused
+    // 512 / 256 path the FFT tail scales and leaves the partial sums; otherwise one pass over ztilde does both.
+    auto residual_image = [&](int z0, int cz, int mode) -> int {
+        int parts = 0;
+        int r2 = adjoint_run(p, p->d_cg_zt, p->d_cg_r, zfirst + z0, cz, 0, d.npe1work, false, unscale, p->d_cg_partial, &parts);
+        if (r2) return r2;
+        if (parts == 0) {
+            HIP_TRY(launch_cg_scale_norm2(p->d_cg_zt, N, cz, unscale, p->d_cg_partial, st));
+            parts = kCgPartials;
+        }
+        HIP_TRY(launch_cg_finish(p->d_cg_partial, parts, p->d_cg_num, beta, mode, cz, st));
+        return TRON_OK;
+    };
     for (int z0 = 0; z0 < zcount; z0 += step) {
         const int cz = std::min(step, zcount - z0);
         const unsigned char *y = static_cast<const unsigned char *>(d_in_z0) + (size_t)z0 * d.prof_slide * spoke_bytes;
-        // r = y: the (overlapping) windows of the stream, one contiguous copy per slice (:685; F5)
-        for (int z = 0; z < cz; ++z)
-            HIP_TRY(hipMemcpyAsync(p->d_cg_r + (size_t)z * n, y + (size_t)z * d.prof_slide * spoke_bytes, n * sizeof(float2),
-                                   hipMemcpyDeviceToDevice, st));
+        // r = y: the (overlapping) windows of the stream, one contiguous copy per slice (:685; F5) -- one launch for the batch
+        HIP_TRY(launch_cg_windows(p->d_cg_r, reinterpret_cast<const float2 *>(y), n, (size_t)d.prof_slide * d.nro * p->nchan, cz, st));
         // ztilde = A^H W r (:686), ptilde = ztilde (:687), x = 0 (:683)
-        if ((rc = adjoint_run(p, p->d_cg_zt, p->d_cg_r, zfirst + z0, cz, 0, d.npe1work))) return rc;
-        HIP_TRY(launch_cg_scale_norm2(p->d_cg_zt, N, cz, unscale, p->d_cg_partial, st));
-        HIP_TRY(launch_cg_finish(p->d_cg_partial, p->d_cg_num, p->d_cg_coef, 0, cz, st));
+        if ((rc = residual_image(z0, cz, 0))) return rc;
         HIP_TRY(hipMemcpyAsync(p->d_cg_pt, p->d_cg_zt, cz * N * sizeof(float2), hipMemcpyDeviceToDevice, st));
         HIP_TRY(hipMemsetAsync(p->d_cg_x, 0, cz * N * sizeof(float2), st));
         // the forward operator's angles: the slice's own index range (F4); golden angles are shared with the adjoint's table
@@ -459,15 +483,18 @@ int cgnr_run(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, int zco
         const int trig_stride = golden ? d.prof_slide : 0;
         for (int t = 0; t < p->cfg.niter; ++t) {
             if ((rc = forward_run(p, p->d_cg_v, p->d_cg_pt, cz, trig, trig_stride, p->d_deapod_fwd))) return rc;   // v = A ptilde (:691)
-            HIP_TRY(launch_cg_wnorm2(p->d_cg_v, n, cz, p->nchan, d.nro, p->dcf_a, p->dcf_b, p->d_cg_partial, st));  // <W v, v> (:693,696)
-            HIP_TRY(launch_cg_finish(p->d_cg_partial, p->d_cg_num, p->d_cg_coef, 1, cz, st));                       // alpha (:697; F1)
-            HIP_TRY(launch_cg_axpy(p->d_cg_x, p->d_cg_pt, p->d_cg_coef, 1.f, N, cz, st));                            // x += alpha ptilde (:699)
-            if (t == p->cfg.niter - 1) break;                                                                       // (:701)
-            HIP_TRY(launch_cg_axpy(p->d_cg_r, p->d_cg_v, p->d_cg_coef, -1.f, n, cz, st));                           // r -= alpha v (:703)
-            if ((rc = adjoint_run(p, p->d_cg_zt, p->d_cg_r, zfirst + z0, cz, 0, d.npe1work))) return rc;            // ztilde = A^H W r (:707)
-            HIP_TRY(launch_cg_scale_norm2(p->d_cg_zt, N, cz, unscale, p->d_cg_partial, st));
-            HIP_TRY(launch_cg_finish(p->d_cg_partial, p->d_cg_num, p->d_cg_coef, 2, cz, st));                       // beta (:709; F1)
-            HIP_TRY(launch_cg_xpby(p->d_cg_pt, p->d_cg_zt, p->d_cg_coef, N, cz, st));                               // ptilde = ztilde + beta ptilde (:710)
+            // alpha = |ztilde|^2 / <W v, v> (:693-697; F1)
+            int wparts = 0;
+            HIP_TRY(launch_cg_wnorm2(p->d_cg_v, n, cz, p->nchan, d.nro, p->dcf_a, p->dcf_b, p->d_cg_partial, p->cg_parts, &wparts, st));
+            HIP_TRY(launch_cg_finish(p->d_cg_partial, wparts, p->d_cg_num, alpha, 1, cz, st));
+            if (t == p->cfg.niter - 1) {                                                                           // (:701)
+                HIP_TRY(launch_cg_update(p->d_cg_x, p->d_cg_pt, p->d_cg_zt, alpha, beta, N, cz, 1, st));            // x += alpha ptilde (:699)
+                break;
+            }
+            HIP_TRY(launch_cg_axpy(p->d_cg_r, p->d_cg_v, alpha, -1.f, n, cz, st));                                  // r -= alpha v (:703)
+            if ((rc = residual_image(z0, cz, 2))) return rc;                                                       // ztilde = A^H W r (:707), beta (:709; F1)
+            // x += alpha ptilde (:699) and ptilde = ztilde + beta ptilde (:710) in one pass over ptilde
+            HIP_TRY(launch_cg_update(p->d_cg_x, p->d_cg_pt, p->d_cg_zt, alpha, beta, N, cz, 0, st));
         }
         if (combine) {
             if ((rc = combine_coils(p, static_cast<float2 *>(d_out) + (size_t)z0 * d.nt * d.nx * d.ny, p->d_cg_x, cz))) return rc;        // (:764)

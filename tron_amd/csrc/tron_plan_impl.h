@@ -112,7 +112,8 @@ struct tron_plan {
     float2 *d_trig_fwd = nullptr;    // linear angles in the degridding kernel's own convention (src/tron.cu:555); null: share d_trig
     float2 *d_cg_r = nullptr, *d_cg_v = nullptr, *d_cg_zt = nullptr, *d_cg_pt = nullptr, *d_cg_x = nullptr;
     double *d_cg_partial = nullptr, *d_cg_num = nullptr;
-    float *d_cg_coef = nullptr;
+    float *d_cg_coef = nullptr;      // [2][cg_slices]: alpha, beta
+    int cg_parts = 0;                // partial sums per slice the buffer holds
     int cg_slices = 0;
     float2 *d_coil_tmp = nullptr;    // uncombined coil images of a batch (Walsh combination, nt > 1)
     int coil_tmp_slices = 0;
@@ -184,8 +185,10 @@ int ensure_work(tron_plan *p, int units);
 int ensure_buffer(void **buf, size_t *have, size_t want);
 int check_errflag(tron_plan *p);
 int combine_coils(tron_plan *p, float2 *d_out, const float2 *d_coil, int cz);
+// out_scale / norm_partial: uncombined output only (combine = 0): the images times out_scale and, on the fused 512 / 256 path,
+// fft512_coils_partials(batch) * nchan partial sums of |image|^2 per slice (CGNR); norm_partial_done tells whether they were written
 int adjoint_run(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, int zcount, int combine, int in_stride_spokes = 0,
-                bool defer_join = false);
+                bool defer_join = false, float out_scale = 1.f, double *norm_partial = nullptr, int *norm_parts = nullptr);
 int forward_run(tron_plan *p, void *d_out, const void *d_in, int nimg, const float2 *trig = nullptr, int trig_img_stride = 0,
                 const float *deapod = nullptr);
 int cgnr_run(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, int zcount, int combine);
