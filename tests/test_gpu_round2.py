@@ -217,3 +217,14 @@ def test_forward_non_square_images(oracle, nc, nx, ny, flags, kb):
     assert got.shape == want.shape
     assert rel_l2(got, want) <= 1e-5
     # a non-square ADJOINT cannot be asked for: nx = ny = nro/2 by construction (src/tron.cu:910-911)
+
+
+@pytest.mark.parametrize("kb", [lib.KB_EXACT, lib.KB_FAST])
+@pytest.mark.parametrize("W", [3.5, 4.0])
+def test_forward_wide_kernels_on_the_tiled_degridder(oracle, W, kb):
+    """Kernel half-widths above 3 (`-k 3.5`, `-k 4`) run on degrid_tile_kernel<.., 4> too (round 2: the thread-per-sample
+    kernel); the thread-per-sample kernel stays as the audit instrument (TRON_DEGRID_SIMPLE=1) and must agree."""
+    img = synth.image(2, 32, seed=7301)
+    want, _ = oracle.recon(img, adjoint=0, golden=1, kernwidth=W)
+    got, _ = lib.recon(img, adjoint=False, kb_mode=kb, golden_angle=1, kernwidth=W)
+    assert rel_l2(got, want) <= 1e-5

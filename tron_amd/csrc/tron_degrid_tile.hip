@@ -41,8 +41,9 @@ __global__ void __launch_bounds__(kDgThreads) degrid_tile_kernel(const DegridPar
     constexpr int HALO = L_t::HALO, TS = L_t::TS;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n = p.n;
-    const int tpr = (n + kDgTile - 1) / kDgTile;
+    const int n = p.n;                                          // columns (cosine axis, "Y" of the reference)
+    const int nr = p.nrows > 0 ? p.nrows : n;                   // rows (sine axis, "X"): differs for non-square forward transforms
+    const int tpr = (n + kDgTile - 1) / kDgTile, tprr = (nr + kDgTile - 1) / kDgTile;
     // centre tiles hold the most samples (density ~ 1/r): they are dispatched first, all images of a tile together
     // Workgroup id -> (tile, image, coil chunk).  The coil chunks of one (tile, image) write interleaved 8*CPB-byte
     // pieces of the same output lines (samples are coil-interleaved, src/tron.cu:550): they are placed 8 ids apart, i.e.
@@ -51,14 +52,22 @@ __global__ void __launch_bounds__(kDgThreads) degrid_tile_kernel(const DegridPar
     const int chunks = (p.nrep + CPB - 1) / CPB;
     const int grp = blockIdx.x / (8 * chunks), within = blockIdx.x % (8 * chunks);
     const int ti = grp * 8 + (within & 7);                      // (tile, image) index
-    if (ti >= tpr * tpr * p.nimg) return;
-    const int tile = p.tile_order ? p.tile_order[ti / p.nimg] : ti % (tpr * tpr);
-    const int k = p.tile_order ? ti % p.nimg : ti / (tpr * tpr);     // image
+    if (ti >= tpr * tprr * p.nimg) return;
+    const int tile = p.tile_order ? p.tile_order[ti / p.nimg] : ti % (tpr * tprr);
+    const int k = p.tile_order ? ti % p.nimg : ti / (tpr * tprr);    // image
     const int c0 = (within >> 3) * CPB;
     const int ncb = min(CPB, p.nrep - c0);
     const int tx0 = (tile / tpr) * kDgTile;                     // first row (sine axis, "X" of the reference)
     const int ty0 = (tile % tpr) * kDgTile;                     // first column (cosine axis, "Y")
 
+    {   // every sample lies within n/2 of the grid centre (src/tron.cu:554-561: |R| <= 1/2): a tile whose nearest cell is
+        // farther away owns none -- nothing to load, nothing to produce (the corners of the square: 12 % of the tiles)
+        const float hc = (float)((n + 1) / 2);
+        const float dx = fmaxf(fmaxf((float)tx0 - hc, hc - (float)(tx0 + kDgTile)), 0.f);
+        const float dy = fmaxf(fmaxf((float)ty0 - hc, hc - (float)(ty0 + kDgTile)), 0.f);
+        const float lim = 0.5f * (float)n + 1.5f;
+        if (nr == n && dx * dx + dy * dy > lim * lim) return;
+    }
     KbCoef kb;
     kb.W = p.W; kb.invW = 1.0f / p.W; kb.beta = p.beta;
 #pragma unroll
@@ -77,18 +86,18 @@ __global__ void __launch_bounds__(kDgThreads) degrid_tile_kernel(const DegridPar
             const int ea = e / TS, eb = e - ea * TS;
             const int r = p.in_transposed ? eb : ea, col = p.in_transposed ? ea : eb;   // the fastest index follows memory
             int i = tx0 - HALO + r, j = ty0 - HALO + col;               // periodic wrap, src/tron.cu:569-570
-            if (n >= TS) {                                              // -n <= i < 2n: one step each way
-                i += i < 0 ? n : 0; i -= i >= n ? n : 0;
+            if (n >= TS && nr >= TS) {                                  // -n <= i < 2n: one step each way
+                i += i < 0 ? nr : 0; i -= i >= nr ? nr : 0;
                 j += j < 0 ? n : 0; j -= j >= n ? n : 0;
             } else {
-                i %= n; i += i < 0 ? n : 0;
+                i %= nr; i += i < 0 ? nr : 0;
                 j %= n; j += j < 0 ? n : 0;
             }
             if (p.in_shift) {
-                i += n / 2; if (i >= n) i -= n;
+                i += nr / 2; if (i >= nr) i -= nr;
                 j += n / 2; if (j >= n) j -= n;
             }
-            const float2 *s = src + (p.in_transposed ? (size_t)j * n + i : (size_t)i * n + j) * p.in_p;
+            const float2 *s = src + (p.in_transposed ? (size_t)j * nr + i : (size_t)i * n + j) * p.in_p;
 #pragma unroll
             for (int c = 0; c < CPB; ++c)
                 stage[it][c] = (e < TS * TS && c < ncb) ? s[(size_t)c * p.in_c] : make_float2(0.f, 0.f);
@@ -106,7 +115,7 @@ __global__ void __launch_bounds__(kDgThreads) degrid_tile_kernel(const DegridPar
     }
     if (tid < 8) L.tile[TS * TS * CPB + tid] = make_float2(0.f, 0.f);
 
-    const float half = (float)((n + 1) / 2);                    // src/tron.cu:560-561
+    const float half = (float)((n + 1) / 2), halfr = (float)((nr + 1) / 2);   // src/tron.cu:560-561
     const float eps = 0.01f;
     const float bx_lo = (float)tx0 - eps, bx_hi = (float)(tx0 + kDgTile) + eps;
     const float by_lo = (float)ty0 - eps, by_hi = (float)(ty0 + kDgTile) + eps;
@@ -123,8 +132,8 @@ __global__ void __launch_bounds__(kDgThreads) degrid_tile_kernel(const DegridPar
             float2 cs = make_float2(0.f, 0.f);
             if (pe < p.npe && pe < round0 + kDgMaxSpokes) {
                 cs = p.trig[(size_t)k * p.trig_img_stride + pe];
-                const float ax = (float)n * cs.y / (float)p.nro, ay = (float)n * cs.x / (float)p.nro;   // d/d(ro)
-                const float ox = half - 0.5f * (float)n * cs.y, oy = half - 0.5f * (float)n * cs.x;     // value at ro = 0
+                const float ax = (float)nr * cs.y / (float)p.nro, ay = (float)n * cs.x / (float)p.nro;  // d/d(ro)
+                const float ox = halfr - 0.5f * (float)nr * cs.y, oy = half - 0.5f * (float)n * cs.x;   // value at ro = 0
                 const float ix = safe_rcp(ax), iy = safe_rcp(ay);
                 const float xa = (bx_lo - ox) * ix, xb = (bx_hi - ox) * ix;
                 const float ya = (by_lo - oy) * iy, yb = (by_hi - oy) * iy;
@@ -234,9 +243,9 @@ __global__ void __launch_bounds__(kDgThreads) degrid_tile_kernel(const DegridPar
             const float R = (nro_pow2 ? (float)ro * inv_nro : (float)ro / (float)p.nro) - 0.5f;
             const float2 cs = L.sp_cs[lo];
             float X = cs.y, Y = cs.x;                                   // X = sin, Y = cos (src/tron.cu:559)
-            X = (float)n * R * X + half;
+            X = (float)nr * R * X + halfr;
             Y = (float)n * R * Y + half;
-            const int fx = min(max((int)floorf(X), 0), n - 1);           // owner cell
+            const int fx = min(max((int)floorf(X), 0), nr - 1);          // owner cell
             const int fy = min(max((int)floorf(Y), 0), n - 1);
             if ((unsigned)(fx - tx0) >= (unsigned)kDgTile || (unsigned)(fy - ty0) >= (unsigned)kDgTile) continue;
 
@@ -261,10 +270,10 @@ __global__ void __launch_bounds__(kDgThreads) degrid_tile_kernel(const DegridPar
                     const v2f r = dxy * kb.invW;
                     sxy[t] = __builtin_elementwise_fma(-r, r, one);
                     // outside the window: s <- 1 - (W/W)^2 keeps the polynomial finite, the weight is zeroed below
-                    wxy[t] = (v2f){kb.poly[0], kb.poly[0]};
+                    wxy[t] = (v2f){kb.poly[kKbPolyTerms - kb_terms(CW)], kb.poly[kKbPolyTerms - kb_terms(CW)]};
                 }
 #pragma unroll
-                for (int k = 1; k < kKbPolyTerms; ++k) {
+                for (int k = kKbPolyTerms - kb_terms(CW) + 1; k < kKbPolyTerms; ++k) {
                     const v2f c = {kb.poly[k], kb.poly[k]};
 #pragma unroll
                     for (int t = 0; t < NF; ++t) wxy[t] = __builtin_elementwise_fma(wxy[t], sxy[t], c);
@@ -334,9 +343,9 @@ __global__ void __launch_bounds__(kDgThreads) degrid_tile_kernel(const DegridPar
 template <int CPB, int CW>
 static hipError_t launch_degrid_tile_cpb(const DegridParams &p, int kb_mode, hipStream_t s)
 {
-    const int tpr = (p.n + kDgTile - 1) / kDgTile;
+    const int tpr = (p.n + kDgTile - 1) / kDgTile, tprr = ((p.nrows > 0 ? p.nrows : p.n) + kDgTile - 1) / kDgTile;
     const int chunks = (p.nrep + CPB - 1) / CPB;
-    const size_t nti = (size_t)tpr * tpr * p.nimg;
+    const size_t nti = (size_t)tpr * tprr * p.nimg;
     dim3 grid((unsigned)(((nti + 7) / 8) * 8 * chunks));
     const size_t lds = sizeof(DgLds<CPB, CW>);
     static_assert(sizeof(DgLds<CPB, CW>) <= 64 * 1024, "degrid tile must fit the default dynamic LDS limit");
@@ -358,7 +367,8 @@ static hipError_t launch_degrid_tile_cw(const DegridParams &p, int kb_mode, hipS
     return launch_degrid_tile_cpb<1, CW>(p, kb_mode, s);
 }
 
-// Requires W <= 3 (any n: the halo wraps periodically, onto the tile itself when n is small).
+// Requires W <= 4 (any grid size, square or not: the halo wraps periodically, onto the tile itself when the grid is small).
+// A non-square grid (p.nrows) must come with p.tile_order == nullptr (raster order).
 hipError_t launch_degrid_tile(const DegridParams &p, int kb_mode, hipStream_t s)
 {
     const int cw = (int)ceilf(p.W);
@@ -366,6 +376,7 @@ hipError_t launch_degrid_tile(const DegridParams &p, int kb_mode, hipStream_t s)
         case 1: return launch_degrid_tile_cw<1>(p, kb_mode, s);
         case 2: return launch_degrid_tile_cw<2>(p, kb_mode, s);
         case 3: return launch_degrid_tile_cw<3>(p, kb_mode, s);
+        case 4: return launch_degrid_tile_cw<4>(p, kb_mode, s);
         default: return hipErrorInvalidValue;
     }
 }

@@ -537,6 +537,8 @@ struct Fft512FwdParams {
     const float2 *tw;
     const float *inv_deapod;  // 512*512, indexed by padded position (src/tron.cu:398-400)
     int nchan;
+    int rzero2;               // pass 2: grid points with X^2 + Y^2 > rzero2 (centred) are not stored: no sample's footprint reaches them
+                              // (<= 0: store everything)
 };
 
 // grid = (256/16, nimg*nchan); block = 256.  Line r of a coil image = padded row 128 + r.
@@ -689,17 +691,24 @@ __global__ void __launch_bounds__(256) fft512_fwd_cols_kernel(const Fft512FwdPar
         v[0] = cconj(in[j][0]); v[1] = cconj(in[j][1]); v[6] = cconj(in[j][2]); v[7] = cconj(in[j][3]);
         v[2] = v[3] = v[4] = v[5] = make_float2(0.f, 0.f);
         fft512_inv(v, xch, p.tw, lane);
-        float2 *line = dst + (size_t)(col0 + wave * 4 + j) * kF;
+        const int k2 = col0 + wave * 4 + j;
+        float2 *line = dst + (size_t)k2 * kF;
+        const int yc = k2 < kF / 2 ? k2 : k2 - kF;              // FFT-native index -> centred coordinate
 #pragma unroll
-        for (int j2 = 0; j2 < 8; ++j2) line[lane + 64 * j2] = cconj(v[j2]);
+        for (int j2 = 0; j2 < 8; ++j2) {
+            const int k1 = lane + 64 * j2;
+            const int xc = k1 < kF / 2 ? k1 : k1 - kF;
+            if (p.rzero2 <= 0 || xc * xc + yc * yc <= p.rzero2) line[k1] = cconj(v[j2]);
+        }
     }
 }
 
-hipError_t launch_fft512_forward(const float2 *img, float2 *tmp, float2 *out, const float2 *tw, const float *inv_deapod,
+hipError_t launch_fft512_forward(const float2 *img, float2 *tmp, float2 *out, const float2 *tw, const float *inv_deapod, int rzero,
                                  int nchan, int nimg, hipStream_t s)
 {
     Fft512FwdParams p;
     p.img = img; p.tmp = tmp; p.out = out; p.tw = tw; p.inv_deapod = inv_deapod; p.nchan = nchan;
+    p.rzero2 = rzero > 0 ? rzero * rzero : 0;
     if (nchan > 1 && nchan <= 16) {
         int rows = 16 / nchan;                                  // about 16 lines per workgroup
         if (rows < 1) rows = 1;

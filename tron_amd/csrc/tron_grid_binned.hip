@@ -435,10 +435,10 @@ grid_binned_kernel(const GridParams p)
                         dxy[i] = (v2f){kx - (float)(bx + i), ky - (float)(by + i)};
                         const v2f rr = dxy[i] * kb.invW;
                         sxy[i] = __builtin_elementwise_fma(-rr, rr, one);
-                        wxy[i] = (v2f){kb.poly[0], kb.poly[0]};
+                        wxy[i] = (v2f){kb.poly[kKbPolyTerms - kb_terms(CW)], kb.poly[kKbPolyTerms - kb_terms(CW)]};
                     }
 #pragma unroll
-                    for (int t = 1; t < kKbPolyTerms; ++t) {
+                    for (int t = kKbPolyTerms - kb_terms(CW) + 1; t < kKbPolyTerms; ++t) {
                         const v2f cf = {kb.poly[t], kb.poly[t]};
 #pragma unroll
                         for (int i = 0; i < C::NW; ++i) wxy[i] = __builtin_elementwise_fma(wxy[i], sxy[i], cf);

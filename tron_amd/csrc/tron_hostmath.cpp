@@ -187,7 +187,7 @@ static double bessel_i0_series(double t)
 // Coefficients (highest power first) of a degree-(nterms-1) polynomial in s = 1-(x/W)^2 that
 // approximates G(s) = (0.5/W)*I0(beta*sqrt(s)), the un-normalised Kaiser-Bessel window of
 // src/tron.cu:338-349, on [0,1]: Chebyshev interpolation, converted to the monomial basis in
-// long double.  Returns the largest relative error against G on a dense grid.
+// long double.  Returns the largest error against G on a dense grid, relative to G's peak.
 double kb_poly_fit(float kernwidth, float *poly, int nterms)
 {
     const double beta = kb_beta(kernwidth);
@@ -230,9 +230,9 @@ double kb_poly_fit(float kernwidth, float *poly, int nterms)
         double acc = poly[0];
         for (int k = 1; k < N; ++k) acc = acc * sv + (double)poly[k];
         const double want = amp * bessel_i0_series(beta * sqrt(sv));
-        worst = fmax(worst, fabs(acc / want - 1.0));
+        worst = fmax(worst, fabs(acc - want));
     }
-    return worst;
+    return worst / (amp * bessel_i0_series(beta));           // relative to the window's peak: what a weighted sum feels
 }
 
 // Table of the un-normalised Kaiser-Bessel window of src/tron.cu:338-349 for the arc gridding kernel: k = 128 intervals over

@@ -12,7 +12,12 @@ namespace tron {
 constexpr int kTile = 16;          // Cartesian tile edge owned by one workgroup (gridding)
 constexpr int kGridThreads = 64;   // one wave per tile, each lane owns 2x2 points
 constexpr int kGridRecords = 128;  // sample records staged in LDS per batch
-constexpr int kKbPolyTerms = 16;   // coefficients of the fast Kaiser-Bessel polynomial (degree 15)
+constexpr int kKbPolyTerms = 16;   // slots of the fast Kaiser-Bessel polynomial (highest power first, zeros in front of a shorter one)
+// Terms the polynomial needs for a peak-relative error below 1e-8 (fp32 noise is 6e-8): 8 up to W = 1 (1e-9), 10 up to W = 2
+// (7e-9), 12 up to W = 3 (6e-9), 16 beyond.  The host fits kb_terms(ceil(W)) coefficients into the LAST slots, so a kernel that
+// knows ceil(W) at compile time starts its Horner chain at slot kKbPolyTerms - kb_terms(CW), and one that does not runs all
+// 16 slots over leading zeros to the same value.
+constexpr int kb_terms(int cw) { return cw <= 1 ? 8 : (cw <= 2 ? 10 : (cw <= 3 ? 12 : 16)); }
 
 // Parameters of one gridding launch (adjoint interpolation), see tron_kernels.hip.
 struct GridParams {
@@ -151,7 +156,8 @@ hipError_t launch_fft512_adjoint_coils(const float2 *grid, float2 *tmp, float2 *
                                        int nchan, int nslices, float scale, double *partial, hipStream_t s);
 int fft512_coils_partials(int nslices);
 // fused pad + deapodise + shift + pruned forward FFT for nx = 256, nxos = 512 (tron_fft512.hip)
-hipError_t launch_fft512_forward(const float2 *img, float2 *tmp, float2 *out, const float2 *tw, const float *inv_deapod,
+// rzero: grid points at centred radius > rzero are not stored (no degridded sample's footprint reaches them; 0 = store all)
+hipError_t launch_fft512_forward(const float2 *img, float2 *tmp, float2 *out, const float2 *tw, const float *inv_deapod, int rzero,
                                  int nchan, int nimg, hipStream_t s);
 
 }  // namespace tron

@@ -367,7 +367,9 @@ int forward_run(tron_plan *p, void *d_out, const void *d_in, int nimg, const flo
         if (p->fft512) {
             // fused: pad + deapodise + shift + pruned forward FFT (tron_fft512.hip)
             StageTimer t(p, STAGE_FFT);
-            HIP_TRY(launch_fft512_forward(img, p->d_fft_tmp, p->d_grid, p->d_tw512, deapod, p->nchan, ck, p->stream));
+            // samples lie within nxos/2 of the centre, their footprints (zero-weight slots included) within W + 2 more
+            const int rzero = p->no_disc ? 0 : d.nxos / 2 + (int)ceilf(p->cfg.kernwidth) + 4;
+            HIP_TRY(launch_fft512_forward(img, p->d_fft_tmp, p->d_grid, p->d_tw512, deapod, rzero, p->nchan, ck, p->stream));
         } else {
             PreParams a;
             a.img = img;
@@ -392,7 +394,7 @@ int forward_run(tron_plan *p, void *d_out, const void *d_in, int nimg, const flo
         g.nudata = static_cast<float2 *>(d_out) + (size_t)k0 * p->nchan * d.nro * d.npe1work;
         g.trig = trig + (size_t)k0 * trig_img_stride;
         g.trig_img_stride = trig_img_stride;
-        g.tile_order = p->d_tile_order32;
+        g.tile_order = square ? p->d_tile_order32 : nullptr;     // centre-first tile order for square grids, raster otherwise
         g.in_z = (long long)p->nchan * n2;
         g.in_c = (long long)n2;
         g.in_p = 1;
@@ -410,10 +412,10 @@ int forward_run(tron_plan *p, void *d_out, const void *d_in, int nimg, const flo
         memcpy(g.kb_poly, p->kb_poly, sizeof(g.kb_poly));
         {
             StageTimer t(p, STAGE_DEGRID);
-            if (p->cfg.kernwidth <= 3.f && !p->degrid_simple && square)
-                HIP_TRY(launch_degrid_tile(g, p->kb_mode, p->stream));
+            if (!p->degrid_simple)
+                HIP_TRY(launch_degrid_tile(g, p->kb_mode, p->stream));  // every width the plan accepts (W <= 4), square or not
             else
-                HIP_TRY(launch_degrid(g, p->kb_mode, p->stream));      // also every non-square grid (supported, not tuned)
+                HIP_TRY(launch_degrid(g, p->kb_mode, p->stream));       // TRON_DEGRID_SIMPLE=1: the thread-per-sample audit kernel
         }
     }
     return TRON_OK;

@@ -108,7 +108,11 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
     p->nchan = d.nc * d.nt;
     p->beta = kb_beta(cfg->kernwidth);
     p->kb_mode = cfg->kb_mode == TRON_KB_FAST ? TRON_KB_FAST : TRON_KB_EXACT;
-    p->kb_poly_err = kb_poly_fit(cfg->kernwidth, p->kb_poly, kKbPolyTerms);
+    {   // kb_terms(ceil(W)) coefficients in the last slots, zeros in front (tron_internal.h)
+        const int nt = kb_terms((int)ceilf(cfg->kernwidth));
+        for (int t = 0; t < kKbPolyTerms; ++t) p->kb_poly[t] = 0.f;
+        p->kb_poly_err = kb_poly_fit(cfg->kernwidth, p->kb_poly + (kKbPolyTerms - nt), nt);
+    }
     if (p->kb_mode == TRON_KB_FAST && !(p->kb_poly_err < 1e-7)) p->kb_mode = TRON_KB_EXACT;   // polynomial too short for this beta: stay exact
     dcf_constants(d.nro, d.npe1work, &p->dcf_a, &p->dcf_b);
     p->scale = grid_scale(d.nxos, d.npe1work);
@@ -348,7 +352,7 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
         printf("tronhip: device %d, %s, nchan %d, grid %d^2 -> image %d^2, %d spokes/image, chunk %d, KB %s\n",
                cfg->device, cfg->adjoint ? "adjoint" : "forward", p->nchan, d.nxos, d.nx, d.npe1work, p->chunk,
                p->kb_mode == TRON_KB_FAST ? "fast" : "exact");
-        printf("tronhip: fast Kaiser-Bessel polynomial max relative error %.2e\n", p->kb_poly_err);
+        printf("tronhip: fast Kaiser-Bessel polynomial (%d terms) max error relative to the peak %.2e\n", kb_terms((int)ceilf(cfg->kernwidth)), p->kb_poly_err);
         printf("tronhip: gridding kernel: %s\n", tron_plan_grid_kernel_name(p));
         printf("tronhip: plan %.3f s = HIP runtime + code objects %.3f, tables %.3f (of which the arc kernel's run tables %.3f), work buffers %.3f\n",
                since(), t_runtime, t_tables - t_runtime, t_arc1 - t_arc0, t_work - t_tables);
@@ -541,6 +545,8 @@ extern "C" int tron_degridradial2d(tron_plan *p, void *d_nudata, const void *d_u
     g.in_p = p->nchan;
     g.in_shift = 0;
     g.n = d.nxos;
+    g.nrows = d.nyos != d.nxos ? d.nyos : 0;
+    if (g.nrows) g.tile_order = nullptr;                       // raster order for non-square grids
     g.nrep = p->nchan;
     g.nro = d.nro;
     g.npe = d.npe1work;
@@ -549,7 +555,7 @@ extern "C" int tron_degridradial2d(tron_plan *p, void *d_nudata, const void *d_u
     g.beta = p->beta;
     memcpy(g.kb_poly, p->kb_poly, sizeof(g.kb_poly));
     StageTimer t(p, STAGE_DEGRID);
-    if (p->cfg.kernwidth <= 3.f && !p->degrid_simple)
+    if (!p->degrid_simple)
         HIP_TRY(launch_degrid_tile(g, p->kb_mode, p->stream));
     else
         HIP_TRY(launch_degrid(g, p->kb_mode, p->stream));
