@@ -44,6 +44,15 @@ constexpr int kArcMaxBatches = 96;
 constexpr int kArcSeg = 64;            // longest spoke segment through tile + halo: (32 + 2 * 3) sqrt(2) = 54
 constexpr float kPi = 3.14159265358979f;
 
+// one and two coils: five workgroups per CU (83 / 94 VGPRs) beat four with larger batches by 3-4 % / 1 % (same-box A/B)
+#ifndef TRON_ARC_NREC1
+#define TRON_ARC_NREC1 2048
+#define TRON_ARC_WAVES1 5
+#endif
+#ifndef TRON_ARC_NREC2
+#define TRON_ARC_NREC2 1024
+#define TRON_ARC_WAVES2 5
+#endif
 template <int CPB>
 struct ArcCfg {
     // sample records per batch.  One buffer: same-box A/B at 8 coils, gridding us per coil-slice: two buffers of 304 records
@@ -53,9 +62,9 @@ struct ArcCfg {
 #ifdef TRON_ARC_NREC
     static constexpr int NREC = TRON_ARC_NREC;
 #else
-    static constexpr int NREC = CPB >= 8 ? 608 : (CPB >= 6 ? 800 : (CPB >= 4 ? 800 : (CPB >= 2 ? 1600 : 3072)));
+    static constexpr int NREC = CPB >= 8 ? 608 : (CPB >= 6 ? 800 : (CPB >= 4 ? 800 : (CPB >= 2 ? TRON_ARC_NREC2 : TRON_ARC_NREC1)));
 #endif
-    static constexpr int WAVES = CPB >= 6 ? 3 : 4;
+    static constexpr int WAVES = CPB >= 6 ? 3 : (CPB >= 4 ? 4 : (CPB >= 2 ? TRON_ARC_WAVES2 : TRON_ARC_WAVES1));
 #ifdef TRON_ARC_DOUBLE_BUFFER
     static constexpr int NBUF = 2;
 #else
@@ -427,6 +436,7 @@ grid_arc_kernel(const GridParams p)
         tlo = T - D;
         thi = T + D;
     }
+    const v2f p0v = {X0f, Y0f}, p1v = {X1f, Y1f}, lscale2 = {p.lut_scale, p.lut_scale};
     const float We = p.W + 1e-3f;
     const float xlo = X0f - We, xhi = X1f + We, ylo = Y0f - We, yhi = Y1f + We;
 
@@ -435,7 +445,6 @@ grid_arc_kernel(const GridParams p)
     const unsigned dbase = lds_addr(L.d);
     constexpr unsigned kBufBytes = (unsigned)(C::NREC * CPB * 8);
     constexpr unsigned kRecStep = CPB == 1 ? 4u : 16u;              // bytes between consecutive records of one plane
-    const float lscale = p.lut_scale;
     const float dcf_a = p.apply_dcf ? p.dcf_a : 0.0f, dcf_b = p.apply_dcf ? p.dcf_b : 1.0f;
 
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -511,7 +520,7 @@ grid_arc_kernel(const GridParams p)
             }
         };
 #ifndef TRON_ARC_SKIP_DMA
-        if (ns > 0 && C::NBUF == 2) issue(0);
+        if (ns > 0) issue(0);                                   // batch 0 flies under the window search
 #endif
         APROF_MARK(2);                                          // DMA issue
 
@@ -535,8 +544,8 @@ grid_arc_kernel(const GridParams p)
 
         const float rcpK = 1.0f / (float)K;
         for (int b = 0; b < K && ns > 0; ++b) {
-            if (C::NBUF == 1) {
-                if (b > 0) lds_barrier();                       // everyone has left the buffer
+            if (C::NBUF == 1 && b > 0) {
+                lds_barrier();                                  // everyone has left the buffer
                 issue(b);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's pieces of batch b have landed
@@ -602,14 +611,15 @@ grid_arc_kernel(const GridParams p)
                 acc[0][0].x += (float)ua; continue;
 #endif
                 unsigned addr = buf + (unsigned)((int)(sb >> 17) - s_ulo + ua) * kRecStep;
-                float uf = (float)ua;
+                v2f ufv = {(float)ua, (float)ua};
+                const v2f csv = {cs.x, cs.y};
                 int bit = ua - bandlo;
                 for (int u = ua; u <= ub; ++u) {
                     { const unsigned long long bm_ = __ballot(1); if (lane == __builtin_ctzll(bm_)) { APROF_COUNT(14, 1); APROF_COUNT(15, __popcll(bm_)); } }
-                    const float kx = uf * cs.x, ky = uf * cs.y;                               // src/tron.cu:514-515
-                    // four table lookups and the samples, all asked for before the first is used (one LDS round trip per visit)
-                    const float t0 = fabsf(kx - X0f) * lscale, t1 = fabsf(kx - X1f) * lscale;
-                    const float t2 = fabsf(ky - Y0f) * lscale, t3 = fabsf(ky - Y1f) * lscale;
+                    // (kx, ky) = u (cos, sin), the distances to the block's columns / rows and their table positions as packed pairs
+                    const v2f kxy = ufv * csv;                                                // src/tron.cu:514-515
+                    const v2f t02 = (kxy - p0v) * lscale2, t13 = (kxy - p1v) * lscale2;       // (x - X0, y - Y0), (x - X1, y - Y1), times the table scale
+                    const float t0 = fabsf(t02.x), t2 = fabsf(t02.y), t1 = fabsf(t13.x), t3 = fabsf(t13.y);
                     const v4f e0 = *(lds_f4p)(size_t)(lut0 + (unsigned)t0 * 16u), e1 = *(lds_f4p)(size_t)(lut0 + (unsigned)t1 * 16u);
                     const v4f e2 = *(lds_f4p)(size_t)(lut0 + (unsigned)t2 * 16u), e3 = *(lds_f4p)(size_t)(lut0 + (unsigned)t3 * 16u);
                     v4f dd[CPB / 2 > 0 ? CPB / 2 : 1];
@@ -621,7 +631,7 @@ grid_arc_kernel(const GridParams p)
 #pragma unroll
                         for (int c = 0; c < CPB / 2; ++c) dd[c] = *(lds_f4p)(size_t)(addr + (unsigned)(c * C::NREC * 16));
                     }
-                    const float sdc = fmaf(dcf_a, uf, dcf_b);                                 // src/tron.cu:412 (|ro - nro/2| = u)
+                    const float sdc = fmaf(dcf_a, ufv.x, dcf_b);                              // src/tron.cu:412 (|ro - nro/2| = u)
                     const float f0 = __builtin_amdgcn_fractf(t0), f1 = __builtin_amdgcn_fractf(t1);
                     const float f2 = __builtin_amdgcn_fractf(t2), f3 = __builtin_amdgcn_fractf(t3);
                     const float wx0 = fmaf(f0, fmaf(f0, e0.z, e0.y), e0.x), wx1 = fmaf(f1, fmaf(f1, e1.z, e1.y), e1.x);
@@ -649,7 +659,7 @@ grid_arc_kernel(const GridParams p)
                             acc[q][2 * c + 1].y = fmaf(d.w, wq[q], acc[q][2 * c + 1].y);
                         }
                     }
-                    uf += 1.0f;
+                    ufv += (v2f){1.0f, 1.0f};
                     addr += kRecStep;
                     ++bit;
                 }

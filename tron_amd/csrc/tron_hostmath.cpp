@@ -353,6 +353,7 @@ bool build_centre_relief_order(int nxos, int tile, int npe, float W, int max_par
     slots.clear();
     // an inner sample's footprint (floor(k) - ceil(W) + 1 .. floor(k) + ceil(W)) must stay inside the inner tile
     inner_r0 = tile / 2 - (int)ceilf(W);
+    if (const char *e = tuning_env("TRON_INNER_R0")) inner_r0 = std::max(4, std::min(inner_r0, atoi(e)));   // (A/B: a smaller inner tile load)
     if (nxos < 4 * tile || (nxos / 2) % tile != 0 || inner_r0 < 8 || nxos / 2 - 1 < inner_r0) return false;
     std::vector<int> plain;
     build_tile_order(nxos, tile, plain);
