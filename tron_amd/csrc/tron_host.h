@@ -28,7 +28,8 @@ void build_deapod_table_rect(int rows, int cols, float kernwidth, float sigma, f
 void build_tile_order(int nxos, int tile, std::vector<int> &order);
 void build_split_tile_order(int nxos, int tile, int npe, float W, int target, int max_parts,
                             std::vector<int> &order, std::vector<int> &slots);
-bool build_centre_relief_order(int nxos, int tile, int npe, float W, int max_parts, int &inner_r0, std::vector<int> &order, std::vector<int> &slots);
+bool build_centre_relief_order(int nxos, int tile, int npe, float W, int max_parts, int &inner_r0, std::vector<int> &order, std::vector<int> &slots,
+                               int target_records = 1400);
 float kb_beta(float kernwidth);
 // arc gridding kernel: Kaiser-Bessel table, 128 quadratic pieces over [0, W) (c0, c1, c2, 0 per entry), zero beyond; returns the
 // largest error relative to the peak

@@ -347,7 +347,8 @@ void build_split_tile_order(int nxos, int tile, int npe, float W, int target, in
 // Centre relief (binned kernel, GridParams::inner_r0): the plain tile order plus `parts` entries of the origin-centred
 // inner tile (id = tile count), which come first -- they are ordinary-sized workgroups, and the reduce pass waits for them.
 // slots[0] describes the inner tile for grid_reduce_parts_kernel.  Only for grids whose centre is a corner of four tiles.
-bool build_centre_relief_order(int nxos, int tile, int npe, float W, int max_parts, int &inner_r0, std::vector<int> &order, std::vector<int> &slots)
+bool build_centre_relief_order(int nxos, int tile, int npe, float W, int max_parts, int &inner_r0, std::vector<int> &order, std::vector<int> &slots,
+                               int target_records)
 {
     order.clear();
     slots.clear();
@@ -360,7 +361,7 @@ bool build_centre_relief_order(int nxos, int tile, int npe, float W, int max_par
     const int ntiles = (int)plain.size();
     if (ntiles >= 0xffff) return false;
     const int records = npe * (2 * inner_r0 - 1);                 // inner samples per image
-    const int parts = std::max(1, std::min(std::min(max_parts, 15), (records + 700) / 1400));
+    const int parts = std::max(1, std::min(std::min(max_parts, 15), (records + target_records / 2) / target_records));   // about target_records per workgroup
     slots.push_back(ntiles | (parts << 20));
     for (int g = 0; g < parts; ++g) order.push_back(ntiles | (g << 16) | (parts << 20));
     order.insert(order.end(), plain.begin(), plain.end());

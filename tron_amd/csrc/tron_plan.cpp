@@ -183,6 +183,17 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
                 p->relief_r0 = r0;
                 if ((rc = upload(&p->d_tile_order32_relief, rorder.data(), rorder.size() * sizeof(int)))) return bail(rc);
                 if ((rc = upload(&p->d_relief_slots, rslots.data(), rslots.size() * sizeof(int)))) return bail(rc);
+                // small launches: 15 parts, i.e. about half the serial chain per workgroup (a 32-slice launch lasts ~0.35 ms,
+                // an inner-tile workgroup of 1/8 of the spokes 0.2 ms)
+                std::vector<int> sorder, sslots;
+                int r1 = 0;
+                if (build_centre_relief_order(d.nxos, kBinnedTile, d.npe1work, cfg->kernwidth, 15, r1, sorder, sslots, 700) && r1 == r0 &&
+                    ((sslots[0] >> 20) & 15) > p->relief_parts) {
+                    p->relief_entries_small = (int)sorder.size();
+                    p->relief_parts_small = (sslots[0] >> 20) & 15;
+                    if ((rc = upload(&p->d_tile_order32_relief_small, sorder.data(), sorder.size() * sizeof(int)))) return bail(rc);
+                    if ((rc = upload(&p->d_relief_slots_small, sslots.data(), sslots.size() * sizeof(int)))) return bail(rc);
+                }
             }
             t_arc0 = since();
             t_arc1 = t_arc0;
@@ -401,6 +412,8 @@ extern "C" int tron_plan_destroy(tron_plan *p)
     hipFree(p->d_partial);
     hipFree(p->d_tile_order32_relief);
     hipFree(p->d_relief_slots);
+    hipFree(p->d_tile_order32_relief_small);
+    hipFree(p->d_relief_slots_small);
     hipFree(p->d_relief_partial);
     hipFree(p->d_deapod);
     hipFree(p->d_errflag);

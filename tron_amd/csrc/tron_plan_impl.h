@@ -78,6 +78,9 @@ struct tron_plan {
     // centre relief of the binned gridding kernel (GridParams::inner_r0): entry list with the inner tile's parts, its slot
     int *d_tile_order32_relief = nullptr, *d_relief_slots = nullptr;
     int relief_entries = 0, relief_parts = 0, relief_r0 = 0;
+    // the same with the inner tile dealt to more workgroups, for launches of fewer than 32 slices (its serial chain bounds them)
+    int *d_tile_order32_relief_small = nullptr, *d_relief_slots_small = nullptr;
+    int relief_entries_small = 0, relief_parts_small = 0;
     float2 *d_relief_partial = nullptr;
     size_t relief_slices = 0;
     size_t partial_slices = 0;
