@@ -1,0 +1,119 @@
+"""The arc gridding kernel (tron_grid_arc.hip, round 3): every shape it takes, against the oracle AND against the binned kernel
+it replaced (TRON_GRID_KERNEL=binned), and the plans it must NOT take.
+
+What is checked is the reference's gridradial2d + pipeline (src/tron.cu:465-536, 623-655) through the oracle at the
+north_star's 1e-5 relative L2, and agreement of the two fast kernels at 2e-6 (they differ in summation order and in how the
+Kaiser-Bessel window is evaluated: table vs polynomial)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import rel_l2
+import synth
+from tron_amd import lib
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _kernel_name(shape, **flags):
+    cfg = lib.default_config(adjoint=1, **flags)
+    dims = lib.derive_dims(cfg, shape)
+    with lib.Plan(cfg, dims) as plan:
+        return plan.grid_kernel_name()
+
+
+def _binned(data, **flags):
+    """The same reconstruction with the binned kernel on every tile: a child process, because the switch is read once."""
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r); from tron_amd import lib\n"
+        "d = np.load(sys.argv[1]); out, _ = lib.recon(d, adjoint=True, **eval(sys.argv[3])); np.save(sys.argv[2], out)\n" % ROOT)
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        np.save(os.path.join(tmp, "in.npy"), data)
+        env = dict(os.environ, TRON_TUNING="1", TRON_GRID_KERNEL="binned")
+        r = subprocess.run([sys.executable, "-c", code, os.path.join(tmp, "in.npy"), os.path.join(tmp, "out.npy"), repr(flags)],
+                           env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return np.load(os.path.join(tmp, "out.npy"))
+
+
+CASES = [
+    # nc, nro, spokes per slice, slices, flags
+    (8, 256, 201, 3, dict(golden_angle=1)),                       # 256^2 grid, centre = tile corner
+    (2, 256, 150, 4, dict(golden_angle=1, prof_slide=37)),         # sliding windows, 2 coils
+    (4, 128, 64, 5, dict(golden_angle=1, skip_angles=7)),            # smallest grid the kernel takes (4 x 4 tiles)
+    (6, 256, 100, 2, dict(golden_angle=0)),                         # linear angles (6 coils: no slice groups)
+    (1, 256, 180, 3, dict(golden_angle=1)),                          # one coil: 4-byte LDS-DMA planes
+    (8, 256, 120, 2, dict(golden_angle=1, kernwidth=1.0)),          # W = 1
+    (2, 256, 120, 2, dict(golden_angle=1, kernwidth=3.0)),          # W = 3
+    (4, 256, 90, 2, dict(golden_angle=1, kernwidth=2.5)),           # fractional W
+    (8, 1024, 60, 1, dict(golden_angle=1)),                       # 1024^2 grid, few spokes
+]
+
+
+@pytest.mark.parametrize("nc,nro,npe,nz,flags", CASES)
+def test_arc_kernel_vs_oracle_and_binned(oracle, nc, nro, npe, nz, flags):
+    slide = flags.get("prof_slide", npe)
+    data = synth.kspace(nc, nro, npe + slide * (nz - 1), seed=9000 + nc + nro + npe)
+    fl = dict(flags)
+    fl.setdefault("prof_slide", npe)
+    fl["data_undersamp"] = (npe + 0.5) / nro          # npe1work = int(data_undersamp * nro), src/tron.cu:916
+    assert "grid_arc_kernel" in _kernel_name(data.shape, **fl)
+    got, dims = lib.recon(data, adjoint=True, **fl)
+    assert dims.nz == nz and dims.npe1work == npe
+    oflags = {("golden" if k == "golden_angle" else k): v for k, v in fl.items()}
+    for z in sorted({0, nz // 2, nz - 1}):
+        want, _ = oracle.recon(data, adjoint=1, zfirst=z, zcount=1, **oflags)
+        assert rel_l2(got[..., z], want[..., z]) <= 1e-5, z
+    other = _binned(data, **fl)
+    assert rel_l2(got, other) <= 2e-6
+
+
+def test_arc_kernel_half_input_and_determinism(oracle):
+    """complex-half k-space, 4 and 8 coils (the halves are converted in LDS, in place); identical bits run to run."""
+    for nc in (4, 8):
+        data = synth.kspace(nc, 256, 140 * 2, seed=9100 + nc)
+        h = np.stack([data.real, data.imag]).astype(np.float16)
+        fl = dict(golden_angle=1, data_undersamp=0.547, prof_slide=140)
+        a, dims = lib.recon(h, adjoint=True, input_half=1, **fl)
+        b, _ = lib.recon(h, adjoint=True, input_half=1, **fl)
+        assert np.array_equal(a, b)
+        rounded = (h[0].astype(np.float32) + 1j * h[1].astype(np.float32)).astype(np.complex64)
+        want, _ = oracle.recon(rounded, adjoint=1, golden=1, data_undersamp=0.547, prof_slide=140)
+        assert rel_l2(a, want) <= 1e-5
+
+
+@pytest.mark.parametrize("shape,flags,why", [
+    ((1, 3, 256, 100, 1), dict(golden_angle=1, data_undersamp=0.39), "odd channel count (1 coil x 3 repetitions; the reference takes 1 or an even number of coils)"),
+    ((2, 1, 160, 100, 1), dict(golden_angle=1, data_undersamp=0.63), "grid centre inside a tile (nxos 160)"),
+    ((2, 1, 256, 100, 1), dict(golden_angle=1, data_undersamp=0.39, gridos=1.5), "nro != nxos"),
+    ((2, 1, 64, 40, 1), dict(golden_angle=1, data_undersamp=0.625), "grid smaller than 4 x 4 tiles"),
+])
+def test_shapes_the_arc_kernel_leaves_to_the_binned_kernel(oracle, shape, flags, why):
+    assert "grid_arc_kernel" not in _kernel_name(shape, **flags), why
+    data = synth.kspace(shape[0], shape[2], shape[3], seed=9200 + shape[2], nt=shape[1])
+    got, _ = lib.recon(data, adjoint=True, **flags)
+    oflags = {("golden" if k == "golden_angle" else k): v for k, v in flags.items()}
+    if shape[1] == 1:
+        want, _ = oracle.recon(data, adjoint=1, **oflags)
+        assert rel_l2(got, want) <= 1e-5, why
+    else:                                       # nt > 1 is defined as nt separate runs (test_repetitions_nt_gt_1)
+        for t in range(shape[1]):
+            want, _ = oracle.recon(np.asfortranarray(data[:, t:t + 1]), adjoint=1, **oflags)
+            assert rel_l2(got[:, t:t + 1], want) <= 1e-5, (why, t)
+
+
+def test_a_workers_plan_holds_only_its_own_run_tables():
+    """tron_recon_radial2d_multi: three workers on one GPU, each with a plan (and arc run tables) for its own slice block,
+    give the single-plan bytes."""
+    data = synth.kspace(2, 256, 90 + 30 * 8, seed=9300)
+    fl = dict(golden_angle=1, data_undersamp=0.3516, prof_slide=30)
+    one, dims = lib.recon(data, adjoint=True, **fl)
+    assert dims.nz == 9
+    multi, _ = lib.recon_multi(data, adjoint=True, devices=[0, 0, 0], **fl)
+    assert np.array_equal(one, multi)
