@@ -133,7 +133,7 @@ def forward_bench(args, rank, local_rank, world, torch, group, lib):
         alg = 8 * NXOS * NXOS + 8 * nro * npe                    # degridding alone: grid read + sample write
         achieved = alg * nc * nimg * reps / n / (ms / n * 1e-3) / 1e9
         fwd_units = nc * nimg * reps / n
-        ftraffic, fstale, fnote = traffic_capture(workload_key(args), ("degrid_tile_kernel", "degrid_kernel"), fwd_units)
+        ftraffic, fstale, fnote = traffic_capture(workload_key(args), ("degrid_stream_kernel", "degrid_tile_kernel", "degrid_kernel"), fwd_units)
         err = None
         if not args.no_check:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -152,7 +152,7 @@ def forward_bench(args, rank, local_rank, world, torch, group, lib):
                        "coils": nc, "images_per_gpu": nimg, "kb_mode": args.kb},
             "algorithmic_gbps_per_gpu": round(gbps, 1), "algorithmic_frac_of_peak": round(gbps / HBM_PEAK_GBPS, 4),
             "parity_rel_l2_vs_oracle": err,
-            "roofline": {"bound": "hbm", "kernel": "degrid_tile_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": plan.degrid_kernel_name(), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": ftraffic, "traffic_stale": fstale, "traffic_source": fnote,
                          "bytes_per_launch": int(alg * fwd_units), "units_per_launch": fwd_units, "launch_ms": round(ms / n, 4),
                          "stage_share": {k: round(v[0] / sum(x[0] for x in stages.values()), 3) for k, v in stages.items()}},

@@ -188,6 +188,9 @@ int tron_plan_sync(tron_plan *plan);
 int tron_plan_two_lanes(tron_plan *plan, int enable, int *had_two_lanes);
 /* Names the gridding kernel(s) the plan's adjoint launches (measurement tooling); a static string. */
 const char *tron_plan_grid_kernel_name(const tron_plan *plan);
+/* Names the degridding kernel the plan's most recent forward launch ran ("" before the first one): degrid_stream_kernel
+   for launches of 16 images and more on grids of whole 32x32 tiles, degrid_tile_kernel otherwise. */
+const char *tron_plan_degrid_kernel_name(const tron_plan *plan);
 
 /* Per-stage device timing with hipEvents on the plan's stream (off by default; costs one
    event pair per launch).  stage: 0 grid, 1 fft, 2 post (crop+deapod+SoS), 3 pre

@@ -1,0 +1,215 @@
+// Streaming tiled degridding = degridradial2d of the reference (src/tron.cu:540-577) for launches of many images.
+//
+// degrid_tile_kernel (tron_degrid_tile.hip) loads one tile, clips the spokes, runs the sample loop and retires, three
+// workgroups per CU by LDS: the tile load and the clipping of one overlap the sample loops of the others only by chance.
+// Here ONE workgroup of 768 threads owns a CU (three waves per SIMD, as there) and walks a run of images of its tile and
+// coil chunk: the next image's tile + halo is copied global -> LDS by the DMA path (global_load_lds_dwordx4, no
+// registers) into the second of two tile buffers while the current one is sampled, and the spoke lists are built once
+// per run when every image has the same angles.  How many images a run holds depends on the tile: the centre tiles hold
+// the most samples (density ~ 1/r) and take short runs so that no workgroup outlasts the launch (DegridParams::group_end).
+// (Entering the sample loop a fraction of a pass late per wave, so that the waves' LDS and VALU phases interleave: no gain.)
+//
+// The tile is held as the input planes lie in memory ([col][row] for the fused forward FFT, which stores the grid
+// transposed): the sample loop strides accordingly.  The halo is rounded up to even widths so that a 16-byte piece
+// (two points) never straddles the periodic wrap (src/tron.cu:569-570) or the fftshift of :646, both folded into the
+// source index.  Coordinates, weights and accumulation order are dg_sample_loop's, i.e. the reference's.
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "tron_degrid_sample.h"
+
+namespace tron {
+
+constexpr int kDsThreads = 768;    // three waves per SIMD: 168 registers each (the unrolled gather wants ~150)
+constexpr int kDsMaxSpokes = 512;   // spokes clipped per round
+constexpr int kDsMaxBlocks = 512;   // 64-record blocks indexed by the inverse map
+constexpr int kDsCoils = 4;         // coils per workgroup (32-byte pieces of the coil-interleaved output lines)
+
+template <int CW>
+struct DsLds : DgLists<kDsMaxSpokes, kDsMaxBlocks, kDsThreads / 64> {
+    static constexpr int HALO = (CW + 1) & ~1;                // points before the tile: ceil(W), rounded up to even (16-byte pieces)
+    static constexpr int TS = (kDgTile + HALO + CW + 2) & ~1; // ... and ceil(W) + 1 after it (the fast weights' last slot), rounded likewise
+    // row pitch in points: = 6 or 12 mod 32, so that no short step (a rows, b points) lands on the same pair of the 64
+    // banks (a * PITCH + b = 0 mod 32 has no solution shorter than 5): spokes of any angle gather with few conflicts
+    static constexpr int PITCH = TS <= 38 ? 38 : 44;
+    static constexpr int PLANE = TS * PITCH;
+    static constexpr int BUF = PLANE * kDsCoils;              // points per tile buffer
+    alignas(16) float2 tile[2 * BUF + 16];                    // two buffers of [coil][a][b], b along memory; zeroed pad
+};
+
+template <int CW, bool TR, int KB>
+__global__ void __launch_bounds__(kDsThreads) degrid_stream_kernel(const DegridParams p)
+{
+    using L_t = DsLds<CW>;
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    L_t &L = *reinterpret_cast<L_t *>(lds_raw);
+    constexpr int HALO = L_t::HALO, TS = L_t::TS, PITCH = L_t::PITCH, PLANE = L_t::PLANE, BUF = L_t::BUF;
+    constexpr int SX = TR ? 1 : PITCH, SY = TR ? PITCH : 1;          // LDS strides of a step along the sine / cosine axis
+
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int n = p.n;                                          // columns (cosine axis, "Y" of the reference)
+    const int nr = p.nrows > 0 ? p.nrows : n;                   // rows (sine axis, "X")
+    const int tpr = n / kDgTile, tprr = nr / kDgTile;
+    // Workgroup id -> (tile, image run, coil chunk).  The coil chunks of one (tile, run) write interleaved 32-byte pieces
+    // of the same output lines (samples are coil-interleaved, src/tron.cu:550): they are placed 8 ids apart, i.e. on the
+    // same XCD and in step with each other, so its L2 merges the pieces before they reach HBM.
+    const int chunks = (p.nrep + kDsCoils - 1) / kDsCoils;
+    const int grp = blockIdx.x / (8 * chunks), within = blockIdx.x % (8 * chunks);
+    int rem = grp * 8 + (within & 7);                           // (tile, run) index: classes of run length 1, 2, 4, 8, 16
+    int tpos = 0, run = 1, k0 = -1;
+    {
+        const int ntiles = tpr * tprr;
+        int t0 = 0;
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+            const int t1 = c < 4 ? min(p.group_end[c], ntiles) : ntiles;
+            const int g = min(1 << c, p.group_max);
+            const int runs = (p.nimg + g - 1) / g;
+            const int cnt = max(t1 - t0, 0) * runs;
+            if (k0 < 0) {
+                if (rem < cnt) { tpos = t0 + rem / runs; run = g; k0 = (rem % runs) * g; }
+                else rem -= cnt;
+            }
+            t0 = max(t0, t1);
+        }
+    }
+    if (k0 < 0) return;
+    const int k1 = min(p.nimg, k0 + run);
+    const int tile = p.tile_order ? p.tile_order[tpos] : tpos;
+    const int c0 = (within >> 3) * kDsCoils;
+    const int ncb = min(kDsCoils, p.nrep - c0);
+    const int tx0 = (tile / tpr) * kDgTile;                     // first row (sine axis, "X" of the reference)
+    const int ty0 = (tile % tpr) * kDgTile;                     // first column (cosine axis, "Y")
+
+    {   // every sample lies within n/2 of the grid centre (src/tron.cu:554-561: |R| <= 1/2): a tile whose nearest cell is
+        // farther away owns none
+        const float hc = (float)((n + 1) / 2);
+        const float dx = fmaxf(fmaxf((float)tx0 - hc, hc - (float)(tx0 + kDgTile)), 0.f);
+        const float dy = fmaxf(fmaxf((float)ty0 - hc, hc - (float)(ty0 + kDgTile)), 0.f);
+        const float lim = 0.5f * (float)n + 1.5f;
+        if (nr == n && dx * dx + dy * dy > lim * lim) return;
+    }
+    KbCoef kb;
+    kb.W = p.W; kb.invW = 1.0f / p.W; kb.beta = p.beta;
+#pragma unroll
+    for (int t = 0; t < kKbPolyTerms; ++t) kb.poly[t] = p.kb_poly[t];
+
+    // ---- the tile's 16-byte pieces: source offsets once per workgroup (periodic wrap of src/tron.cu:569-570 and the
+    //      fftshift(INVERSE) of :646 folded in), piece q -> LDS bytes [16 q, 16 q + 16) of a buffer
+    constexpr int PPC = PLANE / 2;                              // pieces per coil plane (those past a row's TS points: padding, not fetched)
+    constexpr int NIT = (PPC * kDsCoils + kDsThreads - 1) / kDsThreads;
+    unsigned voff[NIT];
+    bool vact[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int q = it * kDsThreads + tid;
+        const int c = q / PPC, e = q - c * PPC;
+        const int a = e / (PITCH / 2), b = 2 * (e - a * (PITCH / 2));
+        int i = tx0 - HALO + (TR ? b : a), j = ty0 - HALO + (TR ? a : b);
+        i += i < 0 ? nr : 0; i -= i >= nr ? nr : 0;              // -nr <= i < 2 nr: one step each way
+        j += j < 0 ? n : 0; j -= j >= n ? n : 0;
+        if (p.in_shift) {
+            i += nr / 2; if (i >= nr) i -= nr;
+            j += n / 2; if (j >= n) j -= n;
+        }
+        voff[it] = (unsigned)(((size_t)c * p.in_c + (TR ? (size_t)j * nr + i : (size_t)i * n + j)) * sizeof(float2));
+        vact[it] = c < ncb && b < TS;
+    }
+    const unsigned tile_lds = lds_addr(L.tile);
+    auto fetch = [&](const int k, const int buf) {
+        const float2 *src = p.udata + (size_t)k * p.in_z + (size_t)c0 * p.in_c;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const unsigned dst = tile_lds + (unsigned)((buf * BUF) * sizeof(float2)) + (unsigned)((it * kDsThreads + wave * 64) * 16);
+            if (vact[it]) lds_dma16_s(src, voff[it], (unsigned)__builtin_amdgcn_readfirstlane((int)dst));
+        }
+    };
+    fetch(k0, 0);
+    if (tid < 16) L.tile[2 * BUF + tid] = make_float2(0.f, 0.f);
+
+    const int nrounds = (p.npe + kDsMaxSpokes - 1) / kDsMaxSpokes;
+    DgRound rd;
+    rd.nacc = rd.nrec = 0; rd.mapped = true;
+    for (int k = k0; k < k1; ++k) {
+        const int buf = (k - k0) & 1;
+        const bool relist = k == k0 || nrounds > 1 || p.trig_img_stride != 0;
+        if (relist && TRON_DBG_LT(p, 2)) rd = dg_clip_round<kDsThreads, kDsMaxSpokes, kDsMaxBlocks>(p, L, k, 0, tid, tx0, ty0, n, nr);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this thread's pieces of image k have landed
+        __syncthreads();                                        // ... everybody's; and nobody still samples the other buffer
+        if (k + 1 < k1) fetch(k + 1, buf ^ 1);
+        float2 *dst = p.nudata + (size_t)k * p.nro * p.npe * p.nrep;
+        for (int r = 0; r < nrounds && TRON_DBG_LT(p, 2); ++r) {
+            if (r > 0) {
+                __syncthreads();                                // the lists of the round before are no longer read
+                rd = dg_clip_round<kDsThreads, kDsMaxSpokes, kDsMaxBlocks>(p, L, k, r * kDsMaxSpokes, tid, tx0, ty0, n, nr);
+            }
+            dg_sample_loop<kDsCoils, CW, KB, kDsThreads, kDsMaxSpokes, PLANE, HALO, SX, SY>(p, kb, L, buf * BUF, rd, tid, tx0, ty0, n, nr,
+                                                                                         dst, c0, ncb);
+        }
+        if (relist && k + 1 < k1 && (nrounds > 1 || p.trig_img_stride != 0)) __syncthreads();   // before the lists are rebuilt
+    }
+}
+
+template <int CW, bool TR>
+static hipError_t launch_degrid_stream_cw(const DegridParams &p, int kb_mode, hipStream_t s)
+{
+    const int ntiles = (p.n / kDgTile) * ((p.nrows > 0 ? p.nrows : p.n) / kDgTile);
+    const int chunks = (p.nrep + kDsCoils - 1) / kDsCoils;
+    size_t nruns = 0;
+    int t0 = 0;
+    for (int c = 0; c < 5; ++c) {
+        const int t1 = c < 4 ? std::min(p.group_end[c], ntiles) : ntiles;
+        const int g = std::min(1 << c, p.group_max);
+        nruns += (size_t)std::max(t1 - t0, 0) * ((p.nimg + g - 1) / g);
+        t0 = std::max(t0, t1);
+    }
+    dim3 grid((unsigned)(((nruns + 7) / 8) * 8 * chunks));
+    const size_t lds = sizeof(DsLds<CW>);
+    static_assert(sizeof(DsLds<CW>) <= 160 * 1024, "two tile buffers and the spoke lists must fit the CU's LDS");
+    if (kb_mode == TRON_KB_EXACT) {
+        static hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(degrid_stream_kernel<CW, TR, TRON_KB_EXACT>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(DsLds<CW>));
+        if (once != hipSuccess) return once;
+        hipLaunchKernelGGL((degrid_stream_kernel<CW, TR, TRON_KB_EXACT>), grid, dim3(kDsThreads), lds, s, p);
+    } else {
+        static hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(degrid_stream_kernel<CW, TR, TRON_KB_FAST>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(DsLds<CW>));
+        if (once != hipSuccess) return once;
+        hipLaunchKernelGGL((degrid_stream_kernel<CW, TR, TRON_KB_FAST>), grid, dim3(kDsThreads), lds, s, p);
+    }
+    return hipGetLastError();
+}
+
+// Launches of many images on grids of whole tiles: see the head of this file.  Anything else: degrid_tile_kernel.
+bool degrid_stream_supported(const DegridParams &p, int kb_mode)
+{
+    const int nr = p.nrows > 0 ? p.nrows : p.n;
+    const int cw = (int)ceilf(p.W);
+    return cw >= 1 && cw <= (kb_mode == TRON_KB_EXACT ? 4 : 2) && p.tile_order && p.in_p == 1 && p.n % kDgTile == 0 && nr % kDgTile == 0 && p.n >= 2 * kDgTile && nr >= 2 * kDgTile
+           && p.nrep >= kDsCoils && p.group_max >= 4 && p.nro <= 0x7fff
+           && ((size_t)kDsCoils * p.in_c + (size_t)p.n * nr) * sizeof(float2) < (1ull << 32);
+}
+
+hipError_t launch_degrid_stream(const DegridParams &p, int kb_mode, hipStream_t s)
+{
+    const int cw = (int)ceilf(p.W);
+    if (p.in_transposed) {
+        switch (cw) {
+            case 1: return launch_degrid_stream_cw<1, true>(p, kb_mode, s);
+            case 2: return launch_degrid_stream_cw<2, true>(p, kb_mode, s);
+            case 3: return launch_degrid_stream_cw<3, true>(p, kb_mode, s);
+            case 4: return launch_degrid_stream_cw<4, true>(p, kb_mode, s);
+        }
+    } else {
+        switch (cw) {
+            case 1: return launch_degrid_stream_cw<1, false>(p, kb_mode, s);
+            case 2: return launch_degrid_stream_cw<2, false>(p, kb_mode, s);
+            case 3: return launch_degrid_stream_cw<3, false>(p, kb_mode, s);
+            case 4: return launch_degrid_stream_cw<4, false>(p, kb_mode, s);
+        }
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace tron

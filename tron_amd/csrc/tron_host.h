@@ -26,6 +26,10 @@ void build_band_table(int nxos, float kernwidth, uint32_t *band);
 void build_deapod_table(int n, float kernwidth, float sigma, float *inv_weight);
 void build_deapod_table_rect(int rows, int cols, float kernwidth, float sigma, float *inv_weight);
 void build_tile_order(int nxos, int tile, std::vector<int> &order);
+// run-length classes of the streaming degridding kernel over build_tile_order's centre-first positions: a tile expected to hold
+// `est` samples per image takes runs of 2^c images, c the smallest with est * 2^c >= target (c <= 4); end[c] = first position
+// past class c (classes are made monotone along the order)
+void build_degrid_groups(int nxos, int tile, int npe, int nro, int target, int end[4]);
 void build_split_tile_order(int nxos, int tile, int npe, float W, int target, int max_parts,
                             std::vector<int> &order, std::vector<int> &slots);
 bool build_centre_relief_order(int nxos, int tile, int npe, float W, int max_parts, int &inner_r0, std::vector<int> &order, std::vector<int> &slots,

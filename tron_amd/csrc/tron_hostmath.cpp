@@ -312,6 +312,26 @@ void build_tile_order(int nxos, int tile, std::vector<int> &order)
     for (size_t i = 0; i < t.size(); ++i) order[i] = t[i].id;
 }
 
+void build_degrid_groups(int nxos, int tile, int npe, int nro, int target, int end[4])
+{
+    std::vector<int> order;
+    build_tile_order(nxos, tile, order);
+    const int tpr = (nxos + tile - 1) / tile;
+    int cls = 0;
+    for (int c = 0; c < 4; ++c) end[c] = (int)order.size();
+    for (size_t pos = 0; pos < order.size(); ++pos) {
+        const int id = order[pos];
+        const int x0 = (id % tpr) * tile - nxos / 2, y0 = (id / tpr) * tile - nxos / 2;
+        double dens = 0.0;                                   // radial sampling density npe / (pi r) per unit area, nro / nxos samples per cell
+        for (int y = y0; y < y0 + tile; ++y)
+            for (int x = x0; x < x0 + tile; ++x) dens += 1.0 / std::max(0.5, sqrt((x + 0.5) * (x + 0.5) + (y + 0.5) * (y + 0.5)));
+        const double est = npe / M_PI * dens * nro / std::max(nxos, 1);
+        int need = 0;
+        while (need < 4 && est * (1 << need) < target) ++need;
+        while (cls < need) end[cls++] = (int)pos;            // classes only grow along the order
+    }
+}
+
 // Tile list of the binned gridding kernel for SMALL launches: a tile expected to hold more than `target` sample records
 // per image is dealt to several workgroups over disjoint spoke ranges (entry = tile | part << 16 | parts << 20 | slot << 24),
 // so that its serial chain no longer bounds the launch.  Expected records of a tile = integral of the radial sampling

@@ -90,6 +90,8 @@ struct DegridParams {
     int in_p, in_shift;       // pixel stride; 1: input is the raw FFT output (second fftshift folded into indexing)
     int in_transposed;        // degrid_tile_kernel: input planes are stored [col][row] (fused forward FFT)
     int debug;                // TRON_DEBUG_SKIP (timing bisection): 1 = no sample loop, 2 = tile load only
+    int group_end[4];         // degrid_stream_kernel: tile_order positions [group_end[c-1], group_end[c]) take runs of 2^c images (c = 4: the rest)
+    int group_max;            // ... capped by this (a quarter of the launch's images at most); < 4: degrid_tile_kernel only (8 images of 8 coils: 2.07 vs 1.79 us per coil image there)
     int n, nrep, nro, npe, nimg;
     int nrows;                // simple kernel only: rows of a non-square grid (0: n); n is then the column count
     float W, beta;
@@ -144,8 +146,12 @@ hipError_t launch_cg_axpy(float2 *y, const float2 *x, const float *coef, float s
 hipError_t launch_cg_update(float2 *x, float2 *pt, const float2 *zt, const float *alpha, const float *beta, size_t n, int nslices, int last, hipStream_t s);
 hipError_t launch_coil_combine(float2 *out, const float2 *coil, int nimg, int nc, int nt, int mode, int npatch, int nslices, hipStream_t s);
 constexpr int kCgPartials = 64;  // = kCgBlocks
-// tiled degridding (tron_degrid_tile.hip), W <= 3
+// tiled degridding (tron_degrid_tile.hip), W <= 4
 hipError_t launch_degrid_tile(const DegridParams &p, int kb_mode, hipStream_t s);
+// the same for launches of many images: one workgroup walks a run of images of its tile, the next tile buffer arriving by
+// LDS-DMA while the current one is sampled (tron_degrid_stream.hip); launch only what degrid_stream_supported accepts
+bool degrid_stream_supported(const DegridParams &p, int kb_mode);   // fast weights: W <= 2 (wider unrolled weight sets spill at 128 registers)
+hipError_t launch_degrid_stream(const DegridParams &p, int kb_mode, hipStream_t s);
 // fused pruned inverse FFT + crop + deapodise + SoS for nxos = 512, nx = 256 (tron_fft512.hip)
 // rzero: grid points at integer radius > rzero hold zeros by construction and are not read (0 = read everything)
 hipError_t launch_fft512_adjoint(const float2 *grid, float2 *tmp, float2 *out, const float2 *tw, const float *inv_deapod, int rzero,

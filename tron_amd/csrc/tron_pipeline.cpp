@@ -414,9 +414,15 @@ int forward_run(tron_plan *p, void *d_out, const void *d_in, int nimg, const flo
         g.W = p->cfg.kernwidth;
         g.beta = p->beta;
         memcpy(g.kb_poly, p->kb_poly, sizeof(g.kb_poly));
+        memcpy(g.group_end, p->dg_group_end, sizeof(g.group_end));
+        g.group_max = (square && !p->degrid_tile_only) ? std::min(16, ck / 4) : 0;   // runs of images only where they leave enough workgroups
         {
             StageTimer t(p, STAGE_DEGRID);
-            if (!p->degrid_simple)
+            const bool stream = !p->degrid_simple && degrid_stream_supported(g, p->kb_mode);
+            p->last_degrid_kernel = stream ? "degrid_stream_kernel" : p->degrid_simple ? "degrid_kernel" : "degrid_tile_kernel";
+            if (stream)
+                HIP_TRY(launch_degrid_stream(g, p->kb_mode, p->stream)); // many images on a grid of whole tiles
+            else if (!p->degrid_simple)
                 HIP_TRY(launch_degrid_tile(g, p->kb_mode, p->stream));  // every width the plan accepts (W <= 4), square or not
             else
                 HIP_TRY(launch_degrid(g, p->kb_mode, p->stream));       // TRON_DEGRID_SIMPLE=1: the thread-per-sample audit kernel

@@ -147,6 +147,10 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
         std::vector<int> order;
         build_tile_order(d.nxos, kBinnedTile, order);
         if ((rc = upload(&p->d_tile_order32, order.data(), order.size() * sizeof(int)))) return bail(rc);
+        if (!cfg->adjoint) {
+            static const int target = tuning_env("TRON_DEGRID_RUN") ? atoi(tuning_env("TRON_DEGRID_RUN")) : 24000;   // tuning knob: samples per run
+            build_degrid_groups(d.nxos, kBinnedTile, d.npe1work, d.nro, target, p->dg_group_end);
+        }
     }
     if (cfg->adjoint) {
         std::vector<uint32_t> band(n2);
@@ -372,6 +376,7 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
     p->debug_skip = 0;
     if (const char *dbg = tuning_env("TRON_DEBUG_SKIP")) p->debug_skip = atoi(dbg);
     p->degrid_simple = tuning_env("TRON_DEGRID_SIMPLE") != nullptr;
+    p->degrid_tile_only = tuning_env("TRON_DEGRID_TILE") != nullptr;      // tuning knob: never the streaming degridding kernel
     if (const char *sp = tuning_env("TRON_SLICES_PER_PASS")) p->slices_per_pass = atoi(sp) != 0;
     if (const char *lp = tuning_env("TRON_GRID_LDS_PAD")) p->grid_lds_pad = atoi(lp);
     p->no_disc = tuning_env("TRON_NO_DISC") != nullptr;
@@ -446,6 +451,11 @@ extern "C" const char *tron_plan_grid_kernel_name(const tron_plan *p)
     if (p->arc) return "grid_arc_kernel (+ grid_binned_kernel on the inner tile, grid_reduce_parts_kernel)";
     if (p->binned) return p->relief_entries > 0 ? "grid_binned_kernel (+ grid_reduce_parts_kernel)" : "grid_binned_kernel";
     return "grid_tile_kernel";
+}
+
+extern "C" const char *tron_plan_degrid_kernel_name(const tron_plan *p)
+{
+    return p ? p->last_degrid_kernel : "";
 }
 
 extern "C" int tron_plan_sync(tron_plan *p)
@@ -568,6 +578,7 @@ extern "C" int tron_degridradial2d(tron_plan *p, void *d_nudata, const void *d_u
     g.beta = p->beta;
     memcpy(g.kb_poly, p->kb_poly, sizeof(g.kb_poly));
     StageTimer t(p, STAGE_DEGRID);
+    p->last_degrid_kernel = p->degrid_simple ? "degrid_kernel" : "degrid_tile_kernel";
     if (!p->degrid_simple)
         HIP_TRY(launch_degrid_tile(g, p->kb_mode, p->stream));
     else

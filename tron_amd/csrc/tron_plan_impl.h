@@ -70,6 +70,7 @@ struct tron_plan {
     uint32_t *d_band = nullptr;
     int *d_tile_order = nullptr;
     int *d_tile_order32 = nullptr;   // 32x32 tiles of the binned (fast) gridding kernel
+    int dg_group_end[4] = {0, 0, 0, 0};   // forward: run-length classes of the streaming degridding kernel over that order
     bool binned = false;
     // small launches of the binned kernel: heavy (k-space-centre) tiles dealt to several workgroups each
     int *d_tile_order32_split = nullptr, *d_split_slots = nullptr;
@@ -134,7 +135,8 @@ struct tron_plan {
     bool slices_per_pass = true;   // TRON_SLICES_PER_PASS=0 turns the linear-angle slice grouping off (A/B, tests)
     bool poison = false;           // TRON_POISON_GRID (tests): NaN-fill the work grid
     int debug_skip = 0;            // environment knobs, read once at plan creation (never on the launch path)
-    bool degrid_simple = false, no_disc = false;
+    bool degrid_simple = false, degrid_tile_only = false, no_disc = false;
+    const char *last_degrid_kernel = "";   // tron_plan_degrid_kernel_name
     bool pin_host = false;         // hipHostRegister the caller's buffers in tron_recon_radial2d[_range]
     bool timing = false;
     bool sync_each = false;        // TRON_SYNC_EACH=1: synchronise after every launch and name the failing stage

@@ -55,7 +55,7 @@ EXPORTS = [
     "tron_config_default", "tron_derive_dims", "tron_plan_create", "tron_plan_destroy",
     "tron_recon_radial2d", "tron_recon_radial2d_range", "tron_recon_radial2d_block", "tron_recon_radial2d_multi", "tron_nufft_adj_radial2d", "tron_cgnr_radial2d", "tron_nufft_radial2d",
     "tron_precompensate", "tron_gridradial2d", "tron_degridradial2d", "tron_plan_sync",
-    "tron_plan_timing", "tron_plan_timing_get", "tron_plan_timing_reset", "tron_plan_two_lanes", "tron_plan_grid_kernel_name",
+    "tron_plan_timing", "tron_plan_timing_get", "tron_plan_timing_reset", "tron_plan_two_lanes", "tron_plan_grid_kernel_name", "tron_plan_degrid_kernel_name",
     "tron_host_trig_table", "tron_host_band_table", "tron_host_deapod_table", "tron_host_numa_cpulist",
     "tron_device_count", "tron_device_malloc", "tron_device_free", "tron_memcpy_h2d", "tron_memcpy_d2h",
     "tron_last_error", "tron_version",
@@ -102,6 +102,7 @@ def load():
     sig("tron_plan_sync", i, [p])
     sig("tron_plan_two_lanes", i, [p, i, ctypes.POINTER(i)])
     sig("tron_plan_grid_kernel_name", ctypes.c_char_p, [p])
+    sig("tron_plan_degrid_kernel_name", ctypes.c_char_p, [p])
     sig("tron_host_numa_cpulist", i, [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(i), i])
     sig("tron_plan_timing", i, [p, i])
     sig("tron_plan_timing_get", i, [p, i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)])
@@ -274,6 +275,10 @@ class Plan:
     def grid_kernel_name(self) -> str:
         """Which gridding kernels this plan launches (bench.py's roofline line, the traffic captures)."""
         return load().tron_plan_grid_kernel_name(self._h).decode()
+
+    def degrid_kernel_name(self) -> str:
+        """Which degridding kernel the most recent forward launch of this plan ran ("" before the first)."""
+        return load().tron_plan_degrid_kernel_name(self._h).decode()
 
     def two_lanes(self, enable=True) -> bool:
         """Serialise (False) or restore (True) the gridding || FFT overlap; returns whether the plan has a second lane."""
