@@ -21,9 +21,25 @@ namespace tron {
 constexpr int kF = 512;         // line length
 constexpr int kFKeep = 256;     // outputs kept per line
 constexpr int kLinesPerWg = 16; // lines per workgroup (4 waves x 4 lines): 128-byte transposed segments
-constexpr int kPA = 72;         // LDS pitches (float2 units) chosen for <= 2-way bank conflicts
-constexpr int kPB = 65;
-constexpr int kXch = 8 * kPA;   // exchange region per wave (float2), >= 8*kPB
+constexpr int kPA = 72;         // LDS pitch (float2 units) of the first exchange: stage B's loads fall on 32 distinct bank pairs
+constexpr int kXch = 8 * kPA;   // exchange region per wave (float2), >= the 512 points of the second exchange
+
+// One ds_read_b64 at LDS byte address a.  volatile: hipcc pairs neighbouring 8-byte LDS loads into ds_read2_b64 /
+// ds_read2st64_b64, which move 128 B per clock on a 32-bank modulus where ds_read_b64 moves 256 on 64 banks -- the FFT
+// kernels kept the LDS busy for 73 % of their time, 41 % of that in bank conflicts.
+__device__ __forceinline__ float2 lds_ld64(const unsigned a)
+{
+    const v2f t = *(const volatile __attribute__((address_space(3))) v2f *)(size_t)a;
+    return make_float2(t.x, t.y);
+}
+
+// Second exchange (stage B -> stage C), point (j1, k1, m2) of the 8 x 8 x 8 cube: the eight points a stage-C thread reads
+// lie 32 apart, and within a 32-point block the slot is (4 k1 + (j1 & 3)) ^ g(m2).  Stage C's loads (m2 fixed, lanes over
+// k1 and j1 & 3) then fall on 32 distinct bank pairs; stage B's stores (j1 fixed, 16-lane groups over m2 and k1 & 1) on 16.
+__device__ __forceinline__ int xch2_index(const int j1, const int k1, const int m2)
+{
+    return (j1 >> 2) * 256 + m2 * 32 + ((k1 * 4 + (j1 & 3)) ^ ((m2 & 3) | ((m2 >> 2) << 3)));
+}
 
 __device__ __forceinline__ float2 cmul(const float2 a, const float2 w)
 {
@@ -76,24 +92,25 @@ __device__ __forceinline__ void fft512_inv(float2 v[8], float2 *xch, const float
 #pragma unroll
     for (int k1 = 0; k1 < 8; ++k1) xch[k1 * kPA + lane] = v[k1];
     wave_lds_fence();
+    const unsigned xa = lds_addr(xch);
     // stage B: thread (k1 = lane>>3, m2 = lane&7): DFT over m1, twiddle w64^(m2*j1)
     {
         const int k1 = lane >> 3, m2 = lane & 7;
 #pragma unroll
-        for (int m1 = 0; m1 < 8; ++m1) v[m1] = xch[k1 * kPA + m1 * 8 + m2];
+        for (int m1 = 0; m1 < 8; ++m1) v[m1] = lds_ld64(xa + (unsigned)((k1 * kPA + m1 * 8 + m2) * (int)sizeof(float2)));
         wave_lds_fence();                                                  // stage B's stores reuse the region at another pitch
         dft8_inv(v);
 #pragma unroll
         for (int j1 = 1; j1 < 8; ++j1) v[j1] = cmul(v[j1], tw[(8 * m2 * j1) & 511]);
 #pragma unroll
-        for (int j1 = 0; j1 < 8; ++j1) xch[j1 * kPB + lane] = v[j1];      // B[j1][k1*8 + m2]
+        for (int j1 = 0; j1 < 8; ++j1) xch[xch2_index(j1, k1, m2)] = v[j1];   // B[j1][k1*8 + m2]
     }
     wave_lds_fence();
     // stage C: thread (k1 = lane&7, j1 = lane>>3): DFT over m2 -> X[k1 + 8*j1 + 64*j2]
     {
         const int k1 = lane & 7, j1 = lane >> 3;
 #pragma unroll
-        for (int m2 = 0; m2 < 8; ++m2) v[m2] = xch[j1 * kPB + k1 * 8 + m2];
+        for (int m2 = 0; m2 < 8; ++m2) v[m2] = lds_ld64(xa + (unsigned)(xch2_index(j1, k1, m2) * (int)sizeof(float2)));
         wave_lds_fence();                                                  // the next line's stage A stores come after these loads
         dft8_inv(v);
     }
@@ -167,7 +184,7 @@ __global__ void __launch_bounds__(256) fft512_rows_kernel(const Fft512Params p)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // line j has landed
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const float2 t = lbuf[q * 64 + lane];
+            const float2 t = lds_ld64(lds_addr(lbuf) + (unsigned)((q * 64 + lane) * (int)sizeof(float2)));
             v[q] = inside(q * 64 + lane, lim) ? t : make_float2(0.f, 0.f);
         }
         if (j < 3) {
@@ -320,7 +337,7 @@ __global__ void __launch_bounds__(256, 4) fft512_cols_post_kernel(const Fft512Pa
             float2 v[8];
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this line has landed
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = lbuf[q * 64 + lane];
+            for (int q = 0; q < 8; ++q) v[q] = lds_ld64(lds_addr(lbuf) + (unsigned)((q * 64 + lane) * (int)sizeof(float2)));
             {
                 const int jn = (j + 1) % LPW, cn = c + (j == LPW - 1 ? 1 : 0);
                 if (cn < nloop) {
