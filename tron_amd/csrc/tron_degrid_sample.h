@@ -22,7 +22,8 @@ struct DgLists {
     int sp_start[MAXSP + 1];       // exclusive scan of len
     float2 sp_cs[MAXSP];           // (cos, sin) of the accepted spokes: the sample loop stays off global memory
     int wcnt[2 * NWAVES];
-    unsigned short first[MAXB];    // spoke slot holding record 64*b: starts the per-lane spoke search
+    unsigned short first[MAXB];    // spoke slot holding record 64*b
+    alignas(8) unsigned int segbits[2 * MAXB];   // bit r: record r is the first of its spoke's segment (64 records per wave pass: one 8-byte word)
 };
 
 struct DgRound {
@@ -112,10 +113,14 @@ __device__ __forceinline__ DgRound dg_clip_round(const DegridParams &p, Lists &L
     r.nrec = L.sp_start[nacc];
     r.mapped = r.nrec <= 64 * MAXB;
     if (r.mapped) {
-        // inverse map: which spoke holds record 64*b (a wave pass covers exactly one such block)
+        // inverse map: which spoke holds record 64*b (a wave pass covers exactly one such block), and where the segments
+        // start inside the block: a lane's spoke is first[b] + the segment starts at records (64 b, rec]
+        for (int w = tid; w < 2 * ((r.nrec + 63) >> 6); w += NT) L.segbits[w] = 0u;
+        __syncthreads();
         for (int sidx = tid; sidx < nacc; sidx += NT) {
             const int st = L.sp_start[sidx], en = L.sp_start[sidx + 1];
             for (int b = (st + 63) >> 6; 64 * b < en; ++b) L.first[b] = (unsigned short)sidx;
+            atomicOr(&L.segbits[st >> 5], 1u << (st & 31));
         }
         __syncthreads();
     }
@@ -140,19 +145,12 @@ __device__ __forceinline__ void dg_sample_loop(const DegridParams &p, const KbCo
         // spoke holding record `rec`: largest s with sp_start[s] <= rec
         int lo;
         if (rd.mapped) {
-            // start at the spoke of the pass's first record, then count the segment starts up to `rec`, four
-            // independent LDS reads at a time (segments are tens of records long: one round as a rule)
-            lo = L.first[rec >> 6];
-            for (;;) {
-                int sv[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) sv[j] = L.sp_start[min(lo + 1 + j, nacc)];   // sp_start[nacc] = nrec > rec
-                int cnt = 0;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) cnt += sv[j] <= rec ? 1 : 0;
-                lo += cnt;
-                if (cnt < 4) break;
-            }
+            // the spoke of the pass's first record plus the segment starts between it and `rec`: two wave-uniform LDS
+            // reads and a population count (a search over sp_start cost two more dependent LDS round trips per pass)
+            const int b = rec >> 6;
+            const unsigned long long starts = *reinterpret_cast<const unsigned long long *>(&L.segbits[2 * b]);
+            const unsigned long long upto = ((2ull << (tid & 63)) - 1ull) & ~1ull;     // records (64 b, rec]
+            lo = L.first[b] + __popcll(starts & upto);
         } else {
             // 8-ary search: the seven splitters of a round are independent LDS reads
             lo = 0;

@@ -16,7 +16,8 @@ namespace tron {
 
 constexpr int kDgThreads = 256;
 constexpr int kDgMaxSpokes = 256;   // spokes clipped per round (one per thread)
-constexpr int kDgMaxBlocks = 256;   // 64-record blocks indexed by the inverse map (more records: 8-ary search)
+constexpr int kDgMaxBlocks = 192;   // 64-record blocks indexed by the inverse map (more records: 8-ary search); 256 spokes x 47 samples
+                                    // fit, and three workgroups' LDS still fits the CU (1280-byte allocation granules)
 
 template <int CPB, int CW>
 struct DgLds : DgLists<kDgMaxSpokes, kDgMaxBlocks, kDgThreads / 64> {
