@@ -720,6 +720,75 @@ __global__ void __launch_bounds__(256) fft512_fwd_cols_kernel(const Fft512FwdPar
     }
 }
 
+// Pass 2 with the next block on its way while the current one is transformed.  fft512_fwd_cols_kernel loads a 256 x 16
+// block, waits, transforms and stores, four workgroups per CU overlapping by chance: 3.5 TB/s of its own traffic, where the
+// adjoint passes reach 4.8 with their LDS-DMA prefetch.  Here one workgroup of 1 024 threads (16 waves = the 16 columns
+// of a block, four waves per SIMD as there) owns the CU and walks kFwdColBlocks consecutive column blocks of one coil
+// image: block b + 1 is copied global -> LDS (global_load_lds_dwordx4: no registers) into the second of two 32 KiB
+// buffers while block b is transformed.  A buffer holds the block as it lies in memory, [row][16 columns], the 16-byte
+// column pairs of a row XOR-swizzled with the row so that a column read (64 rows, one per lane) is 2-way instead of
+// 16-way conflicted.  The copy is waited for BEFORE the block's lines are stored: it has had the transform's time to
+// land, and the stores are never waited for.  Twiddles come from LDS (a compiler-tracked global load between the
+// copy's issue and its use would make the compiler's s_waitcnt drain the copy).
+constexpr int kFwdColThreads = 1024;
+#ifndef TRON_FWD_COL_BLOCKS
+#define TRON_FWD_COL_BLOCKS 8
+#endif
+constexpr int kFwdColBlocks = TRON_FWD_COL_BLOCKS;   // column blocks per workgroup
+constexpr int kFwdColBuf = kFKeep * kLinesPerWg;   // float2 per buffer
+constexpr size_t kFwdColLds = (2 * kFwdColBuf + (kFwdColThreads / 64) * kXch + kF) * sizeof(float2);
+
+__global__ void __launch_bounds__(kFwdColThreads) fft512_fwd_cols_dma_kernel(const Fft512FwdParams p)
+{
+    extern __shared__ __align__(16) float2 s_dyn[];            // two block buffers | exchange regions | twiddles
+    float2 *s_in = s_dyn;
+    float2 *xch = s_dyn + 2 * kFwdColBuf + (threadIdx.x >> 6) * kXch;
+    float2 *s_tw = s_dyn + 2 * kFwdColBuf + (kFwdColThreads / 64) * kXch;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ci = blockIdx.y;
+    const int b0 = blockIdx.x * kFwdColBlocks;
+    const float2 *src = p.tmp + (size_t)ci * kFKeep * kF;
+    float2 *dst = p.out + (size_t)ci * kF * kF;
+    // piece q = 16 bytes = columns 2 cp, 2 cp + 1 of row q >> 3; it lands at slot (q & 7) of its row, cp = slot ^ ((row >> 1) & 7)
+    auto fetch = [&](const int blk, const int buf) {
+#pragma unroll
+        for (int it = 0; it < kFwdColBuf / 2 / kFwdColThreads; ++it) {
+            const int q = it * kFwdColThreads + threadIdx.x;
+            const int row = q >> 3, cp = (q & 7) ^ ((row >> 1) & 7);
+            lds_dma16_nt(src + (size_t)row * kF + blk * kLinesPerWg + 2 * cp,
+                         lds_addr(s_in) + (unsigned)((buf * kFwdColBuf + 2 * (it * kFwdColThreads + wave * 64)) * sizeof(float2)));
+        }
+    };
+    fetch(b0, 0);
+    for (int i = threadIdx.x; i < kF; i += kFwdColThreads) s_tw[i] = p.tw[i];
+    for (int b = 0; b < kFwdColBlocks; ++b) {
+        const int buf = b & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this thread's pieces of block b have landed
+        __syncthreads();                                        // ... everybody's; and nobody still reads the other buffer
+        if (b + 1 < kFwdColBlocks) fetch(b0 + b + 1, buf ^ 1);
+        // FFT-input row sr = 64q + lane holds padded row (sr + 256) % 512 = 128 + r:  q = 0,1 -> r = 128 + sr; q = 6,7 -> r = sr - 384
+        const unsigned in0 = lds_addr(s_in) + (unsigned)(buf * kFwdColBuf * sizeof(float2));
+        auto at = [&](const int row) {
+            const int cp = (wave >> 1) ^ ((row >> 1) & 7);
+            return lds_ld64(in0 + (unsigned)((row * kLinesPerWg + 2 * cp + (wave & 1)) * (int)sizeof(float2)));
+        };
+        float2 v[8];
+        v[0] = cconj(at(128 + lane)); v[1] = cconj(at(192 + lane)); v[6] = cconj(at(lane)); v[7] = cconj(at(64 + lane));
+        v[2] = v[3] = v[4] = v[5] = make_float2(0.f, 0.f);
+        fft512_inv(v, xch, s_tw, lane);
+        const int k2 = (b0 + b) * kLinesPerWg + wave;
+        float2 *line = dst + (size_t)k2 * kF;
+        const int yc = k2 < kF / 2 ? k2 : k2 - kF;              // FFT-native index -> centred coordinate
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the copy of block b + 1 (issued a transform ago), not the stores below
+#pragma unroll
+        for (int j2 = 0; j2 < 8; ++j2) {
+            const int k1 = lane + 64 * j2;
+            const int xc = k1 < kF / 2 ? k1 : k1 - kF;
+            if (p.rzero2 <= 0 || xc * xc + yc * yc <= p.rzero2) line[k1] = cconj(v[j2]);
+        }
+    }
+}
+
 hipError_t launch_fft512_forward(const float2 *img, float2 *tmp, float2 *out, const float2 *tw, const float *inv_deapod, int rzero,
                                  int nchan, int nimg, hipStream_t s)
 {
@@ -737,7 +806,15 @@ hipError_t launch_fft512_forward(const float2 *img, float2 *tmp, float2 *out, co
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(fft512_fwd_cols_kernel, dim3(kF / kLinesPerWg, nimg * nchan), dim3(256), 0, s, p);
+    static const bool cols_plain = tuning_env("TRON_FFT_FWD_COLS_PLAIN") != nullptr;     // tuning knob: the pass without the LDS-DMA prefetch
+    if (cols_plain) {
+        hipLaunchKernelGGL(fft512_fwd_cols_kernel, dim3(kF / kLinesPerWg, nimg * nchan), dim3(256), 0, s, p);
+    } else {
+        static hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(fft512_fwd_cols_dma_kernel),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwdColLds);
+        if (once != hipSuccess) return once;
+        hipLaunchKernelGGL(fft512_fwd_cols_dma_kernel, dim3(kF / kLinesPerWg / kFwdColBlocks, nimg * nchan), dim3(kFwdColThreads), kFwdColLds, s, p);
+    }
     return hipGetLastError();
 }
 
