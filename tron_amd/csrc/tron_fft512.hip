@@ -720,6 +720,68 @@ __global__ void __launch_bounds__(256) fft512_fwd_cols_kernel(const Fft512FwdPar
     }
 }
 
+// Pass 1 the same way (see fft512_fwd_cols_dma_kernel below for the scheme): one workgroup of 1 024 threads walks
+// kFwdRowSteps steps of `rows` consecutive image rows with all their coils -- a contiguous piece of the coil-interleaved
+// image, copied as it lies -- and the 1/w factors of those rows; wave = line (row, coil).  grid = (256 / (rows * steps), nimg).
+constexpr int kFwdRowThreads = 1024;
+constexpr int kFwdRowSteps = 8;
+
+__global__ void __launch_bounds__(kFwdRowThreads) fft512_fwd_rows_dma_kernel(const Fft512FwdParams p, const int rows)
+{
+    extern __shared__ __align__(16) float2 s_dyn[];            // exchange regions | twiddles | two image buffers | two 1/w buffers
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float2 *xch = s_dyn + wave * kXch;
+    float2 *s_tw = s_dyn + (kFwdRowThreads / 64) * kXch;
+    float2 *s_in = s_tw + kF;
+    const int belems = rows * kFKeep * p.nchan;                 // float2 per image buffer
+    float *s_inv = reinterpret_cast<float *>(s_in + 2 * belems);   // [buf][row in step][256]
+    const int k = blockIdx.y;
+    const int r0 = blockIdx.x * rows * kFwdRowSteps;
+    const int nlines = rows * p.nchan;
+    auto fetch = [&](const int step, const int buf) {
+        const float2 *src = p.img + ((size_t)k * kFKeep + r0 + step * rows) * kFKeep * p.nchan;
+        for (int q0 = wave * 64; q0 < belems / 2; q0 += kFwdRowThreads)
+            if (q0 + lane < belems / 2)
+                lds_dma16(src + 2 * (q0 + lane), lds_addr(s_in) + (unsigned)((buf * belems + 2 * q0) * sizeof(float2)));
+        if (wave < rows)                                        // the row's 1/w factors at padded columns 128 .. 383 (src/tron.cu:398-400)
+            lds_dma16(p.inv_deapod + (size_t)(r0 + step * rows + wave + 128) * kF + 128 + 4 * lane,
+                      lds_addr(s_inv) + (unsigned)((buf * rows + wave) * kFKeep * sizeof(float)));
+    };
+    fetch(0, 0);
+    for (int i = threadIdx.x; i < kF; i += kFwdRowThreads) s_tw[i] = p.tw[i];
+    for (int step = 0; step < kFwdRowSteps; ++step) {
+        const int buf = step & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this thread's pieces of the step have landed
+        __syncthreads();                                        // ... everybody's; and nobody still reads the other buffer
+        if (step + 1 < kFwdRowSteps) fetch(step + 1, buf ^ 1);
+        if (wave < nlines) {
+            const int rl = wave / p.nchan, c = wave - rl * p.nchan;
+            const int r = r0 + step * rows + rl;
+            const unsigned lin = lds_addr(s_in) + (unsigned)((buf * belems + rl * kFKeep * p.nchan + c) * sizeof(float2));
+            const unsigned inv0 = lds_addr(s_inv) + (unsigned)((buf * rows + rl) * kFKeep * sizeof(float));
+            float2 v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {                       // same index map as fft512_fwd_rows_kernel
+                const int q = t < 2 ? t : t + 4;
+                const int y = t < 2 ? 128 + 64 * q + lane : 64 * (q - 6) + lane;
+                if (r > 0 && y > 0) {                                                   // src/tron.cu:449-450
+                    float2 u = lds_ld64(lin + (unsigned)(y * p.nchan * (int)sizeof(float2)));
+                    const float inv = *(const volatile __attribute__((address_space(3))) float *)(size_t)(inv0 + (unsigned)(y * 4));
+                    u.x *= inv; u.y *= inv;
+                    v[q] = cconj(u);
+                }
+            }
+            fft512_inv(v, xch, s_tw, lane);
+            float2 *line = p.tmp + ((size_t)(k * p.nchan + c) * kFKeep + r) * kF;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the next step's copy (issued a transform ago), not the stores below
+#pragma unroll
+            for (int j2 = 0; j2 < 8; ++j2) line[lane + 64 * j2] = cconj(v[j2]);
+        }
+    }
+}
+
 // Pass 2 with the next block on its way while the current one is transformed.  fft512_fwd_cols_kernel loads a 256 x 16
 // block, waits, transforms and stores, four workgroups per CU overlapping by chance: 3.5 TB/s of its own traffic, where the
 // adjoint passes reach 4.8 with their LDS-DMA prefetch.  Here one workgroup of 1 024 threads (16 waves = the 16 columns
@@ -799,8 +861,18 @@ hipError_t launch_fft512_forward(const float2 *img, float2 *tmp, float2 *out, co
         int rows = 16 / nchan;                                  // about 16 lines per workgroup
         if (rows < 1) rows = 1;
         while (kFKeep % rows) --rows;
-        const size_t lds = (size_t)rows * nchan * kInPitch * sizeof(float2);   // <= 33 KiB
-        hipLaunchKernelGGL(fft512_fwd_rows_lds_kernel, dim3(kFKeep / rows, nimg), dim3(256), lds, s, p, rows);
+        static const bool rows_plain = tuning_env("TRON_FFT_FWD_ROWS_PLAIN") != nullptr;   // tuning knob: the pass without the LDS-DMA prefetch
+        if (!rows_plain && kFKeep % (rows * kFwdRowSteps) == 0) {
+            const size_t lds = ((kFwdRowThreads / 64) * kXch + kF + 2 * (size_t)rows * kFKeep * nchan) * sizeof(float2)
+                               + 2 * (size_t)rows * kFKeep * sizeof(float);             // <= 146 KiB
+            static hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(fft512_fwd_rows_dma_kernel),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (once != hipSuccess) return once;
+            hipLaunchKernelGGL(fft512_fwd_rows_dma_kernel, dim3(kFKeep / (rows * kFwdRowSteps), nimg), dim3(kFwdRowThreads), lds, s, p, rows);
+        } else {
+            const size_t lds = (size_t)rows * nchan * kInPitch * sizeof(float2);   // <= 33 KiB
+            hipLaunchKernelGGL(fft512_fwd_rows_lds_kernel, dim3(kFKeep / rows, nimg), dim3(256), lds, s, p, rows);
+        }
     } else {
         hipLaunchKernelGGL(fft512_fwd_rows_kernel, dim3(kFKeep / kLinesPerWg, nimg * nchan), dim3(256), 0, s, p);
     }
