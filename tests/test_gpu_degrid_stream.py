@@ -71,6 +71,18 @@ def test_stream_kernel_vs_oracle(oracle, kb):
         assert rel_l2(got[k], want.reshape(-1, order="F")) <= TOL_PIPELINE, k
 
 
+@pytest.mark.parametrize("nc", [2, 6, 10, 12, 16])
+def test_fused_forward_fft_coil_counts_vs_oracle(oracle, nc):
+    """The fused 256 -> 512 forward FFT passes (tron_fft512.hip: next block by LDS-DMA beside the transform) take `rows` image
+    rows x all coils per step, rows = 16 // nc (8, 2, 1, 1, 1 here): coil counts that do and do not divide 16 (odd counts other than 1: src/tron.cu:963 rejects them)."""
+    img = synth.image(nc, 256, seed=9600 + nc)
+    us = 24 / 512 + 1e-6
+    want, p = oracle.recon(img, adjoint=0, golden=1, data_undersamp=us)
+    assert (p.nxos, p.nx) == (512, 256)
+    got, _ = lib.recon(img, adjoint=False, golden_angle=1, data_undersamp=us)
+    assert rel_l2(got, want) <= TOL_PIPELINE
+
+
 def test_small_launches_stay_on_the_tile_kernel():
     """Fewer than 16 images leave too few workgroups for runs of images: the tile kernel takes them."""
     imgs = [synth.image(4, 256, seed=9400 + k) for k in range(8)]
