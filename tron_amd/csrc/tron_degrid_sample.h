@@ -127,58 +127,193 @@ __device__ __forceinline__ DgRound dg_clip_round(const DegridParams &p, Lists &L
     return r;
 }
 
+// What a sample needs from its record, fast weights: the 2 ceil(W) + 2 ceil(W) window weights (zero where the reference skips
+// a point), where its footprint starts in a tile buffer, where the sample goes, and whether this tile owns it at all.
+// It does not depend on the image: the streaming kernel keeps it in registers over a run of images with the same angles.
+template <int NF>
+struct DgPrep {
+    float wx[NF], wy[NF];
+    int t0;                         // byte offset of the footprint's first point from the start of a tile buffer
+    int soff;                       // sample's index in the image's output: (pe * nro + ro) * nrep + c0
+    bool own;
+};
+
+// spoke holding record `rec` of the round's list: largest s with sp_start[s] <= rec (lane = rec & 63)
+template <int MAXSP, class LdsT>
+__device__ __forceinline__ int dg_spoke_of(LdsT &L, const DgRound rd, const int rec, const int lane)
+{
+    if (rd.mapped) {
+        // the spoke of the pass's first record plus the segment starts between it and `rec`: two wave-uniform LDS
+        // reads and a population count (a search over sp_start cost two more dependent LDS round trips per pass)
+        const int b = rec >> 6;
+        const unsigned long long starts = *reinterpret_cast<const unsigned long long *>(&L.segbits[2 * b]);
+        const unsigned long long upto = ((2ull << lane) - 1ull) & ~1ull;           // records (64 b, rec]
+        return L.first[b] + __popcll(starts & upto);
+    }
+    // 8-ary search: the seven splitters of a round are independent LDS reads
+    int lo = 0;
+    int span = rd.nacc;
+    while (span > 1) {
+        const int step = (span + 7) >> 3;
+        const int end = lo + span;
+        int sv[7];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) sv[j - 1] = L.sp_start[min(lo + j * step, MAXSP)];
+        int cnt = 0;
+#pragma unroll
+        for (int j = 1; j < 8; ++j) cnt += (lo + j * step < end && sv[j - 1] <= rec) ? 1 : 0;
+        lo += cnt * step;
+        span = min(step, end - lo);
+    }
+    return lo;
+}
+
+// Coordinates of record `rec` (src/tron.cu:554-561) and whether the tile at (tx0, ty0) owns the sample.
+template <int MAXSP, class LdsT>
+__device__ __forceinline__ bool dg_coords(const DegridParams &p, LdsT &L, const DgRound rd, const int rec, const int lane,
+                                          const int tx0, const int ty0, const int n, const int nr, int &pe, int &ro, float &X, float &Y)
+{
+    const float half = (float)((n + 1) / 2), halfr = (float)((nr + 1) / 2);   // src/tron.cu:560-561
+    const float inv_nro = 1.0f / (float)p.nro;
+    const bool nro_pow2 = (p.nro & (p.nro - 1)) == 0;               // then ro / nro == ro * (1 / nro) exactly
+    const int lo = dg_spoke_of<MAXSP>(L, rd, rec, lane);
+    pe = L.sp_pe[lo];
+    ro = (L.sp_seg[lo] & 0xffff) + (rec - L.sp_start[lo]);
+    // thread's polar and Cartesian coordinates, src/tron.cu:554-561
+    const float R = (nro_pow2 ? (float)ro * inv_nro : (float)ro / (float)p.nro) - 0.5f;
+    const float2 cs = L.sp_cs[lo];
+    X = cs.y; Y = cs.x;                                             // X = sin, Y = cos (src/tron.cu:559)
+    X = (float)nr * R * X + halfr;
+    Y = (float)n * R * Y + half;
+    const int fx = min(max((int)floorf(X), 0), nr - 1);              // owner cell
+    const int fy = min(max((int)floorf(Y), 0), n - 1);
+    return (unsigned)(fx - tx0) < (unsigned)kDgTile && (unsigned)(fy - ty0) < (unsigned)kDgTile;
+}
+
+template <int CW, int MAXSP, int HALO, int SX, int SY, class LdsT>
+__device__ __forceinline__ DgPrep<2 * CW> dg_prep(const DegridParams &p, const KbCoef &kb, LdsT &L, const DgRound rd, const int rec,
+                                                  const int lane, const int tx0, const int ty0, const int n, const int nr, const int c0)
+{
+    constexpr int NF = 2 * CW;
+    DgPrep<NF> P;
+    const float W = p.W;
+    int pe, ro;
+    float X, Y;
+    P.own = dg_coords<MAXSP>(p, L, rd, rec, lane, tx0, ty0, n, nr, pe, ro, X, Y);
+    P.soff = (pe * p.nro + ro) * p.nrep + c0;
+    // all weights first, as interleaved packed polynomials (x and y of a slot share an instruction).
+    // 2*CW slots suffice: [X-W, X+W] holds more integers only when both end points sit at distance
+    // exactly W, where the weight is 0; a slot with |d| >= W gets weight 0, which is what skipping it
+    // (src/tron.cu:563,566) amounts to.  Then NF x NF fixed-offset LDS reads.
+    const int xu0 = (int)ceilf(X - W), yu0 = (int)ceilf(Y - W);
+    v2f sxy[NF], wxy[NF];
+    const v2f one = {1.0f, 1.0f};
+#pragma unroll
+    for (int t = 0; t < NF; ++t) {
+        const v2f dxy = {(float)(xu0 + t) - X, (float)(yu0 + t) - Y};
+        const v2f r = dxy * kb.invW;
+        sxy[t] = __builtin_elementwise_fma(-r, r, one);
+        // outside the window: s <- 1 - (W/W)^2 keeps the polynomial finite, the weight is zeroed below
+        wxy[t] = (v2f){kb.poly[kKbPolyTerms - kb_terms(CW)], kb.poly[kKbPolyTerms - kb_terms(CW)]};
+    }
+#pragma unroll
+    for (int k = kKbPolyTerms - kb_terms(CW) + 1; k < kKbPolyTerms; ++k) {
+        const v2f c = {kb.poly[k], kb.poly[k]};
+#pragma unroll
+        for (int t = 0; t < NF; ++t) wxy[t] = __builtin_elementwise_fma(wxy[t], sxy[t], c);
+    }
+#pragma unroll
+    for (int t = 0; t < NF; ++t) {
+        P.wx[t] = fabsf((float)(xu0 + t) - X) < W ? wxy[t].x : 0.0f;
+        P.wy[t] = fabsf((float)(yu0 + t) - Y) < W ? wxy[t].y : 0.0f;
+    }
+    P.t0 = ((xu0 + HALO - tx0) * SX + (yu0 + HALO - ty0) * SY) * (int)sizeof(float2);
+    return P;
+}
+
+// The sample of a prepared record from the tile buffer at L.tile[tile_off]: NF x NF points x CPB coils, stored to dst.
+// ROLLED: one row of the footprint per iteration of a loop that is NOT unrolled -- a wave cannot have more than 15 LDS reads
+// in flight anyway (lgkmcnt), the unrolled form holds ~150 registers, this one ~100 (same speed where both fit).
+template <int CPB, int CW, int PLANE, int SX, int SY, bool ROLLED, class LdsT>
+__device__ __forceinline__ void dg_gather_store(const DegridParams &p, LdsT &L, const int tile_off, const DgPrep<2 * CW> &P,
+                                                float2 *dst, const int ncb)
+{
+    constexpr int NF = 2 * CW;
+    float2 acc[CPB];
+#pragma unroll
+    for (int c = 0; c < CPB; ++c) acc[c] = make_float2(0.f, 0.f);
+    unsigned t0 = lds_addr(L.tile) + (unsigned)(tile_off * (int)sizeof(float2) + P.t0);
+    // volatile keeps hipcc from pairing the reads into ds_read2_b64, which moves 128 B per clock on a 32-bank modulus;
+    // ds_read_b64 moves 256 on 64 banks
+    if (ROLLED) {
+        float wx[NF];
+#pragma unroll
+        for (int t = 0; t < NF; ++t) wx[t] = P.wx[t];
+#pragma unroll 1
+        for (int sx = 0; sx < NF; ++sx) {
+            const float wxs = wx[0];
+#pragma unroll
+            for (int t = 0; t < NF; ++t) {
+                const float wgt = wxs * P.wy[t];                            // src/tron.cu:568
+#pragma unroll
+                for (int c = 0; c < CPB; ++c) {
+                    const v2f v = *(const volatile __attribute__((address_space(3))) v2f *)(size_t)(
+                        t0 + (unsigned)((c * PLANE + t * SY) * (int)sizeof(float2)));
+                    acc[c].x = fmaf(v.x, wgt, acc[c].x);                    // src/tron.cu:573
+                    acc[c].y = fmaf(v.y, wgt, acc[c].y);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t + 1 < NF; ++t) wx[t] = wx[t + 1];
+            t0 += (unsigned)(SX * (int)sizeof(float2));
+        }
+    } else {
+#pragma unroll
+        for (int sx = 0; sx < NF; ++sx)
+#pragma unroll
+            for (int t = 0; t < NF; ++t) {
+                const float wgt = P.wx[sx] * P.wy[t];                       // src/tron.cu:568
+#pragma unroll
+                for (int c = 0; c < CPB; ++c) {
+                    const v2f v = *(const volatile __attribute__((address_space(3))) v2f *)(size_t)(
+                        t0 + (unsigned)((c * PLANE + sx * SX + t * SY) * (int)sizeof(float2)));
+                    acc[c].x = fmaf(v.x, wgt, acc[c].x);                    // src/tron.cu:573
+                    acc[c].y = fmaf(v.y, wgt, acc[c].y);
+                }
+            }
+    }
+    float2 *o = dst + P.soff;
+    if (CPB % 2 == 0 && ncb == CPB && (p.nrep & 1) == 0) {                  // c0 is a multiple of CPB: 16-byte aligned
+#pragma unroll
+        for (int c = 0; c < CPB; c += 2)
+            *reinterpret_cast<float4 *>(o + c) = make_float4(acc[c].x, acc[c].y, acc[c + 1].x, acc[c + 1].y);
+    } else {
+#pragma unroll
+        for (int c = 0; c < CPB; ++c)
+            if (c < ncb) o[c] = acc[c];
+    }
+}
+
 // The samples of one round, dealt out flat over the NT threads.  The tile (CPB coil planes of PLANE points each, HALO points
 // before the tile's first row and column) starts at L.tile[tile_off]; SX / SY are the strides of a step along the sine
 // ("X") and cosine ("Y") axes.
 // `tile_off` is an index, not a pointer: a pointer handed through a call can lose the LDS address space (flat loads).
-template <int CPB, int CW, int KB, int NT, int MAXSP, int PLANE, int HALO, int SX, int SY, class LdsT>
+template <int CPB, int CW, int KB, int NT, int MAXSP, int PLANE, int HALO, int SX, int SY, bool ROLLED, class LdsT>
 __device__ __forceinline__ void dg_sample_loop(const DegridParams &p, const KbCoef &kb, LdsT &L, const int tile_off, const DgRound rd,
                                                const int tid, const int tx0, const int ty0, const int n, const int nr,
-                                               float2 *dst, const int c0, const int ncb)
+                                               float2 *dst, const int c0, const int ncb, const int first_rec = 0)
 {
     const float W = p.W;
-    const int nacc = rd.nacc, nrec = rd.nrec;
-    const float half = (float)((n + 1) / 2), halfr = (float)((nr + 1) / 2);   // src/tron.cu:560-561
-    const float inv_nro = 1.0f / (float)p.nro;
-    const bool nro_pow2 = (p.nro & (p.nro - 1)) == 0;               // then ro / nro == ro * (1 / nro) exactly
-    for (int rec = tid; rec < nrec && TRON_DBG_LT(p, 1); rec += NT) {
-        // spoke holding record `rec`: largest s with sp_start[s] <= rec
-        int lo;
-        if (rd.mapped) {
-            // the spoke of the pass's first record plus the segment starts between it and `rec`: two wave-uniform LDS
-            // reads and a population count (a search over sp_start cost two more dependent LDS round trips per pass)
-            const int b = rec >> 6;
-            const unsigned long long starts = *reinterpret_cast<const unsigned long long *>(&L.segbits[2 * b]);
-            const unsigned long long upto = ((2ull << (tid & 63)) - 1ull) & ~1ull;     // records (64 b, rec]
-            lo = L.first[b] + __popcll(starts & upto);
-        } else {
-            // 8-ary search: the seven splitters of a round are independent LDS reads
-            lo = 0;
-            int span = nacc;
-            while (span > 1) {
-                const int step = (span + 7) >> 3;
-                const int end = lo + span;
-                int sv[7];
-#pragma unroll
-                for (int j = 1; j < 8; ++j) sv[j - 1] = L.sp_start[min(lo + j * step, MAXSP)];
-                int cnt = 0;
-#pragma unroll
-                for (int j = 1; j < 8; ++j) cnt += (lo + j * step < end && sv[j - 1] <= rec) ? 1 : 0;
-                lo += cnt * step;
-                span = min(step, end - lo);
-            }
+    const int nrec = rd.nrec;
+    for (int rec = first_rec + tid; rec < nrec && TRON_DBG_LT(p, 1); rec += NT) {
+        if (KB == TRON_KB_FAST) {
+            const DgPrep<2 * CW> P = dg_prep<CW, MAXSP, HALO, SX, SY>(p, kb, L, rd, rec, tid & 63, tx0, ty0, n, nr, c0);
+            if (P.own) dg_gather_store<CPB, CW, PLANE, SX, SY, ROLLED>(p, L, tile_off, P, dst, ncb);
+            continue;
         }
-        const int pe = L.sp_pe[lo];
-        const int ro = (L.sp_seg[lo] & 0xffff) + (rec - L.sp_start[lo]);
-        // thread's polar and Cartesian coordinates, src/tron.cu:554-561
-        const float R = (nro_pow2 ? (float)ro * inv_nro : (float)ro / (float)p.nro) - 0.5f;
-        const float2 cs = L.sp_cs[lo];
-        float X = cs.y, Y = cs.x;                                   // X = sin, Y = cos (src/tron.cu:559)
-        X = (float)nr * R * X + halfr;
-        Y = (float)n * R * Y + half;
-        const int fx = min(max((int)floorf(X), 0), nr - 1);          // owner cell
-        const int fy = min(max((int)floorf(Y), 0), n - 1);
-        if ((unsigned)(fx - tx0) >= (unsigned)kDgTile || (unsigned)(fy - ty0) >= (unsigned)kDgTile) continue;
+        int pe, ro;
+        float X, Y;
+        if (!dg_coords<MAXSP>(p, L, rd, rec, tid & 63, tx0, ty0, n, nr, pe, ro, X, Y)) continue;
 
         constexpr int NS = 2 * CW + 1;                              // at most floor(2W)+1 integers in [X-W, X+W]
         const int xu0 = (int)ceilf(X - W), yu0 = (int)ceilf(Y - W);
@@ -186,52 +321,7 @@ __device__ __forceinline__ void dg_sample_loop(const DegridParams &p, const KbCo
         float2 acc[CPB];
 #pragma unroll
         for (int c = 0; c < CPB; ++c) acc[c] = make_float2(0.f, 0.f);
-
-        if (KB == TRON_KB_FAST) {
-            // all weights first, as interleaved packed polynomials (x and y of a slot share an instruction).
-            // 2*CW slots suffice: [X-W, X+W] holds more integers only when both end points sit at distance
-            // exactly W, where the weight is 0; a slot with |d| >= W gets weight 0, which is what skipping it
-            // (src/tron.cu:563,566) amounts to.  Then NF x NF fixed-offset LDS reads.
-            constexpr int NF = 2 * CW;
-            v2f sxy[NF], wxy[NF];
-            const v2f one = {1.0f, 1.0f};
-#pragma unroll
-            for (int t = 0; t < NF; ++t) {
-                const v2f dxy = {(float)(xu0 + t) - X, (float)(yu0 + t) - Y};
-                const v2f r = dxy * kb.invW;
-                sxy[t] = __builtin_elementwise_fma(-r, r, one);
-                // outside the window: s <- 1 - (W/W)^2 keeps the polynomial finite, the weight is zeroed below
-                wxy[t] = (v2f){kb.poly[kKbPolyTerms - kb_terms(CW)], kb.poly[kKbPolyTerms - kb_terms(CW)]};
-            }
-#pragma unroll
-            for (int k = kKbPolyTerms - kb_terms(CW) + 1; k < kKbPolyTerms; ++k) {
-                const v2f c = {kb.poly[k], kb.poly[k]};
-#pragma unroll
-                for (int t = 0; t < NF; ++t) wxy[t] = __builtin_elementwise_fma(wxy[t], sxy[t], c);
-            }
-            float wx[NF], wy[NF];
-#pragma unroll
-            for (int t = 0; t < NF; ++t) {
-                wx[t] = fabsf((float)(xu0 + t) - X) < W ? wxy[t].x : 0.0f;
-                wy[t] = fabsf((float)(yu0 + t) - Y) < W ? wxy[t].y : 0.0f;
-            }
-            const unsigned t0 = lds_addr(L.tile) + (unsigned)((tile_off + (xu0 + lrow0) * SX + lcol0 * SY) * (int)sizeof(float2));
-#pragma unroll
-            for (int sx = 0; sx < NF; ++sx)
-#pragma unroll
-                for (int t = 0; t < NF; ++t) {
-                    const float wgt = wx[sx] * wy[t];                       // src/tron.cu:568
-#pragma unroll
-                    for (int c = 0; c < CPB; ++c) {
-                        // volatile keeps hipcc from pairing these into ds_read2_b64, which moves 128 B per clock on a
-                        // 32-bank modulus; ds_read_b64 moves 256 on 64 banks
-                        const v2f v = *(const volatile __attribute__((address_space(3))) v2f *)(size_t)(
-                            t0 + (unsigned)((c * PLANE + sx * SX + t * SY) * (int)sizeof(float2)));
-                        acc[c].x = fmaf(v.x, wgt, acc[c].x);                // src/tron.cu:573
-                        acc[c].y = fmaf(v.y, wgt, acc[c].y);
-                    }
-                }
-        } else {
+        {
             float wy[NS];
             int ny = 0;
 #pragma unroll

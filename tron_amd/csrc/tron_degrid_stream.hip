@@ -138,23 +138,48 @@ __global__ void __launch_bounds__(kDsThreads) degrid_stream_kernel(const DegridP
     const int nrounds = (p.npe + kDsMaxSpokes - 1) / kDsMaxSpokes;
     DgRound rd;
     rd.nacc = rd.nrec = 0; rd.mapped = true;
+    // Same angles every image and one clipping round: the records are the same for every image of the run, and so is all a
+    // sample needs from its record -- weights, footprint, destination (DgPrep).  Fast weights: the first kDsKeep passes'
+    // worth is computed once and kept in registers over the run (a tile holds ~1 000 records on average, 1.3 passes of 768;
+    // the counters showed VALU and LDS time adding up rather than overlapping, and two thirds of a pass's VALU
+    // instructions are this preparation); later passes and the exact weights take the per-record loop.
+    constexpr int kDsKeep = 2;
+    const bool same_records = nrounds == 1 && p.trig_img_stride == 0;
+    DgPrep<2 * CW> kept[kDsKeep];
+#pragma unroll
+    for (int j = 0; j < kDsKeep; ++j) kept[j].own = false;
+    if (same_records && TRON_DBG_LT(p, 2)) {
+        rd = dg_clip_round<kDsThreads, kDsMaxSpokes, kDsMaxBlocks>(p, L, k0, 0, tid, tx0, ty0, n, nr);
+        if (KB == TRON_KB_FAST) {
+#pragma unroll
+            for (int j = 0; j < kDsKeep; ++j) {
+                const int rec = tid + j * kDsThreads;
+                if (rec < rd.nrec) kept[j] = dg_prep<CW, kDsMaxSpokes, HALO, SX, SY>(p, kb, L, rd, rec, tid & 63, tx0, ty0, n, nr, c0);
+            }
+        }
+    }
+    const int first_rec = (same_records && KB == TRON_KB_FAST) ? kDsKeep * kDsThreads : 0;
     for (int k = k0; k < k1; ++k) {
         const int buf = (k - k0) & 1;
-        const bool relist = k == k0 || nrounds > 1 || p.trig_img_stride != 0;
-        if (relist && TRON_DBG_LT(p, 2)) rd = dg_clip_round<kDsThreads, kDsMaxSpokes, kDsMaxBlocks>(p, L, k, 0, tid, tx0, ty0, n, nr);
+        if (!same_records && TRON_DBG_LT(p, 2)) rd = dg_clip_round<kDsThreads, kDsMaxSpokes, kDsMaxBlocks>(p, L, k, 0, tid, tx0, ty0, n, nr);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this thread's pieces of image k have landed
         __syncthreads();                                        // ... everybody's; and nobody still samples the other buffer
         if (k + 1 < k1) fetch(k + 1, buf ^ 1);
         float2 *dst = p.nudata + (size_t)k * p.nro * p.npe * p.nrep;
+        if (TRON_DBG_LT(p, 1)) {
+#pragma unroll
+            for (int j = 0; j < kDsKeep; ++j)
+                if (kept[j].own) dg_gather_store<kDsCoils, CW, PLANE, SX, SY, true>(p, L, buf * BUF, kept[j], dst, ncb);
+        }
         for (int r = 0; r < nrounds && TRON_DBG_LT(p, 2); ++r) {
             if (r > 0) {
                 __syncthreads();                                // the lists of the round before are no longer read
                 rd = dg_clip_round<kDsThreads, kDsMaxSpokes, kDsMaxBlocks>(p, L, k, r * kDsMaxSpokes, tid, tx0, ty0, n, nr);
             }
-            dg_sample_loop<kDsCoils, CW, KB, kDsThreads, kDsMaxSpokes, PLANE, HALO, SX, SY>(p, kb, L, buf * BUF, rd, tid, tx0, ty0, n, nr,
-                                                                                         dst, c0, ncb);
+            dg_sample_loop<kDsCoils, CW, KB, kDsThreads, kDsMaxSpokes, PLANE, HALO, SX, SY, true>(p, kb, L, buf * BUF, rd, tid, tx0, ty0, n, nr,
+                                                                                         dst, c0, ncb, first_rec);
         }
-        if (relist && k + 1 < k1 && (nrounds > 1 || p.trig_img_stride != 0)) __syncthreads();   // before the lists are rebuilt
+        if (!same_records && k + 1 < k1) __syncthreads();       // before the lists are rebuilt
     }
 }
 
@@ -195,8 +220,8 @@ bool degrid_stream_supported(const DegridParams &p, int kb_mode)
 {
     const int nr = p.nrows > 0 ? p.nrows : p.n;
     const int cw = (int)ceilf(p.W);
-    return cw >= 1 && cw <= (kb_mode == TRON_KB_EXACT ? 4 : 2) && p.tile_order && p.in_p == 1 && p.n % kDgTile == 0 && nr % kDgTile == 0 && p.n >= 2 * kDgTile && nr >= 2 * kDgTile
-           && p.nrep >= kDsCoils && p.group_max >= 4 && (p.trig_img_stride == 0 || p.nimg >= 32) && p.nro <= 0x7fff
+    return cw >= 1 && cw <= (kb_mode == TRON_KB_EXACT ? 4 : 3) && p.tile_order && p.in_p == 1 && p.n % kDgTile == 0 && nr % kDgTile == 0 && p.n >= 2 * kDgTile && nr >= 2 * kDgTile
+           && (long long)p.nro * p.npe * p.nrep < (1ll << 31) && p.nrep >= kDsCoils && p.group_max >= 4 && (p.trig_img_stride == 0 || p.nimg >= 32) && p.nro <= 0x7fff
            && ((size_t)kDsCoils * p.in_c + (size_t)p.n * nr) * sizeof(float2) < (1ull << 32);
 }
 

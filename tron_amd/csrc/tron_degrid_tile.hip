@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(kDgThreads) degrid_tile_kernel(const DegridPar
         // (keeping the tile loads in flight across the first clip round was tried: the registers it pins cost more
         //  than the exposed latency, 2.78 -> 2.91 us per coil image; two records per thread side by side, to overlap one's
         //  LDS reads with the other's arithmetic: 2.18 -> 2.40)
-        dg_sample_loop<CPB, CW, KB, kDgThreads, kDgMaxSpokes, TS * TS, HALO, TS, 1>(p, kb, L, 0, rd, tid, tx0, ty0, n, nr, dst, c0, ncb);
+        dg_sample_loop<CPB, CW, KB, kDgThreads, kDgMaxSpokes, TS * TS, HALO, TS, 1, false>(p, kb, L, 0, rd, tid, tx0, ty0, n, nr, dst, c0, ncb);
         __syncthreads();
     }
 }
@@ -151,6 +151,7 @@ static hipError_t launch_degrid_tile_cw(const DegridParams &p, int kb_mode, hipS
 hipError_t launch_degrid_tile(const DegridParams &p, int kb_mode, hipStream_t s)
 {
     const int cw = (int)ceilf(p.W);
+    if ((long long)p.nro * p.npe * p.nrep >= (1ll << 31)) return hipErrorInvalidValue;      // a sample's output index is an int (DgPrep::soff)
     switch (cw) {
         case 1: return launch_degrid_tile_cw<1>(p, kb_mode, s);
         case 2: return launch_degrid_tile_cw<2>(p, kb_mode, s);
