@@ -7,14 +7,14 @@
 // registers) into the second of two tile buffers while the current one is sampled, and the spoke lists are built once
 // per run when every image has the same angles.  How many images a run holds depends on the tile: the centre tiles hold
 // the most samples (density ~ 1/r) and take short runs so that no workgroup outlasts the launch (DegridParams::group_end).
-// Measured and not kept (8 coils x 64 images, 1.80 us per coil image as built): entering the sample loop a fraction of a pass
-// late per wave, so that the waves' LDS and VALU phases interleave (no gain); 1024 threads = four waves per SIMD (the
-// unrolled gather spills at 128 registers: 2.07); the records of ALL images of a run as one stream of 64-record blocks
-// over three tile buffers, dealt one block per wave and step (1.83) or handed out through an LDS counter with no barrier
-// at all (1.80).  A phase clock (s_memtime per wave) showed 30 % of the wave cycles at the per-image barrier; without
-// the barrier the same cycles reappear inside the phases: at three waves per SIMD the loop is bound by its own
-// dependency chain (VALU ~45 %, LDS ~46 % busy, bank conflicts 2.7 x for ANY row pitch: 32 samples along a spoke
-// always meet a short vector of the bank lattice).
+// Measured and not kept (8 coils x 64 images, 1.68-1.78 us per coil image as built; DESIGN.md sections 4.4 and 8 have the
+// numbers): waves entering the sample loop a fraction of a pass apart; 512 and 1 024 threads; the records of ALL images of
+// a run as one stream of 64-record blocks over three tile buffers, dealt a block per wave and step or handed out through an
+// LDS counter with no barrier at all; the kept records dealt evenly over the waves; the wait for the next copy moved between
+// a wave's first gather and its first store; three tile buffers with counted vmcnt waits.  Elimination builds: copies,
+// clipping and barriers alone 0.74 us, with the gather 1.37, with the stores instead 1.44, everything 1.70 -- the copies and
+// the stores add up as if they shared one path, the gather (LDS ~50 % busy, bank conflicts 2.25-fold measured and 2.7-fold
+// simulated for ANY row pitch: 32 samples along a spoke always meet a short vector of the bank lattice) overlaps them in part.
 //
 // The tile is held as the input planes lie in memory ([col][row] for the fused forward FFT, which stores the grid
 // transposed): the sample loop strides accordingly.  The halo is rounded up to even widths so that a 16-byte piece
