@@ -43,6 +43,7 @@ struct DsLds : DgLists<kDsMaxSpokes, kDsMaxBlocks, kDsThreads / 64> {
     static constexpr int PLANE = TS * PITCH;
     static constexpr int BUF = PLANE * kDsCoils;              // points per tile buffer
     alignas(16) float2 tile[2 * BUF + 16];                    // two buffers of [coil][a][b], b along memory; zeroed pad
+    float4 stage[(kDsThreads / 64) * 128];                    // per wave: the sums of a pass on their way to the lanes that store them (dg_gather_store, PAIRS)
 };
 
 template <int CW, bool TR, int KB>
@@ -167,9 +168,16 @@ __global__ void __launch_bounds__(kDsThreads) degrid_stream_kernel(const DegridP
         if (k + 1 < k1) fetch(k + 1, buf ^ 1);
         float2 *dst = p.nudata + (size_t)k * p.nro * p.npe * p.nrep;
         if (TRON_DBG_LT(p, 1)) {
+            const bool pairs = ncb == kDsCoils && (p.nrep & 1) == 0;      // whole 16-byte pieces
 #pragma unroll
-            for (int j = 0; j < kDsKeep; ++j)
-                if (kept[j].own) dg_gather_store<kDsCoils, CW, PLANE, SX, SY, true>(p, L, buf * BUF, kept[j], dst, ncb);
+            for (int j = 0; j < kDsKeep; ++j) {
+                if (pairs) {
+                    // (the same in the per-record loop -- later passes, CGNR's per-image lists -- measured no gain)
+                    if (__any(kept[j].own)) dg_gather_store<kDsCoils, CW, PLANE, SX, SY, true, true>(p, L, buf * BUF, kept[j], dst, ncb, L.stage + wave * 128);
+                } else if (kept[j].own) {
+                    dg_gather_store<kDsCoils, CW, PLANE, SX, SY, true>(p, L, buf * BUF, kept[j], dst, ncb);
+                }
+            }
         }
         for (int r = 0; r < nrounds && TRON_DBG_LT(p, 2); ++r) {
             if (r > 0) {
