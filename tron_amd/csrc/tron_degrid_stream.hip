@@ -121,6 +121,7 @@ __global__ void __launch_bounds__(kDsThreads) degrid_stream_kernel(const DegridP
             i += nr / 2; if (i >= nr) i -= nr;
             j += n / 2; if (j >= n) j -= n;
         }
+        if (TR) { i += p.in_rot; if (i >= nr) i -= nr; } else { j += p.in_rot; if (j >= n) j -= n; }
         voff[it] = (unsigned)(((size_t)c * p.in_c + (TR ? (size_t)j * nr + i : (size_t)i * n + j)) * sizeof(float2));
         vact[it] = c < ncb && b < TS;
     }

@@ -90,6 +90,7 @@ __global__ void __launch_bounds__(kDgThreads) degrid_tile_kernel(const DegridPar
                 i += nr / 2; if (i >= nr) i -= nr;
                 j += n / 2; if (j >= n) j -= n;
             }
+            if (p.in_transposed) { i += p.in_rot; if (i >= nr) i -= nr; } else { j += p.in_rot; if (j >= n) j -= n; }
             const float2 *s = src + (p.in_transposed ? (size_t)j * nr + i : (size_t)i * n + j) * p.in_p;
 #pragma unroll
             for (int c = 0; c < CPB; ++c)

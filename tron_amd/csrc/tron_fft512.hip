@@ -556,6 +556,7 @@ struct Fft512FwdParams {
     int nchan;
     int rzero2;               // pass 2: grid points with X^2 + Y^2 > rzero2 (centred) are not stored: no sample's footprint reaches them
                               // (<= 0: store everything)
+    int rot;                  // pass 2: point k1 of an output line is stored at (k1 + rot) mod 512 (DegridParams::in_rot)
 };
 
 // grid = (256/16, nimg*nchan); block = 256.  Line r of a coil image = padded row 128 + r.
@@ -715,7 +716,7 @@ __global__ void __launch_bounds__(256) fft512_fwd_cols_kernel(const Fft512FwdPar
         for (int j2 = 0; j2 < 8; ++j2) {
             const int k1 = lane + 64 * j2;
             const int xc = k1 < kF / 2 ? k1 : k1 - kF;
-            if (p.rzero2 <= 0 || xc * xc + yc * yc <= p.rzero2) line[k1] = cconj(v[j2]);
+            if (p.rzero2 <= 0 || xc * xc + yc * yc <= p.rzero2) line[(k1 + p.rot) & (kF - 1)] = cconj(v[j2]);
         }
     }
 }
@@ -846,15 +847,16 @@ __global__ void __launch_bounds__(kFwdColThreads) fft512_fwd_cols_dma_kernel(con
         for (int j2 = 0; j2 < 8; ++j2) {
             const int k1 = lane + 64 * j2;
             const int xc = k1 < kF / 2 ? k1 : k1 - kF;
-            if (p.rzero2 <= 0 || xc * xc + yc * yc <= p.rzero2) line[k1] = cconj(v[j2]);
+            if (p.rzero2 <= 0 || xc * xc + yc * yc <= p.rzero2) line[(k1 + p.rot) & (kF - 1)] = cconj(v[j2]);
         }
     }
 }
 
-hipError_t launch_fft512_forward(const float2 *img, float2 *tmp, float2 *out, const float2 *tw, const float *inv_deapod, int rzero,
+hipError_t launch_fft512_forward(const float2 *img, float2 *tmp, float2 *out, const float2 *tw, const float *inv_deapod, int rzero, int rot,
                                  int nchan, int nimg, hipStream_t s)
 {
     Fft512FwdParams p;
+    p.rot = rot;
     p.img = img; p.tmp = tmp; p.out = out; p.tw = tw; p.inv_deapod = inv_deapod; p.nchan = nchan;
     p.rzero2 = rzero > 0 ? rzero * rzero : 0;
     if (nchan > 1 && nchan <= 16) {

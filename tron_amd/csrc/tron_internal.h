@@ -89,6 +89,8 @@ struct DegridParams {
     long long in_z, in_c;     // input strides per image and per coil
     int in_p, in_shift;       // pixel stride; 1: input is the raw FFT output (second fftshift folded into indexing)
     int in_transposed;        // degrid_tile_kernel: input planes are stored [col][row] (fused forward FFT)
+    int in_rot;               // ... with every line rotated: point i of a line lies at (i + in_rot) mod its length (the streaming kernel's halo:
+                              // a tile's row segments then start on a 128-byte line, three lines each instead of four)
     int debug;                // TRON_DEBUG_SKIP (timing bisection): 1 = no sample loop, 2 = tile load only
     int group_end[4];         // degrid_stream_kernel: tile_order positions [group_end[c-1], group_end[c]) take runs of 2^c images (c = 4: the rest)
     int group_max;            // ... capped by this (a quarter of the launch's images at most); < 4: degrid_tile_kernel only (8 images of 8 coils: 2.07 vs 1.79 us per coil image there)
@@ -163,7 +165,7 @@ hipError_t launch_fft512_adjoint_coils(const float2 *grid, float2 *tmp, float2 *
 int fft512_coils_partials(int nslices);
 // fused pad + deapodise + shift + pruned forward FFT for nx = 256, nxos = 512 (tron_fft512.hip)
 // rzero: grid points at centred radius > rzero are not stored (no degridded sample's footprint reaches them; 0 = store all)
-hipError_t launch_fft512_forward(const float2 *img, float2 *tmp, float2 *out, const float2 *tw, const float *inv_deapod, int rzero,
+hipError_t launch_fft512_forward(const float2 *img, float2 *tmp, float2 *out, const float2 *tw, const float *inv_deapod, int rzero, int rot,
                                  int nchan, int nimg, hipStream_t s);
 
 }  // namespace tron

@@ -446,6 +446,7 @@ __global__ void __launch_bounds__(256) degrid_kernel(const DegridParams p)
                 int i = (xu % nr + nr) % nr;                          // src/tron.cu:569-570 ((xu + n) % n for |xu| < n)
                 int j = (yu % n + n) % n;
                 if (p.in_shift) { i = (i + nr / 2) % nr; j = (j + n / 2) % n; }   // fftshift(INVERSE) of :646 folded in
+                if (p.in_transposed) i = (i + p.in_rot) % nr; else j = (j + p.in_rot) % n;
                 const float2 *u = src + (p.in_transposed ? (size_t)j * nr + i : (size_t)i * n + j) * p.in_p;
 #pragma unroll
                 for (int c = 0; c < CPB; ++c)

@@ -368,12 +368,15 @@ int forward_run(tron_plan *p, void *d_out, const void *d_in, int nimg, const flo
     for (int k0 = 0; k0 < nimg; k0 += p->chunk) {
         const int ck = std::min(p->chunk, nimg - k0);
         const float2 *img = static_cast<const float2 *>(d_in) + (size_t)k0 * p->nchan * d.nx * d.ny;
+        // the fused FFT stores every grid line rotated by the streaming degridder's halo (tuning knob TRON_GRID_ROT)
+        static const int rot_env = tuning_env("TRON_GRID_ROT") ? atoi(tuning_env("TRON_GRID_ROT")) : -1;
+        const int grid_rot = rot_env >= 0 ? rot_env : (((int)ceilf(p->cfg.kernwidth) + 1) & ~1);
         if (p->fft512) {
             // fused: pad + deapodise + shift + pruned forward FFT (tron_fft512.hip)
             StageTimer t(p, STAGE_FFT);
             // samples lie within nxos/2 of the centre, their footprints (zero-weight slots included) within W + 2 more
             const int rzero = p->no_disc ? 0 : d.nxos / 2 + (int)ceilf(p->cfg.kernwidth) + 4;
-            HIP_TRY(launch_fft512_forward(img, p->d_fft_tmp, p->d_grid, p->d_tw512, deapod, rzero, p->nchan, ck, p->stream));
+            HIP_TRY(launch_fft512_forward(img, p->d_fft_tmp, p->d_grid, p->d_tw512, deapod, rzero, grid_rot, p->nchan, ck, p->stream));
         } else {
             PreParams a;
             a.img = img;
@@ -404,6 +407,7 @@ int forward_run(tron_plan *p, void *d_out, const void *d_in, int nimg, const flo
         g.in_p = 1;
         g.in_shift = 1;
         g.in_transposed = p->fft512 ? 1 : 0;      // launch_fft512_forward stores the grid transposed
+        g.in_rot = p->fft512 ? grid_rot : 0;
         g.debug = p->debug_skip;
         g.n = d.nxos;
         g.nrows = square ? 0 : d.nyos;
