@@ -3,6 +3,11 @@
 One workgroup walks a run of images of its tile, the next tile arriving by LDS-DMA while the current one is sampled.  The
 sample loop is the tile kernel's (tron_degrid_sample.h), so the two kernels must agree BIT FOR BIT on any input; the
 oracle (degridradial2d, src/tron.cu:540-577 restated) is the checker for both."""
+import os
+import subprocess
+import sys
+import tempfile
+
 import numpy as np
 import pytest
 
@@ -11,6 +16,8 @@ from conftest import rel_l2
 from tron_amd import lib
 
 pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 TOL_PIPELINE = 1e-5
 
@@ -81,6 +88,39 @@ def test_fused_forward_fft_coil_counts_vs_oracle(oracle, nc):
     assert (p.nxos, p.nx) == (512, 256)
     got, _ = lib.recon(img, adjoint=False, golden_angle=1, data_undersamp=us)
     assert rel_l2(got, want) <= TOL_PIPELINE
+
+
+def _forward_in_child(imgs, nimg, env, **flags):
+    """_forward in a child process: the switches below are read once per process."""
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import test_gpu_degrid_stream as t\n"
+        "d = np.load(sys.argv[1]); imgs = [np.asfortranarray(d[..., k:k+1]) for k in range(d.shape[-1])]\n"
+        "out, name = t._forward(imgs, len(imgs), **eval(sys.argv[3])); np.save(sys.argv[2], out.view(np.float32))\n"
+        % (ROOT, os.path.join(ROOT, "tests")))
+    with tempfile.TemporaryDirectory() as tmp:
+        np.save(os.path.join(tmp, "in.npy"), np.concatenate(imgs, axis=-1))
+        r = subprocess.run([sys.executable, "-c", code, os.path.join(tmp, "in.npy"), os.path.join(tmp, "out.npy"), repr(flags)],
+                           env=dict(os.environ, TRON_TUNING="1", **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return np.load(os.path.join(tmp, "out.npy"))
+
+
+def test_forward_switches_change_no_bit():
+    """The forward grid's line rotation (DegridParams::in_rot) only moves points in memory, and the forward FFT passes with the
+    LDS-DMA prefetch run the same line transform as the ones without: every switch must leave the samples bit-identical."""
+    nc, nimg = 8, 16
+    imgs = [synth.image(nc, 256, seed=9700 + k) for k in range(nimg)]
+    flags = dict(golden_angle=1, data_undersamp=32 / 512 + 1e-6)
+    ref = _forward_in_child(imgs, nimg, {}, **flags)
+    assert np.isfinite(ref).all()
+    for env in ({"TRON_GRID_ROT": "0"}, {"TRON_GRID_ROT": "4"}, {"TRON_FFT_FWD_COLS_PLAIN": "1"}, {"TRON_FFT_FWD_ROWS_PLAIN": "1"},
+                {"TRON_DEGRID_TILE": "1", "TRON_GRID_ROT": "0"}, {"TRON_DEGRID_SIMPLE": "1"}):
+        got = _forward_in_child(imgs, nimg, env, **flags)
+        if "TRON_DEGRID_SIMPLE" in env:         # the thread-per-sample kernel: the exact weights' order, fast weights differ in the last bits
+            assert rel_l2(got, ref) <= 2e-6, env
+        else:
+            assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), env
 
 
 def test_small_launches_stay_on_the_tile_kernel():
