@@ -152,7 +152,74 @@ __global__ void __launch_bounds__(kDsThreads) degrid_stream_kernel(const DegridP
     for (int j = 0; j < kDsKeep; ++j) kept[j].own = false;
     if (same_records && TRON_DBG_LT(p, 2)) {
         rd = dg_clip_round<kDsThreads, kDsMaxSpokes, kDsMaxBlocks>(p, L, k0, 0, tid, tx0, ty0, n, nr);
-        if (KB == TRON_KB_FAST) {
+        if (KB == TRON_KB_FAST && rd.nrec <= kDsKeep * kDsThreads && !p.debug_nosort) {
+            // All records fit the kept passes: they are dealt out SORTED BY THE POINT THEIR FOOTPRINT STARTS AT (counting sort
+            // through the wave stage area, once per run).  The lanes of a wave then gather from neighbouring points of a tile
+            // row -- consecutive LDS addresses -- where the samples of a spoke, 64 in a row, met 2.25-fold bank conflicts
+            // whatever the row pitch.  Records of other tiles' samples drop out here instead of idling a lane every image.
+            constexpr int EPT = (PLANE + kDsThreads - 1) / kDsThreads;      // points per thread in the scan
+            unsigned *hist = reinterpret_cast<unsigned *>(L.stage);         // [PLANE] counts, then first positions
+            unsigned short *perm = reinterpret_cast<unsigned short *>(hist + PLANE);   // [nrec] record ids in sorted order
+            static_assert((PLANE + kDsKeep * kDsThreads / 2) * 4 <= (int)sizeof(L.stage), "sort tables must fit the stage area");
+            for (int i = tid; i < PLANE; i += kDsThreads) hist[i] = 0u;
+            __syncthreads();
+            int slot[kDsKeep], rank[kDsKeep];
+#pragma unroll
+            for (int j = 0; j < kDsKeep; ++j) {
+                const int rec = tid + j * kDsThreads;
+                slot[j] = -1; rank[j] = 0;
+                if (rec < rd.nrec) {
+                    int pe, ro;
+                    float X, Y;
+                    if (dg_coords<kDsMaxSpokes>(p, L, rd, rec, tid & 63, tx0, ty0, n, nr, pe, ro, X, Y)) {
+                        slot[j] = ((int)ceilf(X - p.W) + HALO - tx0) * SX + ((int)ceilf(Y - p.W) + HALO - ty0) * SY;
+                        rank[j] = (int)atomicAdd(&hist[slot[j]], 1u);
+                    }
+                }
+            }
+            __syncthreads();
+            {   // exclusive scan of the counts
+                unsigned cnt[EPT], tsum = 0u;
+#pragma unroll
+                for (int e = 0; e < EPT; ++e) {
+                    const int i = tid * EPT + e;
+                    cnt[e] = i < PLANE ? hist[i] : 0u;
+                    tsum += cnt[e];
+                }
+                unsigned v = tsum;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const unsigned t = __shfl_up(v, o);
+                    if ((tid & 63) >= o) v += t;
+                }
+                if ((tid & 63) == 63) L.wcnt[wave] = (int)v;
+                __syncthreads();
+                unsigned run = v - tsum;
+                for (int w = 0; w < wave; ++w) run += (unsigned)L.wcnt[w];
+#pragma unroll
+                for (int e = 0; e < EPT; ++e) {
+                    const int i = tid * EPT + e;
+                    if (i < PLANE) hist[i] = run;
+                    run += cnt[e];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < kDsKeep; ++j)
+                if (slot[j] >= 0) perm[hist[slot[j]] + rank[j]] = (unsigned short)(tid + j * kDsThreads);
+            int nown = 0;
+            for (int w = 0; w < kDsThreads / 64; ++w) nown += L.wcnt[w];
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < kDsKeep; ++j) {
+                const int idx = tid + j * kDsThreads;
+                if (idx < nown) {
+                    const int rec = perm[idx];
+                    kept[j] = dg_prep<CW, kDsMaxSpokes, HALO, SX, SY>(p, kb, L, rd, rec, rec & 63, tx0, ty0, n, nr, c0);
+                }
+            }
+            __syncthreads();                                                // the stage area goes back to the waves
+        } else if (KB == TRON_KB_FAST) {
 #pragma unroll
             for (int j = 0; j < kDsKeep; ++j) {
                 const int rec = tid + j * kDsThreads;

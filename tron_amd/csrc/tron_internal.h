@@ -93,6 +93,7 @@ struct DegridParams {
                               // a tile's row segments then start on a 128-byte line, three lines each instead of four)
     int debug;                // TRON_DEBUG_SKIP (timing bisection): 1 = no sample loop, 2 = tile load only
     int group_end[4];         // degrid_stream_kernel: tile_order positions [group_end[c-1], group_end[c]) take runs of 2^c images (c = 4: the rest)
+    int debug_nosort;         // degrid_stream_kernel (tuning knob TRON_DEGRID_NOSORT): the kept records in list order, not sorted by footprint
     int group_max;            // ... capped by this (a quarter of the launch's images at most); < 4: degrid_tile_kernel only (8 images of 8 coils: 2.07 vs 1.79 us per coil image there)
     int n, nrep, nro, npe, nimg;
     int nrows;                // simple kernel only: rows of a non-square grid (0: n); n is then the column count

@@ -419,6 +419,8 @@ int forward_run(tron_plan *p, void *d_out, const void *d_in, int nimg, const flo
         g.beta = p->beta;
         memcpy(g.kb_poly, p->kb_poly, sizeof(g.kb_poly));
         memcpy(g.group_end, p->dg_group_end, sizeof(g.group_end));
+        static const bool nosort = tuning_env("TRON_DEGRID_NOSORT") != nullptr;
+        g.debug_nosort = nosort ? 1 : 0;
         g.group_max = (square && !p->degrid_tile_only) ? std::min(16, ck / 4) : 0;   // runs of images only where they leave enough workgroups
         {
             StageTimer t(p, STAGE_DEGRID);
