@@ -49,7 +49,8 @@ CASES = [
     (4, 128, 64, 5, dict(golden_angle=1, skip_angles=7)),            # smallest grid the kernel takes (4 x 4 tiles)
     (6, 256, 100, 2, dict(golden_angle=0)),                         # linear angles (6 coils: no slice groups)
     (1, 256, 180, 3, dict(golden_angle=1)),                          # one coil: 4-byte LDS-DMA planes
-    (8, 256, 120, 2, dict(golden_angle=1, kernwidth=1.0)),          # W = 1
+    (8, 256, 120, 2, dict(golden_angle=1, kernwidth=1.5)),          # W = 1.5 (the narrowest family of widths with a pair table: W > 1)
+    (2, 256, 120, 2, dict(golden_angle=0, kernwidth=1.25)),         # W = 1.25, linear angles: samples at exactly |x| = W on the axis spokes
     (2, 256, 120, 2, dict(golden_angle=1, kernwidth=3.0)),          # W = 3
     (4, 256, 90, 2, dict(golden_angle=1, kernwidth=2.5)),           # fractional W
     (8, 1024, 60, 1, dict(golden_angle=1)),                       # 1024^2 grid, few spokes
@@ -93,6 +94,9 @@ def test_arc_kernel_half_input_and_determinism(oracle):
     ((2, 1, 160, 100, 1), dict(golden_angle=1, data_undersamp=0.63), "grid centre inside a tile (nxos 160)"),
     ((2, 1, 256, 100, 1), dict(golden_angle=1, data_undersamp=0.39, gridos=1.5), "nro != nxos"),
     ((2, 1, 64, 40, 1), dict(golden_angle=1, data_undersamp=0.625), "grid smaller than 4 x 4 tiles"),
+    ((8, 1, 256, 120, 1), dict(golden_angle=1, data_undersamp=0.47, kernwidth=1.0), "W = 1: window B's support starts at the table's origin (build_kb_pair_lut)"),
+    ((2, 1, 256, 120, 1), dict(golden_angle=1, data_undersamp=0.47, kernwidth=0.5), "W < 1: no Kaiser-Bessel pair table (the round-3 table was read out of bounds here)"),
+    ((2, 1, 256, 120, 1), dict(golden_angle=1, data_undersamp=0.47, kernwidth=2.3), "W 2^k is no integer: the window's support would not end on a table piece"),
 ])
 def test_shapes_the_arc_kernel_leaves_to_the_binned_kernel(oracle, shape, flags, why):
     assert "grid_arc_kernel" not in _kernel_name(shape, **flags), why

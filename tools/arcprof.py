@@ -16,6 +16,8 @@ cfg = lib.default_config(adjoint=1, golden_angle=1, data_undersamp=0.7852, prof_
 dims = lib.derive_dims(cfg, (nc, 1, NRO, NPE * nz, 1))
 rng = np.random.default_rng(1)
 data = (rng.random(2 * nc * NRO * NPE * nz, dtype=np.float32) * 2 - 1)
+if os.environ.get("DATA") == "zeros":
+    data[:] = 0
 L = lib.load()
 fn = L.tron_debug_arc_profile
 fn.restype, fn.argtypes = ctypes.c_int, [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
@@ -31,6 +33,8 @@ tot = float(sum(buf[:8]))
 print(f"nc={nc} nz={nz}: {tot:.3e} wave-cycles in total")
 for name, v in zip(NAMES, buf):
     print(f"  {name:40s} {100.0 * v / tot:6.2f} %")
+if buf[9]:
+    print(f"  in-kernel clock (s_memtime / s_memrealtime x 100 MHz, summed over all waves): {buf[8] / buf[9] * 100:.0f} MHz")
 print(f"  outer (spoke) iterations per slice {buf[12] / nz:.0f}, lanes active {buf[13] / max(buf[12], 1) / 64:.3f}")
 print(f"  inner (radius) iterations per slice {buf[14] / nz:.0f}, lanes active {buf[15] / max(buf[14], 1) / 64:.3f}; "
       f"gather cycles per inner iteration {buf[6] / max(buf[14], 1):.0f}")

@@ -26,8 +26,11 @@
 //   window  each thread finds its own run [jlo, jhi] of the list by binary search on the line angles;
 //   batch   the comb's samples are copied global -> LDS by global_load_lds_dwordx4 (one wave instruction per spoke
 //           segment and coil pair) into one of TWO buffers: batch b + 1 flies while batch b is gathered, one barrier each;
-//   gather  thread: for its comb members, clip the spoke against the 2x2 block + footprint, then per radius: two products
-//           for (kx, ky), four table lookups, band tests, 4 points x CPB coils of packed FMAs from four 16-byte LDS reads.
+//   gather  thread: its comb members four at a time: clip each spoke against the 2x2 block + footprint (a packed descriptor:
+//           radii, first record, run entry), sort the four by chord length in registers (a wave runs the longest chord of
+//           its lanes: with every lane's longest first the k-th chords of a wave match far better), then per chord and radius:
+//           (kx, ky) as one packed product, ONE table position per axis serving both columns (rows) of the block (pair table,
+//           build_kb_pair_lut), band tests, 4 points x CPB coils of packed FMAs from four 16-byte LDS reads.
 // No floating-point atomics; the output is written once, coil-planar, in FFT-native order (tron_grid_store.h).
 #include <stdlib.h>
 
@@ -46,11 +49,11 @@ constexpr float kPi = 3.14159265358979f;
 
 // one and two coils: five workgroups per CU (83 / 94 VGPRs) beat four with larger batches by 3-4 % / 1 % (same-box A/B)
 #ifndef TRON_ARC_NREC1
-#define TRON_ARC_NREC1 2048
+#define TRON_ARC_NREC1 1520
 #define TRON_ARC_WAVES1 5
 #endif
 #ifndef TRON_ARC_NREC2
-#define TRON_ARC_NREC2 1024
+#define TRON_ARC_NREC2 760
 #define TRON_ARC_WAVES2 5
 #endif
 template <int CPB>
@@ -62,7 +65,9 @@ struct ArcCfg {
 #ifdef TRON_ARC_NREC
     static constexpr int NREC = TRON_ARC_NREC;
 #else
-    static constexpr int NREC = CPB >= 8 ? 608 : (CPB >= 6 ? 800 : (CPB >= 4 ? 800 : (CPB >= 2 ? TRON_ARC_NREC2 : TRON_ARC_NREC1)));
+    // LDS is handed out in units of 1280 bytes on gfx950 (160 KiB / 128): WAVES workgroups per CU need ArcLds <= 42 / 32 / 25 units
+    // for 3 / 4 / 5 (a first build of this table at 54 144 bytes ran TWO workgroups per CU, not three, and hid a 25 % saving)
+    static constexpr int NREC = CPB >= 8 ? 528 : (CPB >= 6 ? 704 : (CPB >= 4 ? 656 : (CPB >= 2 ? TRON_ARC_NREC2 : TRON_ARC_NREC1)));
 #endif
     static constexpr int WAVES = CPB >= 6 ? 3 : (CPB >= 4 ? 4 : (CPB >= 2 ? TRON_ARC_WAVES2 : TRON_ARC_WAVES1));
 #ifdef TRON_ARC_DOUBLE_BUFFER
@@ -77,8 +82,12 @@ template <int CPB>
 constexpr int arc_rec_bytes() { return CPB * 8; }
 
 template <int CPB>
+struct ArcLds;
+template <int CPB>
+constexpr bool arc_lds_fits() { return (sizeof(ArcLds<CPB>) + 1279) / 1280 * ArcCfg<CPB>::WAVES <= 128; }
+template <int CPB>
 struct ArcLds {
-    float4 lut[kArcLutEntries];            // Kaiser-Bessel window on [i, i + 1) / scale: c0 + f (c1 + f c2)
+    float2 lut[3 * kArcLutEntries];        // Kaiser-Bessel pair table, planes c0 | c1 | c2: entry = (this column, the next one), build_kb_pair_lut
     unsigned s_a[kArcMaxSpokes];           // run entry: sample index of its first record | (records run downwards) << 31
     unsigned s_b[kArcMaxSpokes];           //            ulo | len << 10 | record offset inside its batch << 17
     float2 s_cs[kArcMaxSpokes];            //            (cos, sin) of the (flipped) direction
@@ -101,10 +110,10 @@ int grid_arc_nrec(int nchan, int half_in)  // records per batch for a plan of nc
 #ifdef TRON_ARC_PROFILE
 constexpr int kArcProfSlots = 16, kArcProfCopies = 4096;
 __device__ unsigned long long g_arc_prof[kArcProfCopies * kArcProfSlots];
-#define APROF_DECL unsigned prof_acc[kArcProfSlots] = {}; unsigned long long prof_t = __builtin_readcyclecounter()
+#define APROF_DECL unsigned prof_acc[kArcProfSlots] = {}; unsigned long long prof_t = __builtin_readcyclecounter(); const unsigned long long prof_c0 = prof_t, prof_r0 = __builtin_amdgcn_s_memrealtime()
 #define APROF_MARK(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); prof_acc[i] += (unsigned)(t_ - prof_t); prof_t = t_; } while (0)
 #define APROF_COUNT(i, v) do { prof_acc[i] += (unsigned)(v); } while (0)
-#define APROF_FLUSH do { for (int i_ = 12; i_ < 16; ++i_) for (int o_ = 32; o_ > 0; o_ >>= 1) prof_acc[i_] += __shfl_xor(prof_acc[i_], o_); if (lane == 0) { for (int i_ = 0; i_ < kArcProfSlots; ++i_) if (prof_acc[i_]) atomicAdd(&g_arc_prof[((blockIdx.x * 4 + wave) % kArcProfCopies) * kArcProfSlots + i_], (unsigned long long)prof_acc[i_]); } } while (0)
+#define APROF_FLUSH do { prof_acc[8] = (unsigned)(__builtin_readcyclecounter() - prof_c0); prof_acc[9] = (unsigned)(__builtin_amdgcn_s_memrealtime() - prof_r0); for (int i_ = 12; i_ < 16; ++i_) for (int o_ = 32; o_ > 0; o_ >>= 1) prof_acc[i_] += __shfl_xor(prof_acc[i_], o_); if (lane == 0) { for (int i_ = 0; i_ < kArcProfSlots; ++i_) if (prof_acc[i_]) atomicAdd(&g_arc_prof[((blockIdx.x * 4 + wave) % kArcProfCopies) * kArcProfSlots + i_], (unsigned long long)prof_acc[i_]); } } while (0)
 #else
 #define APROF_DECL
 #define APROF_MARK(i)
@@ -115,6 +124,7 @@ __device__ unsigned long long g_arc_prof[kArcProfCopies * kArcProfSlots];
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(3))) v4f *lds_f4p;
+typedef const __attribute__((address_space(3))) v2f *lds_f2p;
 
 // ------------------------------------------------------------------------------------------------------------------------
 // Plan-time pass: the run of every (window, tile), dealt into combs.  grid = (tiles, windows), block = 256.
@@ -360,6 +370,7 @@ grid_arc_kernel(const GridParams p)
     using C = ArcCfg<CPB>;
     static_assert(CPB == 1 || CPB % 2 == 0, "the samples are copied as 16-byte coil pairs (or one coil as two 4-byte planes)");
     static_assert(!HALF || CPB % 4 == 0, "complex-half samples are copied four coils at a time");
+    static_assert(arc_lds_fits<CPB>(), "ArcCfg::WAVES workgroups of ArcLds do not fit a CU's 128 LDS units of 1280 bytes");
     extern __shared__ __align__(16) unsigned char lds_raw[];
     ArcLds<CPB> &L = *reinterpret_cast<ArcLds<CPB> *>(lds_raw);
 
@@ -436,12 +447,12 @@ grid_arc_kernel(const GridParams p)
         tlo = T - D;
         thi = T + D;
     }
-    const v2f p0v = {X0f, Y0f}, p1v = {X1f, Y1f}, lscale2 = {p.lut_scale, p.lut_scale};
+    const v2f p0v = {X0f, Y0f}, lscale2 = {p.lut_scale, p.lut_scale};
     const float We = p.W + 1e-3f;
     const float xlo = X0f - We, xhi = X1f + We, ylo = Y0f - We, yhi = Y1f + We;
 
-    for (int i = tid; i < p.lut_entries; i += kArcThreads) L.lut[i] = p.kb_lut[i];
-    const unsigned lut0 = lds_addr(L.lut);
+    for (int i = tid; i < 3 * kArcLutEntries; i += kArcThreads) L.lut[i] = p.kb_lut[i];
+    const lds_f2p lutq = (lds_f2p)(__attribute__((address_space(3))) const void *)L.lut + p.lut_bias;      // entry of table position 0
     const unsigned dbase = lds_addr(L.d);
     constexpr unsigned kBufBytes = (unsigned)(C::NREC * CPB * 8);
     constexpr unsigned kRecStep = CPB == 1 ? 4u : 16u;              // bytes between consecutive records of one plane
@@ -590,80 +601,116 @@ grid_arc_kernel(const GridParams p)
 #ifdef TRON_ARC_SKIP_OUTER
             mhi = -1;
 #endif
-            // member loop / radius loop (a flat loop over the visits, in which a lane moves on to its next member while the
-            // others keep visiting, was measured too: 27 % fewer wave iterations, but some lane needs a new
-            // member in 78 % of them and the iteration grows from 87 to 160 instructions: slower)
-            for (int m = mlo; m <= mhi; ++m) {
-                { const unsigned long long bm_ = __ballot(1); if (lane == __builtin_ctzll(bm_)) { APROF_COUNT(12, 1); APROF_COUNT(13, __popcll(bm_)); } }
-                const int i = b + K * m;
-                const float2 cs = L.s_cs[i];
-                const unsigned sb = L.s_b[i];
-                const int s_ulo = (int)(sb & 1023u), s_len = (int)((sb >> 10) & 127u);
-                const float ic = safe_rcp(cs.x), is = safe_rcp(cs.y);
-                // the radii whose sample lies inside the block's footprint: x0 - W < u cos < x1 + W, likewise y  (src/tron.cu:514-516)
-                const float xa = xlo * ic, xb = xhi * ic;
-                const float ya = ylo * is, yb = yhi * is;
-                const float lo = fmaxf(fmaxf(fminf(xa, xb), fminf(ya, yb)), fmaxf((float)s_ulo, blo_f));
-                const float hi = fminf(fminf(fmaxf(xa, xb), fmaxf(ya, yb)), fminf((float)(s_ulo + s_len - 1), bhi_f));
-                const int ua = (int)ceilf(lo), ub = (int)floorf(hi);
-                if (ua > ub) continue;
-#ifdef TRON_ARC_SKIP_INNER
-                acc[0][0].x += (float)ua; continue;
+            // Members four at a time: clip -> descriptor (radii << 28 | first record << 17 | run entry << 8 | first radius - bandlo),
+            // sort the four descending (the radii count leads), visit.  Simulated on the metric trajectory (tools/probe/
+            // arc_util_sim.py, which reproduces the kernel's wave-level counters): radius loop 36.0 k -> 30.4 k wave iterations
+            // per slice, lanes active 0.51 -> 0.60; a flat loop over a lane's visits would reach 0.69 but pays a member switch
+            // inside the hot loop (measured in round 3: slower).
+            // (bottom-tested: hipcc keeps two copies of the accumulators across a top-tested loop with a wave-uniform exit)
+            int m0 = mlo;
+            if (__ballot(m0 <= mhi) != 0ull) do {
+                unsigned desc[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    desc[k] = 0u;
+                    const int m = m0 + k;
+                    asm volatile("" ::: "memory");                                            // one clip after the other: four at once spill accumulators
+                    if (m <= mhi) {
+#ifdef TRON_ARC_PROFILE
+                        { const unsigned long long bm_ = __ballot(1); if (lane == __builtin_ctzll(bm_)) { APROF_COUNT(12, 1); APROF_COUNT(13, __popcll(bm_)); } }
 #endif
-                unsigned addr = buf + (unsigned)((int)(sb >> 17) - s_ulo + ua) * kRecStep;
-                v2f ufv = {(float)ua, (float)ua};
-                const v2f csv = {cs.x, cs.y};
-                int bit = ua - bandlo;
-                for (int u = ua; u <= ub; ++u) {
-                    { const unsigned long long bm_ = __ballot(1); if (lane == __builtin_ctzll(bm_)) { APROF_COUNT(14, 1); APROF_COUNT(15, __popcll(bm_)); } }
-                    // (kx, ky) = u (cos, sin), the distances to the block's columns / rows and their table positions as packed pairs
-                    const v2f kxy = ufv * csv;                                                // src/tron.cu:514-515
-                    const v2f t02 = (kxy - p0v) * lscale2, t13 = (kxy - p1v) * lscale2;       // (x - X0, y - Y0), (x - X1, y - Y1), times the table scale
-                    const float t0 = fabsf(t02.x), t2 = fabsf(t02.y), t1 = fabsf(t13.x), t3 = fabsf(t13.y);
-                    const v4f e0 = *(lds_f4p)(size_t)(lut0 + (unsigned)t0 * 16u), e1 = *(lds_f4p)(size_t)(lut0 + (unsigned)t1 * 16u);
-                    const v4f e2 = *(lds_f4p)(size_t)(lut0 + (unsigned)t2 * 16u), e3 = *(lds_f4p)(size_t)(lut0 + (unsigned)t3 * 16u);
-                    v4f dd[CPB / 2 > 0 ? CPB / 2 : 1];
-                    v2f d1 = {0.f, 0.f};
-                    if constexpr (CPB == 1) {
-                        d1.x = *(const __attribute__((address_space(3))) float *)(size_t)addr;
-                        d1.y = *(const __attribute__((address_space(3))) float *)(size_t)(addr + (unsigned)(C::NREC * 4));
-                    } else {
-#pragma unroll
-                        for (int c = 0; c < CPB / 2; ++c) dd[c] = *(lds_f4p)(size_t)(addr + (unsigned)(c * C::NREC * 16));
+                        const int i = b + K * m;
+                        const float2 cs = L.s_cs[i];
+                        const unsigned sb = L.s_b[i];
+                        const int s_ulo = (int)(sb & 1023u), s_len = (int)((sb >> 10) & 127u);
+                        // 1 / 0 = inf is fine here: the box edges are never 0 (W + 1e-3 is no integer), inf clips like a huge number
+                        const float ic = __builtin_amdgcn_rcpf(cs.x), is = __builtin_amdgcn_rcpf(cs.y);
+                        // the radii whose sample lies inside the block's footprint: x0 - W < u cos < x1 + W, likewise y  (src/tron.cu:514-516)
+                        const float xa = xlo * ic, xb = xhi * ic;
+                        const float ya = ylo * is, yb = yhi * is;
+                        const float lo = fmaxf(fmaxf(fminf(xa, xb), fminf(ya, yb)), fmaxf((float)s_ulo, blo_f));
+                        const float hi = fminf(fminf(fmaxf(xa, xb), fmaxf(ya, yb)), fminf((float)(s_ulo + s_len - 1), bhi_f));
+                        const int ua = (int)ceilf(lo), ub = (int)floorf(hi);
+                        if (ua <= ub)
+                            desc[k] = ((unsigned)(ub - ua + 1) << 28) | ((unsigned)((int)(sb >> 17) - s_ulo + ua) << 17) | ((unsigned)i << 8) | (unsigned)(ua - bandlo);
                     }
-                    const float sdc = fmaf(dcf_a, ufv.x, dcf_b);                              // src/tron.cu:412 (|ro - nro/2| = u)
-                    const float f0 = __builtin_amdgcn_fractf(t0), f1 = __builtin_amdgcn_fractf(t1);
-                    const float f2 = __builtin_amdgcn_fractf(t2), f3 = __builtin_amdgcn_fractf(t3);
-                    const float wx0 = fmaf(f0, fmaf(f0, e0.z, e0.y), e0.x), wx1 = fmaf(f1, fmaf(f1, e1.z, e1.y), e1.x);
-                    const float wy0 = fmaf(f2, fmaf(f2, e2.z, e2.y), e2.x) * sdc, wy1 = fmaf(f3, fmaf(f3, e3.z, e3.y), e3.x) * sdc;
-                    float wq[4];
-                    wq[0] = wx0 * wy0; wq[1] = wx1 * wy0; wq[2] = wx0 * wy1; wq[3] = wx1 * wy1;   // src/tron.cu:516
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)                                                    // src/tron.cu:512,521: bit u - bandlo of the point's band mask
-                        wq[q] = __uint_as_float(__float_as_uint(wq[q]) & (unsigned)__builtin_amdgcn_sbfe((int)bmask[q], bit, 1));
-                    if constexpr (CPB == 1) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            acc[q][0].x = fmaf(d1.x, wq[q], acc[q][0].x);                          // src/tron.cu:519
-                            acc[q][0].y = fmaf(d1.y, wq[q], acc[q][0].y);
-                        }
-                    }
-#pragma unroll
-                    for (int c = 0; c < CPB / 2; ++c) {
-                        const v4f d = dd[c];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            acc[q][2 * c].x = fmaf(d.x, wq[q], acc[q][2 * c].x);                  // src/tron.cu:519
-                            acc[q][2 * c].y = fmaf(d.y, wq[q], acc[q][2 * c].y);
-                            acc[q][2 * c + 1].x = fmaf(d.z, wq[q], acc[q][2 * c + 1].x);
-                            acc[q][2 * c + 1].y = fmaf(d.w, wq[q], acc[q][2 * c + 1].y);
-                        }
-                    }
-                    ufv += (v2f){1.0f, 1.0f};
-                    addr += kRecStep;
-                    ++bit;
                 }
-            }
+#ifdef TRON_ARC_SKIP_INNER
+                acc[0][0].x += (float)(desc[0] + desc[1] + desc[2] + desc[3]); desc[0] = desc[1] = desc[2] = desc[3] = 0u;
+#endif
+#ifndef TRON_ARC_NO_SORT
+#define TRON_ARC_CSWAP(a, b) { const unsigned hi_ = max(desc[a], desc[b]), lo_ = min(desc[a], desc[b]); desc[a] = hi_; desc[b] = lo_; }
+                TRON_ARC_CSWAP(0, 1) TRON_ARC_CSWAP(2, 3) TRON_ARC_CSWAP(0, 2) TRON_ARC_CSWAP(1, 3) TRON_ARC_CSWAP(1, 2)
+#undef TRON_ARC_CSWAP
+#endif
+#pragma unroll 1
+                for (int k = 0; k < 4; ++k) {                                                 // (one copy of the radius loop; k is wave-uniform)
+                    const unsigned dk = k == 0 ? desc[0] : (k == 1 ? desc[1] : (k == 2 ? desc[2] : desc[3]));
+                    if (dk != 0u) {                                                           // (no lane left: the compiler's execz branch skips the body)
+                        const float2 cs = L.s_cs[(dk >> 8) & 511u];
+                        unsigned addr = buf + ((dk >> 17) & 2047u) * kRecStep;
+                        int bit = (int)(dk & 255u);
+                        const int bit_end = bit + (int)(dk >> 28);
+                        const float uf0 = (float)(bit + bandlo);
+                        v2f ufv = {uf0, uf0};
+                        const v2f csv = {cs.x, cs.y};
+                        do {
+#ifdef TRON_ARC_PROFILE
+                            { const unsigned long long bm_ = __ballot(1); if (lane == __builtin_ctzll(bm_)) { APROF_COUNT(14, 1); APROF_COUNT(15, __popcll(bm_)); } }
+#endif
+                            // (kx, ky) = u (cos, sin) and the distances to the block's first column / row, op for op src/tron.cu:514-516;
+                            // their table positions as a packed pair: one position serves both columns (rows) of the block
+                            const v2f kxy = ufv * csv;
+                            const v2f tp = (kxy - p0v) * lscale2;                                      // exact: the scale is a power of two
+                            const v2f tt = {__builtin_truncf(tp.x), __builtin_truncf(tp.y)};
+                            const v2f fv = tp - tt;                                                    // in (-1, 1)
+                            const lds_f2p lx = lutq + (int)tt.x, ly = lutq + (int)tt.y;
+                            const v2f x0c = lx[0], x1c = lx[kArcLutEntries], x2c = lx[2 * kArcLutEntries];
+                            const v2f y0c = ly[0], y1c = ly[kArcLutEntries], y2c = ly[2 * kArcLutEntries];
+                            v4f dd[CPB / 2 > 0 ? CPB / 2 : 1];
+                            v2f d1 = {0.f, 0.f};
+                            if constexpr (CPB == 1) {
+                                d1.x = *(const __attribute__((address_space(3))) float *)(size_t)addr;
+                                d1.y = *(const __attribute__((address_space(3))) float *)(size_t)(addr + (unsigned)(C::NREC * 4));
+                            } else {
+#pragma unroll
+                                for (int c = 0; c < CPB / 2; ++c) dd[c] = *(lds_f4p)(size_t)(addr + (unsigned)(c * C::NREC * 16));
+                            }
+                            const float sdc = fmaf(dcf_a, ufv.x, dcf_b);                              // src/tron.cu:412 (|ro - nro/2| = u)
+                            const v2f fxv = {fv.x, fv.x}, fyv = {fv.y, fv.y}, sdcv = {sdc, sdc};
+                            const v2f wx = __builtin_elementwise_fma(fxv, __builtin_elementwise_fma(fxv, x2c, x1c), x0c);
+                            const v2f wy = __builtin_elementwise_fma(fyv, __builtin_elementwise_fma(fyv, y2c, y1c), y0c) * sdcv;
+                            const v2f w01 = wx * (v2f){wy.x, wy.x}, w23 = wx * (v2f){wy.y, wy.y};    // src/tron.cu:516
+                            float wq[4] = {w01.x, w01.y, w23.x, w23.y};
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)                                                // src/tron.cu:512,521: bit u - bandlo of the point's band mask
+                                wq[q] = __uint_as_float(__float_as_uint(wq[q]) & (unsigned)__builtin_amdgcn_sbfe((int)bmask[q], bit, 1));
+                            if constexpr (CPB == 1) {
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    acc[q][0].x = fmaf(d1.x, wq[q], acc[q][0].x);                      // src/tron.cu:519
+                                    acc[q][0].y = fmaf(d1.y, wq[q], acc[q][0].y);
+                                }
+                            }
+#pragma unroll
+                            for (int c = 0; c < CPB / 2; ++c) {
+                                const v4f d = dd[c];
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    acc[q][2 * c].x = fmaf(d.x, wq[q], acc[q][2 * c].x);              // src/tron.cu:519
+                                    acc[q][2 * c].y = fmaf(d.y, wq[q], acc[q][2 * c].y);
+                                    acc[q][2 * c + 1].x = fmaf(d.z, wq[q], acc[q][2 * c + 1].x);
+                                    acc[q][2 * c + 1].y = fmaf(d.w, wq[q], acc[q][2 * c + 1].y);
+                                }
+                            }
+                            ufv += (v2f){1.0f, 1.0f};
+                            addr += kRecStep;
+                            ++bit;
+                        } while (bit < bit_end);
+                    }
+                }
+                m0 += 4;
+            } while (__ballot(m0 <= mhi) != 0ull);
             APROF_MARK(6);                                      // gather
         }
 
@@ -729,7 +776,8 @@ static hipError_t launch_arc_cpb(const GridParams &p, int first_plain, hipStream
 bool grid_arc_supported(int nchan, int nxos, int nro, int npe, float W, int half_in)
 {
     const bool coils = half_in ? (nchan >= 4 && (nchan & 3) == 0) : (nchan == 1 || (nchan & 1) == 0);
-    return nchan >= 1 && coils && nro == nxos && nxos <= 2048 && npe <= kArcMaxNpe && W <= 3.0f
+    // widths without a Kaiser-Bessel pair table (W <= 1, W 2^k no integer; build_kb_pair_lut) stay on the binned kernel
+    return nchan >= 1 && coils && nro == nxos && nxos <= 2048 && npe <= kArcMaxNpe && W <= 3.0f && kb_pair_lut_scale(W, kArcLutEntries) > 0
            && (nxos / 2) % kArcTile == 0 && nxos >= 4 * kArcTile && (long long)nro * npe * nchan < (1ll << 28);
 }
 

@@ -35,9 +35,11 @@ void build_split_tile_order(int nxos, int tile, int npe, float W, int target, in
 bool build_centre_relief_order(int nxos, int tile, int npe, float W, int max_parts, int &inner_r0, std::vector<int> &order, std::vector<int> &slots,
                                int target_records = 1400);
 float kb_beta(float kernwidth);
-// arc gridding kernel: Kaiser-Bessel table, 128 quadratic pieces over [0, W) (c0, c1, c2, 0 per entry), zero beyond; returns the
-// largest error relative to the peak
-double build_kb_lut(float kernwidth, int entries, float *coef4, float *scale);
+// arc gridding kernel: Kaiser-Bessel table over the signed distance from a 2x2 block's first column, two windows per entry
+// (tron_hostmath.cpp); kb_pair_lut_scale = pieces per grid unit for a table of `cap` entries (0: this width has none),
+// build_kb_pair_lut fills coef[3][cap][2] and returns the entries used
+int kb_pair_lut_scale(float kernwidth, int cap);
+int build_kb_pair_lut(float kernwidth, int cap, float *coef, float *scale, int *bias, double *err);
 // arc gridding kernel: per window of npe spokes (cos_sin + 2 * stride * z), the spokes in ascending line angle (mod pi)
 void build_arc_tables(const float *cos_sin, size_t nwindows, size_t stride, int npe, unsigned short *order, float *phi);
 double kb_poly_fit(float kernwidth, float *poly, int nterms);

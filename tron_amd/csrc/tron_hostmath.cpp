@@ -235,39 +235,79 @@ double kb_poly_fit(float kernwidth, float *poly, int nterms)
     return worst / (amp * bessel_i0_series(beta));           // relative to the window's peak: what a weighted sum feels
 }
 
-// Table of the un-normalised Kaiser-Bessel window of src/tron.cu:338-349 for the arc gridding kernel: k = 128 intervals over
-// [0, W); entry i holds the quadratic through the window's values at the interval's ends and its middle, in f = the
-// fractional position: c0 + f (c1 + f c2).  The last interval ends on the smooth continuation at |x| = W, so the jump to
-// zero there stays exact: entries from k on are zero, up to |x| = W + 1.05, the largest distance the kernel ever looks up.
-// Max error relative to the peak 1.4e-7 at W = 2 (2.6e-7 at W = 3): returned.
-double build_kb_lut(float kernwidth, int entries, float *coef4, float *scale)
+// Table of the un-normalised Kaiser-Bessel window of src/tron.cu:338-349 for the arc gridding kernel, over the SIGNED distance
+// d = k - P0 of a sample coordinate from the first column (row) P0 of a thread's 2x2 block.  Table position t = d s; entry
+// i = trunc(t) (towards zero), fraction f = t - i in (-1, 1); the entry holds TWO quadratics c0 + f (c1 + f c2): component A the
+// window at d (column P0), component B the window at d - 1 (column P0 + 1) -- one position, one fraction and one address serve
+// both columns, and the two evaluations are one packed fma chain.  Planar: coef[0 .. cap) = c0 (A, B), coef[cap .. 2 cap) = c1,
+// coef[2 cap .. 3 cap) = c2, two floats per entry (cap = plane stride in entries); entry index = i + bias.
+//   Exactness of the support.  The reference's window is zero unless |x| < W, strictly (src/tron.cu:341), and jumps there by
+//   0.5 / W; trajectories with spokes along an axis put many samples at EXACTLY |x| = W, or an ulp inside.  s is a power of
+//   two, so t = d s is exact and |d| < W <=> |t| < W s in fp32, W s an integer.  Truncation makes the pieces (i - 1, i] for
+//   i < 0, (-1, 1) for i = 0 and [i, i + 1) for i > 0: every boundary of either window is then the CLOSED end of the first
+//   piece outside (A: t = -W s and t = W s; B: t = (1 - W) s < 0 and t = (1 + W) s), which holds zeros, and the last piece inside
+//   ends on the smooth continuation.  This needs (W - 1) s >= 1: W > 1.  (A floor-indexed table gets t = -W s wrong, a table
+//   with an offset or a scale that is no power of two rounds t near the upper boundaries; both were measured as 8e-6 on a
+//   linear-angle case against 2e-7.)  The piece around t = 0 is two units wide (8 x the others' error, one piece of ~ 2 W s).
+// Returns the pieces per grid unit s for a table of `cap` entries (0: this width has no such table: the caller falls back to
+// the binned kernel); build_kb_pair_lut returns the entries used, *err = largest error relative to the window's peak
+// (1.4e-7 at W = 2 outside the centre piece, 1.1e-6 in it).
+int kb_pair_lut_scale(float kernwidth, int cap)
 {
+    const double W = kernwidth;
+    if (!(W > 1.0) || cap < 16) return 0;
+    for (int s = 256; s >= 8; s >>= 1) {
+        const double ws = W * s;
+        if ((2.0 * W + 1.0) * s + 4.0 > cap || fabs(ws - nearbyint(ws)) > 1e-9 * ws || (W - 1.0) * s < 1.0) continue;
+        return s;
+    }
+    return 0;
+}
+
+int build_kb_pair_lut(float kernwidth, int cap, float *coef, float *scale, int *bias, double *err)
+{
+    const int s = kb_pair_lut_scale(kernwidth, cap);
+    if (s == 0) return 0;
     const double W = kernwidth, beta = kb_beta(kernwidth), amp = 0.5 / W;
-    const int k = 128;
-    auto f = [&](double i) {
-        const double r = i / k;                                      // |x| / W
+    const int ws = (int)nearbyint(W * s);
+    const int b = ws + 2, imin = -ws - 1, imax = ws + s + 1;
+    auto win = [&](double x) {                                       // smooth continuation of the window
+        const double r = x / W;
         return amp * bessel_i0_series(beta * sqrt(std::max(0.0, 1.0 - r * r)));
     };
     double worst = 0.0;
-    for (int i = 0; i < entries; ++i) {
-        double c0 = 0.0, c1 = 0.0, c2 = 0.0;
-        if (i < k) {
-            const double y0 = f(i), ym = f(i + 0.5), y1 = f(i + 1.0);
-            c0 = y0;
-            c2 = 2.0 * (y1 - 2.0 * ym + y0);
-            c1 = y1 - y0 - c2;
-            for (int t = 1; t < 8; ++t) {
-                const double ff = t / 8.0;
-                worst = std::max(worst, fabs(c0 + ff * (c1 + ff * c2) - f(i + ff)) / f(0.0));
+    for (int i = 0; i < 3 * 2 * cap; ++i) coef[i] = 0.f;
+    for (int i = imin; i <= imax; ++i)
+        for (int w = 0; w < 2; ++w) {
+            // window w is F(t) = win(t / s - w) on (lo, hi) = ((w - W) s, (w + W) s); piece i lies inside or outside as a whole
+            const int lo = w * s - ws, hi = w * s + ws;
+            const int p0 = i < 0 ? i - 1 : (i == 0 ? -1 : i), p1 = i <= 0 ? (i == 0 ? 1 : i) : i + 1;      // the piece's ends
+            if (p0 < lo || p1 > hi) continue;
+            auto F = [&](double f) { return win((i + f) / s - w); };
+            double c0 = F(0.0), c1, c2;
+            if (i == 0) {
+                c2 = 0.5 * (F(1.0) + F(-1.0)) - c0;
+                c1 = 0.5 * (F(1.0) - F(-1.0));
+            } else {
+                const double sg = i > 0 ? 1.0 : -1.0;                // nodes 0, sg / 2, sg
+                const double ym = F(0.5 * sg), y1 = F(sg);
+                c2 = 2.0 * (y1 - 2.0 * ym + c0);
+                c1 = sg * (y1 - c0 - c2);
             }
+            for (int t = -7; t < 8; ++t) {
+                const double ff = t / 8.0;
+                if ((i > 0 && ff < 0) || (i < 0 && ff > 0)) continue;
+                worst = std::max(worst, fabs(c0 + ff * (c1 + ff * c2) - F(ff)) / win(0.0));
+            }
+            const int e = i + b;
+            coef[2 * e + w] = (float)c0;
+            coef[2 * (cap + e) + w] = (float)c1;
+            coef[2 * (2 * cap + e) + w] = (float)c2;
         }
-        coef4[4 * i] = (float)c0;
-        coef4[4 * i + 1] = (float)c1;
-        coef4[4 * i + 2] = (float)c2;
-        coef4[4 * i + 3] = 0.f;
-    }
-    *scale = (float)k / kernwidth;
-    return worst;
+    *scale = (float)s;
+    *bias = b;
+    if (err) *err = worst;
+    return imax + b + 1;
 }
 
 void build_arc_tables(const float *cos_sin, size_t nwindows, size_t stride, int npe, unsigned short *order, float *phi)

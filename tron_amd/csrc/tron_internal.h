@@ -59,8 +59,9 @@ struct GridParams {
     const float *arc_ephi;             // [window][arc_cap] -> unwrapped line angle
     int arc_cap, arc_nrec;             // entries per window; records per batch the runs were dealt for
     int arc_slice_stride;              // windows between consecutive slices: 1 (golden angle) or 0 (every slice has the same angles)
-    const float4 *kb_lut;              // Kaiser-Bessel window on [i, i + 1) / lut_scale as c0 + f (c1 + f c2); zero from |x| = W on
-    int lut_entries;
+    const float2 *kb_lut;              // [3][kArcLutEntries] Kaiser-Bessel pair table: position t = d lut_scale of the signed distance d from a block's
+                                       // first column, entry trunc(t) + lut_bias: c0 + f (c1 + f c2) for that column (.x) and the next (.y); zero from |x| = W on
+    int lut_entries, lut_bias;
     float lut_scale;
     int arc_zper;                      // consecutive slices one workgroup grids in turn (the table stays in LDS)
 };
@@ -113,7 +114,7 @@ hipError_t launch_grid_arc(const GridParams &p, int half_in, int first_plain, hi
 hipError_t launch_grid_reduce(const GridParams &p, hipStream_t s);
 bool grid_arc_supported(int nchan, int nxos, int nro, int npe, float W, int half_in);
 int grid_arc_nrec(int nchan, int half_in);
-constexpr int kArcLutEntries = 272;    // Kaiser-Bessel table entries held in LDS (128 intervals per W, up to |x| = W + 1.05, W >= 1)
+constexpr int kArcLutEntries = 400;    // Kaiser-Bessel pair-table entries held in LDS (build_kb_pair_lut: (2 W + 1) s + 4 of them, s a power of two, W > 1)
 // plan-time pass of the arc kernel: clips every window's angle-sorted spokes against every tile and deals the runs into batches
 struct ArcPrepParams {
     const unsigned short *order;       // [window][npe] window-relative spoke index, ascending line angle (mod pi)

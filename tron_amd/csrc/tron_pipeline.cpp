@@ -248,8 +248,9 @@ int adjoint_run_raw(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, 
                     g.arc_nrec = p->arc_nrec;
                     g.arc_slice_stride = golden ? 1 : 0;
                     g.kb_lut = p->d_kb_lut;
-                    g.lut_entries = kArcLutEntries;
+                    g.lut_entries = p->lut_entries;
                     g.lut_scale = p->lut_scale;
+                    g.lut_bias = p->lut_bias;
                     // slices one workgroup grids in turn (tile geometry and the window table are set up once per workgroup)
                     g.arc_zper = p->arc_zper > 0 ? p->arc_zper : (cz >= 64 ? 4 : (cz >= 32 ? 2 : 1));
                     HIP_TRY(launch_grid_arc(g, p->cfg.input_half, relief_parts, st));

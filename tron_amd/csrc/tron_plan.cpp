@@ -261,8 +261,9 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
                 }
             }
             if (p->arc) {
-                std::vector<float> lut(4 * (size_t)kArcLutEntries);
-                p->lut_err = build_kb_lut(cfg->kernwidth, kArcLutEntries, lut.data(), &p->lut_scale);
+                std::vector<float> lut(6 * (size_t)kArcLutEntries);
+                p->lut_entries = build_kb_pair_lut(cfg->kernwidth, kArcLutEntries, lut.data(), &p->lut_scale, &p->lut_bias, &p->lut_err);
+                if (p->lut_entries <= 0) return bail(fail(TRON_ERR_UNSUPPORTED, "no Kaiser-Bessel pair table for width %g", (double)cfg->kernwidth));
                 if ((rc = upload(&p->d_kb_lut, lut.data(), lut.size() * sizeof(float)))) return bail(rc);
                 p->arc_zper = 0;                                    // 0: by launch size (tron_pipeline.cpp)
                 // the inner tile's workgroups are few and slow (every spoke passes the k-space centre): on a stream of their own,

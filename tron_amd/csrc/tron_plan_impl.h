@@ -90,9 +90,10 @@ struct tron_plan {
     int4 *d_arc_hdr = nullptr;
     uint4 *d_arc_ent = nullptr;
     float *d_arc_ephi = nullptr;
-    float4 *d_kb_lut = nullptr;
+    float2 *d_kb_lut = nullptr;
     int arc_cap = 0, arc_nrec = 0, arc_zper = 1;
     float lut_scale = 0;
+    int lut_entries = 0, lut_bias = 0;
     double lut_err = 0;
     hipStream_t stream_inner = nullptr;   // the inner tile's parts (binned kernel) run beside the arc kernel
     hipEvent_t ev_inner[2] = {nullptr, nullptr};
