@@ -192,6 +192,12 @@ const char *tron_plan_grid_kernel_name(const tron_plan *plan);
    for launches of 16 images and more on grids of whole 32x32 tiles, degrid_tile_kernel otherwise. */
 const char *tron_plan_degrid_kernel_name(const tron_plan *plan);
 
+/* Wall-clock seconds tron_plan_create spent on this plan (the reference's one published time, src/RUNME4:219, clocks tron_init
+   too: src/tron.cu:973-978): [0] total, [1] HIP runtime + code objects (the first plan of a process pays for both),
+   [2] host tables and their upload, [3] of [2]: the arc / centre gridding kernels' run tables (host sort by line angle +
+   arc_prep_kernel), [4] device work buffers. */
+int tron_plan_create_times(const tron_plan *plan, double seconds[5]);
+
 /* Per-stage device timing with hipEvents on the plan's stream (off by default; costs one
    event pair per launch).  stage: 0 grid, 1 fft, 2 post (crop+deapod+SoS), 3 pre
    (pad+deapod), 4 degrid.  Returns accumulated milliseconds and launch count since the

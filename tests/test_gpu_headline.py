@@ -96,6 +96,61 @@ def test_config2_linear_256_image_to_512x512_spokes_and_back(oracle, kb):
     assert rel_l2(back, back_want) <= TOL
 
 
+@pytest.mark.timeout(1800)
+def test_device_resident_256_slices_two_lanes_as_the_bench_times_them(oracle):
+    """What bench.py times, under pytest: `tron_nufft_adj_radial2d` on 256 slices x 8 coils resident in HBM = two 128-slice
+    gridding launches with the FFT lane beside them, called twice in a row (the second call's first launches run beside the
+    first call's last FFT passes); slices 0 / 127 / 128 / 255 of the second call against the oracle.  The stream is assembled from
+    eight 32-slice blocks (one seeded generator call each); the oracle grids a block with the global angle index of its first
+    spoke (-s, src/tron.cu:509)."""
+    nc, nz, npe, blk = 8, 256, 402, 32
+    flags = dict(golden=1, data_undersamp=0.7852, prof_slide=npe)
+    cfg = lib.default_config(adjoint=1, golden_angle=1, data_undersamp=0.7852, prof_slide=npe)
+    dims = lib.derive_dims(cfg, (nc, 1, NRO, npe * nz, 1))
+    assert (dims.nz, dims.npe1work, dims.nxos, dims.nx) == (nz, npe, 512, 256)
+    block_bytes = nc * NRO * npe * blk * 8
+    kept = {}
+    with lib.Plan(cfg, dims) as plan:
+        assert "grid_arc_kernel" in plan.grid_kernel_name()
+        d_in = lib.DeviceBuffer(block_bytes * (nz // blk))
+        for k in range(nz // blk):
+            data = synth.kspace(nc, NRO, npe * blk, seed=synth.SEED_BASE + 40 + k)
+            d_in.write(np.asfortranarray(data).reshape(-1, order="F"), k * block_bytes)
+            if k in (0, 3, 4, 7):
+                kept[k] = data
+        d_out = lib.DeviceBuffer(dims.out_bytes)
+        assert plan.two_lanes(True), "a 256-slice plan of 8 coils runs gridding || FFT"
+        plan.adjoint_device(d_out.ptr, d_in.ptr, 0, nz, 1)
+        plan.adjoint_device(d_out.ptr, d_in.ptr, 0, nz, 1)
+        plan.sync()
+        got = d_out.to_numpy(np.complex64, 256 * 256 * nz).reshape((256, 256, nz), order="F")
+    assert np.isfinite(got).all()
+    for z in (0, 127, 128, 255):
+        k = z // blk
+        want, _ = oracle.recon(kept[k], adjoint=1, zfirst=z - k * blk, zcount=1, skip_angles=k * blk * npe, **flags)
+        err = rel_l2(got[..., z], want[0, 0, :, :, z - k * blk])
+        assert err <= TOL, (z, err)
+
+
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("golden", [1, 0])
+def test_forward_at_the_bench_shape_64_images_8_coils_512x512_spokes(oracle, golden):
+    """`bench.py --forward`'s launch under pytest: 8 coils x 64 images of 256^2 -> 512 readout x 512 spokes in ONE
+    tron_nufft_radial2d call (degrid_stream_kernel at full sampling density: the kept-record and sorted-deal paths of the centre
+    tiles are in play), images 0 / 31 / 63 against the oracle's degridradial2d pipeline (src/tron.cu:540-577, 639-649), golden and
+    linear angles."""
+    from test_gpu_degrid_stream import _forward
+    nc, nimg = 8, 64
+    imgs = [synth.image(nc, 256, seed=synth.SEED_BASE + 60 + k) for k in range(nimg)]
+    got, name = _forward(imgs, nimg, golden_angle=golden)
+    assert name == "degrid_stream_kernel"
+    assert got.shape == (nimg, nc * 512 * 512) and np.isfinite(got.view(np.float32)).all()
+    for k in (0, 31, 63):
+        want, p = oracle.recon(imgs[k], adjoint=0, golden=golden)
+        assert (p.nro, p.npe1work, p.nxos) == (512, 512, 512)
+        assert rel_l2(got[k], want.reshape(-1, order="F")) <= TOL, k
+
+
 @pytest.mark.timeout(1200)
 def test_cgnr_at_the_metric_shape(oracle):
     """CGNR (src/tron.cu:665-720) at the headline size: 512 x 402 golden-angle spokes, 2 coils, 2 non-overlapping slices,

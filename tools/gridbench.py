@@ -3,6 +3,9 @@ usage: python tools/gridbench.py [coils] [slices] [kb fast|exact] [reps]"""
 import ctypes, os, sys, time
 os_env_ = __import__("os").environ; os_env_.setdefault("TRON_TUNING", "1")   # the library reads TRON_* switches only under TRON_TUNING=1
 import numpy as np
+if os.environ.get("WITH_TORCH") == "1":     # as bench.py: torch's HIP runtime first (the stage times of the two scripts differ by which runtime the process holds)
+    import torch
+    torch.zeros(1, device="cuda")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tron_amd import lib
 nc = int(sys.argv[1]) if len(sys.argv) > 1 else 8
@@ -19,7 +22,11 @@ if os.environ.get("DATA") == "zeros":      # same instruction stream, no togglin
 with lib.Plan(cfg, dims) as plan:
     d_in = lib.DeviceBuffer.from_numpy(data)
     d_out = lib.DeviceBuffer(dims.out_bytes)
-    plan.adjoint_device(d_out.ptr, d_in.ptr, 0, nz, 1); plan.sync()
+    # WARM untimed calls first (default 1): the chip's clock takes tens of milliseconds of load to settle, and a run of a few
+    # launches from idle is timed on the ramp (gridbench's 5 reps read 15-19 % slower than bench.py's steady state for that reason)
+    for _ in range(int(os.environ.get("WARM", "1"))):
+        plan.adjoint_device(d_out.ptr, d_in.ptr, 0, nz, 1)
+    plan.sync()
     plan.timing(True); plan.timing_reset()
     t0 = time.perf_counter()
     for _ in range(reps):

@@ -322,4 +322,12 @@ hipError_t launch_degrid_stream(const DegridParams &p, int kb_mode, hipStream_t 
     return hipErrorInvalidValue;
 }
 
+__global__ void warm_degrid_stream_tu() {}
+
+hipError_t warm_degrid_stream()   // see warm_kernels() in tron_kernels.hip: this translation unit had none until round 4
+{
+    hipLaunchKernelGGL(warm_degrid_stream_tu, dim3(1), dim3(64), 0, nullptr);
+    return hipGetLastError();
+}
+
 }  // namespace tron

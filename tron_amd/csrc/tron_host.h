@@ -40,6 +40,8 @@ float kb_beta(float kernwidth);
 // build_kb_pair_lut fills coef[3][cap][2] and returns the entries used
 int kb_pair_lut_scale(float kernwidth, int cap);
 int build_kb_pair_lut(float kernwidth, int cap, float *coef, float *scale, int *bias, double *err);
+// centre kernel: per window and block of `groups` its run of the angle-sorted spoke list (first | count << 16)
+void build_centre_windows(const float *phi, size_t nwindows, int npe, const int *groups, int ngroups, float W, uint32_t *out);
 // arc gridding kernel: per window of npe spokes (cos_sin + 2 * stride * z), the spokes in ascending line angle (mod pi)
 void build_arc_tables(const float *cos_sin, size_t nwindows, size_t stride, int npe, unsigned short *order, float *phi);
 double kb_poly_fit(float kernwidth, float *poly, int nterms);

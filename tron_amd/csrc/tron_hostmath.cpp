@@ -310,6 +310,39 @@ int build_kb_pair_lut(float kernwidth, int cap, float *coef, float *scale, int *
     return imax + b + 1;
 }
 
+// Centre kernel (tron_grid_centre.hip): per window and 2x2 block (col | row << 8 of the origin-centred 32 x 32 square) the block's run
+// of the angle-sorted spoke list, first entry | entries << 16, circular.  The arc kernel's rule: a spoke of line angle phi reaches
+// the block's footprint only if its line passes within (W + 1/2)(|cos phi| + |sin phi|) of the block centre (tron_grid_arc.hip).
+void build_centre_windows(const float *phi, size_t nwindows, int npe, const int *groups, int ngroups, float W, uint32_t *out)
+{
+    const float pi = 3.14159265358979f;
+    for (int g = 0; g < ngroups; ++g) {
+        const float Xc = 2.f * (groups[g] & 255) - 16.f + 0.5f, Yc = 2.f * (groups[g] >> 8) - 16.f + 0.5f;
+        const float R = sqrtf(Xc * Xc + Yc * Yc);
+        const float sd0 = (W + 0.52f) * 1.41421356f / R;
+        const float wcs = fminf(1.41421356f, (fabsf(Xc) + fabsf(Yc)) / R + 1.5f * sd0);
+        const float sd = (W + 0.52f) * wcs / R;
+        const float D = sd < 0.999f ? asinf(sd) + 2e-3f : 4.0f;
+        const bool all = !(D < 0.5f * pi - 1e-3f);
+        float T = atan2f(Yc, Xc);
+        T -= floorf(T / pi) * pi;
+        const float tlo = T - D, thi = T + D;
+        const bool wrap = tlo < 0.f || thi >= pi;
+        const float a = tlo < 0.f ? tlo + pi : tlo, b = thi >= pi ? thi - pi : thi;
+        for (size_t w = 0; w < nwindows; ++w) {
+            const float *ph = phi + w * npe;
+            int first = 0, count = npe;
+            if (!all) {
+                const int na = (int)(std::lower_bound(ph, ph + npe, a) - ph), nb = (int)(std::upper_bound(ph, ph + npe, b) - ph);
+                first = na;
+                count = wrap ? npe - na + nb : nb - na;
+                count = std::max(0, std::min(count, npe));
+            }
+            out[w * ngroups + g] = (uint32_t)(first % std::max(npe, 1)) | ((uint32_t)count << 16);
+        }
+    }
+}
+
 void build_arc_tables(const float *cos_sin, size_t nwindows, size_t stride, int npe, unsigned short *order, float *phi)
 {
     std::vector<std::pair<float, int>> key(npe);

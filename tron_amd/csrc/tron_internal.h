@@ -64,6 +64,12 @@ struct GridParams {
     int lut_entries, lut_bias;
     float lut_scale;
     int arc_zper;                      // consecutive slices one workgroup grids in turn (the table stays in LDS)
+    // centre kernel (tron_grid_centre.hip): the angle-sorted spoke lists of the arc kernel's plan, kept
+    const unsigned short *cen_order;   // [window][npe] window-relative spoke index, ascending line angle (mod pi)
+    const uint32_t *cen_win;           // [window][cen_ngroups] the block's run of that list: first entry | entries << 16 (circular)
+    const float2 *cen_cs;              // [window][npe] (cos, sin) of that spoke
+    const int *cen_groups;             // base blocks (col | row << 8) of the quadrant x, y >= 0 of the origin-centred 32 x 32 square, nearest first
+    int cen_ngroups;
 };
 
 struct PostParams {           // crop + deapodise + (optional) root-sum-of-squares, adjoint tail
@@ -112,6 +118,9 @@ constexpr int kBinnedTile = 32;
 // (binned kernel, no_reduce) before and launch_grid_reduce after it
 hipError_t launch_grid_arc(const GridParams &p, int half_in, int first_plain, hipStream_t s);
 hipError_t launch_grid_reduce(const GridParams &p, hipStream_t s);
+// the samples |r| < p.inner_r0 ADDED to the grid the arc kernel has stored (tron_grid_centre.hip): same stream, behind launch_grid_arc
+hipError_t launch_grid_centre(const GridParams &p, int half_in, hipStream_t s);
+hipError_t warm_grid_centre();
 bool grid_arc_supported(int nchan, int nxos, int nro, int npe, float W, int half_in);
 int grid_arc_nrec(int nchan, int half_in);
 constexpr int kArcLutEntries = 400;    // Kaiser-Bessel pair-table entries held in LDS (build_kb_pair_lut: (2 W + 1) s + 4 of them, s a power of two, W > 1)
@@ -139,6 +148,7 @@ hipError_t warm_kernels();       // force-load the code object of tron_kernels.h
 hipError_t warm_grid_binned();   // ... and of tron_grid_binned.hip
 hipError_t warm_fft512();        // ... and of tron_fft512.hip
 hipError_t warm_degrid_tile();   // ... and of tron_degrid_tile.hip
+hipError_t warm_degrid_stream(); // ... and of tron_degrid_stream.hip
 hipError_t warm_cgnr();          // ... and of tron_cgnr.hip
 // CGNR vector kernels (tron_cgnr.hip), batched over slices; per-slice scalars live on the device
 hipError_t launch_cg_scale_norm2(float2 *x, size_t n, int nslices, float scale, double *partial, hipStream_t s);

@@ -46,6 +46,42 @@ int get_fft(tron_plan *p, int batch, int inverse, FftPlan **out)
         // rocFFT builds its twiddle tables with a kernel on a stream of its own; make sure that has
         // finished before the first execution on ours (a non-blocking stream does not wait for it)
         HIP_TRY(hipDeviceSynchronize());
+        // ... and its transform kernels are loaded lazily at their first launch, an upload that a non-blocking stream does not
+        // wait for either (the same race the warm_* launches close for this library's own code objects; on a
+        // fresh box the first process of a test run lost it about one time in three: a wrong image or a memory fault in a rocFFT
+        // size).  The first transform of every (size, direction) of a process therefore runs on the NULL stream, batch 1, on scratch.
+        {
+            static std::mutex warm_mu;
+            static std::set<std::tuple<int, int, int, int>> warmed;
+            std::lock_guard<std::mutex> lock(warm_mu);
+            const auto wkey = std::make_tuple(p->cfg.device, p->d.nxos, p->d.nyos, inverse);
+            if (!warmed.count(wkey)) {
+                rocfft_plan wp = nullptr;
+                rocfft_execution_info wi = nullptr;
+                void *scratch = nullptr, *wwork = nullptr;
+                size_t wbytes = 0;
+                bool ok = rocfft_plan_create(&wp, rocfft_placement_inplace,
+                                             inverse ? rocfft_transform_type_complex_inverse : rocfft_transform_type_complex_forward,
+                                             rocfft_precision_single, 2, lengths, 1, nullptr) == rocfft_status_success &&
+                          rocfft_execution_info_create(&wi) == rocfft_status_success &&
+                          rocfft_execution_info_set_stream(wi, nullptr) == rocfft_status_success &&
+                          rocfft_plan_get_work_buffer_size(wp, &wbytes) == rocfft_status_success &&
+                          hipMalloc(&scratch, lengths[0] * lengths[1] * sizeof(float2)) == hipSuccess &&
+                          hipMemset(scratch, 0, lengths[0] * lengths[1] * sizeof(float2)) == hipSuccess;
+                if (ok && wbytes) ok = hipMalloc(&wwork, wbytes) == hipSuccess && rocfft_execution_info_set_work_buffer(wi, wwork, wbytes) == rocfft_status_success;
+                if (ok) {
+                    void *bufs[1] = {scratch};
+                    ok = rocfft_execute(wp, bufs, nullptr, wi) == rocfft_status_success;
+                }
+                const hipError_t se = hipDeviceSynchronize();
+                if (wi) rocfft_execution_info_destroy(wi);
+                if (wp) rocfft_plan_destroy(wp);
+                hipFree(scratch);
+                hipFree(wwork);
+                if (!ok || se != hipSuccess) return fail(TRON_ERR_FFT, "rocFFT warm-up transform %dx%d failed", p->d.nxos, p->d.nyos);
+                warmed.insert(wkey);
+            }
+        }
         it = p->fft.emplace(key, f).first;
     }
     *out = &it->second;
@@ -232,7 +268,9 @@ int adjoint_run_raw(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, 
                     GridParams gi = g;
                     gi.tile_entries = relief_parts;
                     gi.no_reduce = 1;
-                    if (p->inner_beside) {
+                    if (p->centre_kernel) {
+                        // (the centre kernel adds the samples |r| < inner_r0 behind the arc kernel, below)
+                    } else if (p->inner_beside) {
                         HIP_TRY(hipEventRecord(p->ev_inner[0], st));             // (the reduce pass that last read the parts buffer is behind this)
                         HIP_TRY(hipStreamWaitEvent(p->stream_inner, p->ev_inner[0], 0));
                         HIP_TRY(launch_grid_binned(gi, p->cfg.input_half, p->stream_inner));
@@ -254,8 +292,18 @@ int adjoint_run_raw(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, 
                     // slices one workgroup grids in turn (tile geometry and the window table are set up once per workgroup)
                     g.arc_zper = p->arc_zper > 0 ? p->arc_zper : (cz >= 64 ? 4 : (cz >= 32 ? 2 : 1));
                     HIP_TRY(launch_grid_arc(g, p->cfg.input_half, relief_parts, st));
-                    if (p->inner_beside) HIP_TRY(hipStreamWaitEvent(st, p->ev_inner[1], 0));
-                    HIP_TRY(launch_grid_reduce(g, st));
+                    if (p->centre_kernel) {
+                        const size_t woff = win0 * (size_t)d.npe1work;
+                        g.cen_order = p->d_cen_order + woff;
+                        g.cen_win = p->d_cen_win + win0 * (size_t)p->cen_ngroups;
+                        g.cen_cs = p->d_cen_cs + woff;
+                        g.cen_groups = p->d_cen_groups;
+                        g.cen_ngroups = p->cen_ngroups;
+                        HIP_TRY(launch_grid_centre(g, p->cfg.input_half, st));
+                    } else {
+                        if (p->inner_beside) HIP_TRY(hipStreamWaitEvent(st, p->ev_inner[1], 0));
+                        HIP_TRY(launch_grid_reduce(g, st));
+                    }
                 } else {
                     HIP_TRY(launch_grid_binned(g, p->cfg.input_half, st));
                 }

@@ -39,6 +39,13 @@ std::once_flag g_fft_once;   // rocfft_setup() on the first rocFFT plan (get_fft
 
 extern "C" const char *tron_last_error(void) { return g_last_error.c_str(); }
 
+extern "C" int tron_plan_create_times(const tron_plan *plan, double seconds[5])
+{
+    if (!plan || !seconds) return fail(TRON_ERR_INVALID, "tron_plan_create_times: null argument");
+    for (int i = 0; i < 5; ++i) seconds[i] = plan->create_s[i];
+    return TRON_OK;
+}
+
 extern "C" const char *tron_version(void) { return "tronhip 0.1 (gfx950)"; }
 
 extern "C" int tron_plan_create(tron_plan **out, const tron_config *cfg, const tron_dims *dims)
@@ -94,8 +101,10 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
     HIP_TRY(warm_kernels());
     HIP_TRY(warm_grid_binned());
     HIP_TRY(warm_grid_arc());
+    HIP_TRY(warm_grid_centre());
     HIP_TRY(warm_fft512());
     HIP_TRY(warm_degrid_tile());
+    HIP_TRY(warm_degrid_stream());
     HIP_TRY(warm_cgnr());
     HIP_TRY(hipDeviceSynchronize());
     const double t_runtime = since();                // HIP runtime + code objects (the first plan of a process pays for both)
@@ -215,6 +224,23 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
                 std::vector<unsigned short> order(nwin * npe);
                 std::vector<float> phi(nwin * npe);
                 build_arc_tables(trig.data() + 2 * win_first * (size_t)d.prof_slide, nwin, (size_t)d.prof_slide, npe, order.data(), phi.data());
+                {   // centre kernel: the 2x2 blocks of the origin-centred 32 x 32 square that a sample |r| < inner_r0 can reach, nearest the
+                    // origin (most spokes) first
+                    std::vector<int> groups;
+                    const float reach = (float)(p->relief_r0 - 1) + cfg->kernwidth + 1.0f;
+                    auto d2 = [](int g) { const float x = 2.f * (g & 255) - 15.f, y = 2.f * (g >> 8) - 15.f; return x * x + y * y; };   // block centre
+                    for (int j = 0; j < 16; ++j)
+                        for (int i = 0; i < 16; ++i) {
+                            const float ax = fabsf(2.f * i - 15.f) - 0.5f, ay = fabsf(2.f * j - 15.f) - 0.5f;                           // its nearest point
+                            if (ax * ax + ay * ay <= reach * reach) groups.push_back(i | (j << 8));
+                        }
+                    std::stable_sort(groups.begin(), groups.end(), [&](int a, int b) { return d2(a) < d2(b); });
+                    p->cen_ngroups = (int)groups.size();
+                    if ((rc = upload(&p->d_cen_groups, groups.data(), groups.size() * sizeof(int)))) return bail(rc);
+                    std::vector<uint32_t> wnd(nwin * groups.size());
+                    build_centre_windows(phi.data(), nwin, npe, groups.data(), (int)groups.size(), cfg->kernwidth, wnd.data());
+                    if ((rc = upload(&p->d_cen_win, wnd.data(), wnd.size() * sizeof(uint32_t)))) return bail(rc);
+                }
                 std::vector<float> scs(2 * order.size());
                 for (size_t w = 0; w < nwin; ++w)
                     for (int k = 0; k < npe; ++k) {
@@ -225,7 +251,7 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
                 unsigned short *d_order = nullptr;
                 float *d_phi = nullptr, *d_scs = nullptr;
                 int *d_alloc = nullptr;
-                auto drop = [&]() { hipFree(d_order); hipFree(d_phi); hipFree(d_scs); hipFree(d_alloc); };
+                auto drop = [&]() { hipFree(d_alloc); hipFree(d_phi); p->d_cen_order = d_order; p->d_cen_cs = reinterpret_cast<float2 *>(d_scs); };   // the sorted lists stay: centre kernel
                 // a spoke crosses at most 2 * nxos / 32 + 3 tiles (+ their halos): 56 run entries per spoke bound every window
                 p->arc_cap = npe * (2 * (d.nxos / kBinnedTile) + 24);
                 p->arc_nrec = grid_arc_nrec(p->nchan, cfg->input_half);
@@ -256,6 +282,8 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
                     hipMemset(p->d_errflag, 0, sizeof(flag));
                     hipFree(p->d_arc_hdr); hipFree(p->d_arc_ent); hipFree(p->d_arc_ephi);
                     p->d_arc_hdr = nullptr; p->d_arc_ent = nullptr; p->d_arc_ephi = nullptr;
+                    hipFree(p->d_cen_order); hipFree(p->d_cen_cs);
+                    p->d_cen_order = nullptr; p->d_cen_cs = nullptr;
                     p->arc = false;
                     if (cfg->verbose) printf("tronhip: arc tables overflowed (flag %u): binned gridding kernel\n", flag);
                 }
@@ -266,6 +294,7 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
                 if (p->lut_entries <= 0) return bail(fail(TRON_ERR_UNSUPPORTED, "no Kaiser-Bessel pair table for width %g", (double)cfg->kernwidth));
                 if ((rc = upload(&p->d_kb_lut, lut.data(), lut.size() * sizeof(float)))) return bail(rc);
                 p->arc_zper = 0;                                    // 0: by launch size (tron_pipeline.cpp)
+                if (const char *e = tuning_env("TRON_CENTRE_KERNEL")) p->centre_kernel = strcmp(e, "binned") != 0;
                 // the inner tile's workgroups are few and slow (every spoke passes the k-space centre): on a stream of their own,
                 // most urgent, they run beside the arc kernel instead of in front of it
                 if (const char *e = tuning_env("TRON_ARC_INNER_STREAM")) p->inner_beside = atoi(e) != 0;
@@ -364,6 +393,8 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
         FftPlan *f = nullptr;       // synchronisation) in the middle of the first pipeline
         if ((rc = get_fft(p, (cfg->adjoint ? std::min(p->chunk, std::max(d.nz, 1)) : 1) * p->nchan, cfg->adjoint ? 1 : 0, &f))) return bail(rc);
     }
+    p->create_s[1] = t_runtime; p->create_s[2] = t_tables - t_runtime; p->create_s[3] = t_arc1 - t_arc0; p->create_s[4] = t_work - t_tables;
+    p->create_s[0] = since();
     if (cfg->verbose) {
         printf("tronhip: device %d, %s, nchan %d, grid %d^2 -> image %d^2, %d spokes/image, chunk %d, KB %s\n",
                cfg->device, cfg->adjoint ? "adjoint" : "forward", p->nchan, d.nxos, d.nx, d.npe1work, p->chunk,
@@ -413,6 +444,10 @@ extern "C" int tron_plan_destroy(tron_plan *p)
     hipFree(p->d_arc_ent);
     hipFree(p->d_arc_ephi);
     hipFree(p->d_kb_lut);
+    hipFree(p->d_cen_order);
+    hipFree(p->d_cen_win);
+    hipFree(p->d_cen_cs);
+    hipFree(p->d_cen_groups);
     hipFree(p->d_tile_order32_split);
     hipFree(p->d_split_slots);
     hipFree(p->d_partial);
@@ -449,7 +484,7 @@ extern "C" int tron_plan_destroy(tron_plan *p)
 extern "C" const char *tron_plan_grid_kernel_name(const tron_plan *p)
 {
     if (!p || !p->cfg.adjoint) return "";
-    if (p->arc) return "grid_arc_kernel (+ grid_binned_kernel on the inner tile, grid_reduce_parts_kernel)";
+    if (p->arc) return p->centre_kernel ? "grid_arc_kernel (+ grid_centre_kernel for |r| < inner_r0)" : "grid_arc_kernel (+ grid_binned_kernel on the inner tile, grid_reduce_parts_kernel)";
     if (p->binned) return p->relief_entries > 0 ? "grid_binned_kernel (+ grid_reduce_parts_kernel)" : "grid_binned_kernel";
     return "grid_tile_kernel";
 }

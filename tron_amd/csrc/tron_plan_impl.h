@@ -13,6 +13,8 @@
 #include <string.h>
 
 #include <map>
+#include <set>
+#include <tuple>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -91,6 +93,13 @@ struct tron_plan {
     uint4 *d_arc_ent = nullptr;
     float *d_arc_ephi = nullptr;
     float2 *d_kb_lut = nullptr;
+    // ... and the k-space centre's kernel (tron_grid_centre.hip): the sorted spoke lists, the block groups
+    unsigned short *d_cen_order = nullptr;
+    uint32_t *d_cen_win = nullptr;
+    float2 *d_cen_cs = nullptr;
+    int *d_cen_groups = nullptr;
+    int cen_ngroups = 0;
+    bool centre_kernel = true;            // TRON_CENTRE_KERNEL=binned (A/B): the inner tile on the binned kernel + grid_reduce_parts_kernel, as in round 3
     int arc_cap = 0, arc_nrec = 0, arc_zper = 1;
     float lut_scale = 0;
     int lut_entries = 0, lut_bias = 0;
@@ -135,6 +144,7 @@ struct tron_plan {
     int grid_lds_pad = 0;          // TRON_GRID_LDS_PAD (two-lane experiments): LDS request of the binned gridding kernel
     bool slices_per_pass = true;   // TRON_SLICES_PER_PASS=0 turns the linear-angle slice grouping off (A/B, tests)
     bool poison = false;           // TRON_POISON_GRID (tests): NaN-fill the work grid
+    double create_s[5] = {0, 0, 0, 0, 0};   // tron_plan_create_times
     int debug_skip = 0;            // environment knobs, read once at plan creation (never on the launch path)
     bool degrid_simple = false, degrid_tile_only = false, no_disc = false;
     const char *last_degrid_kernel = "";   // tron_plan_degrid_kernel_name

@@ -55,7 +55,7 @@ EXPORTS = [
     "tron_config_default", "tron_derive_dims", "tron_plan_create", "tron_plan_destroy",
     "tron_recon_radial2d", "tron_recon_radial2d_range", "tron_recon_radial2d_block", "tron_recon_radial2d_multi", "tron_nufft_adj_radial2d", "tron_cgnr_radial2d", "tron_nufft_radial2d",
     "tron_precompensate", "tron_gridradial2d", "tron_degridradial2d", "tron_plan_sync",
-    "tron_plan_timing", "tron_plan_timing_get", "tron_plan_timing_reset", "tron_plan_two_lanes", "tron_plan_grid_kernel_name", "tron_plan_degrid_kernel_name",
+    "tron_plan_timing", "tron_plan_timing_get", "tron_plan_timing_reset", "tron_plan_two_lanes", "tron_plan_grid_kernel_name", "tron_plan_degrid_kernel_name", "tron_plan_create_times",
     "tron_host_trig_table", "tron_host_band_table", "tron_host_deapod_table", "tron_host_numa_cpulist",
     "tron_device_count", "tron_device_malloc", "tron_device_free", "tron_memcpy_h2d", "tron_memcpy_d2h",
     "tron_last_error", "tron_version",
@@ -101,6 +101,7 @@ def load():
     sig("tron_degridradial2d", i, [p, p, p])
     sig("tron_plan_sync", i, [p])
     sig("tron_plan_two_lanes", i, [p, i, ctypes.POINTER(i)])
+    sig("tron_plan_create_times", i, [p, ctypes.POINTER(ctypes.c_double)])
     sig("tron_plan_grid_kernel_name", ctypes.c_char_p, [p])
     sig("tron_plan_degrid_kernel_name", ctypes.c_char_p, [p])
     sig("tron_host_numa_cpulist", i, [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(i), i])
@@ -167,6 +168,12 @@ class DeviceBuffer:
         b = cls(a.nbytes)
         check(load().tron_memcpy_h2d(b.ptr, a.ctypes.data_as(ctypes.c_void_p), a.nbytes))
         return b
+
+    def write(self, a: np.ndarray, offset_bytes: int = 0):
+        """Copies a host array into the buffer at a byte offset (a stream assembled block by block)."""
+        a = np.ascontiguousarray(a)
+        assert 0 <= offset_bytes and offset_bytes + a.nbytes <= self.nbytes
+        check(load().tron_memcpy_h2d(ctypes.c_void_p(self.ptr.value + int(offset_bytes)), a.ctypes.data_as(ctypes.c_void_p), a.nbytes))
 
     def to_numpy(self, dtype, count) -> np.ndarray:
         out = np.empty(count, dtype)
@@ -279,6 +286,12 @@ class Plan:
     def degrid_kernel_name(self) -> str:
         """Which degridding kernel the most recent forward launch of this plan ran ("" before the first)."""
         return load().tron_plan_degrid_kernel_name(self._h).decode()
+
+    def create_times(self) -> dict:
+        """Seconds tron_plan_create spent: total, HIP runtime + code objects, tables, of which the gridding kernels' run tables, work buffers."""
+        t = (ctypes.c_double * 5)()
+        check(load().tron_plan_create_times(self._h, t))
+        return dict(total=t[0], runtime=t[1], tables=t[2], run_tables=t[3], work_buffers=t[4])
 
     def two_lanes(self, enable=True) -> bool:
         """Serialise (False) or restore (True) the gridding || FFT overlap; returns whether the plan has a second lane."""
