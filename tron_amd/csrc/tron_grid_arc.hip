@@ -18,14 +18,19 @@
 //           tile centre so that it never wraps.  Segment = u in [ulo, ulo + len) with the spoke's direction flipped where
 //           needed so that u = |r| > 0 (the tiles of this kernel never hold r = 0: the k-space centre belongs to the inner
 //           tile of the binned kernel, GridParams::inner_r0).
+//   window  thread = 2x2 block of the tile (the gridding kernel's layout): its run of the list, the spokes within
+//           asin((W + 1/2)(|cos| + |sin|) / R) of the block's own direction, by binary search on the line angles;
 //   deal    the run is dealt round-robin into K batches ("combs": batch b = entries b, b + K, ...), K = the fewest batches
 //           whose records fit in half the LDS sample space.  A comb covers the whole tile evenly, so every thread has work
 //           in every batch; each entry gets its record offset inside its comb.
 // grid_arc_kernel, one workgroup = 4 waves = one 32x32 tile, each thread 2x2 points, CPB coils in registers; per slice:
-//   table   the tile's run (<= 512 entries of 20 bytes) is copied to LDS;
-//   window  each thread finds its own run [jlo, jhi] of the list by binary search on the line angles;
+//   table   the tile's run (<= 512 entries of 16 bytes) is copied to LDS; each thread reads its own run [jlo, jhi] of the list
+//           (found by arc_prep_kernel, once per plan, by binary search on the line angles: 1 KB per tile and slice);
 //   batch   the comb's samples are copied global -> LDS by global_load_lds_dwordx4 (one wave instruction per spoke
-//           segment and coil pair) into one of TWO buffers: batch b + 1 flies while batch b is gathered, one barrier each;
+//           segment and coil pair; everything but the lane's byte offset in scalar registers, the segments' table entries read 64
+//           at a time).  What a copy costs is the ISSUE of its instructions, 270-360 cycles each whatever they carry: record-major
+//           copies (16 samples x 4 coil pairs per instruction: a quarter of the cache lines per instruction, three instructions
+//           per segment instead of four) and an L2 prefetch of the next batch were built and measured in round 4: +-0;
 //   gather  thread: its comb members four at a time: clip each spoke against the 2x2 block + footprint (a packed descriptor:
 //           radii, first record, run entry), sort the four by chord length in registers (a wave runs the longest chord of
 //           its lanes: with every lane's longest first the k-th chords of a wave match far better), then per chord and radius:
@@ -49,11 +54,11 @@ constexpr float kPi = 3.14159265358979f;
 
 // one and two coils: five workgroups per CU (83 / 94 VGPRs) beat four with larger batches by 3-4 % / 1 % (same-box A/B)
 #ifndef TRON_ARC_NREC1
-#define TRON_ARC_NREC1 1520
+#define TRON_ARC_NREC1 1776
 #define TRON_ARC_WAVES1 5
 #endif
 #ifndef TRON_ARC_NREC2
-#define TRON_ARC_NREC2 760
+#define TRON_ARC_NREC2 888
 #define TRON_ARC_WAVES2 5
 #endif
 template <int CPB>
@@ -67,7 +72,7 @@ struct ArcCfg {
 #else
     // LDS is handed out in units of 1280 bytes on gfx950 (160 KiB / 128): WAVES workgroups per CU need ArcLds <= 42 / 32 / 25 units
     // for 3 / 4 / 5 (a first build of this table at 54 144 bytes ran TWO workgroups per CU, not three, and hid a 25 % saving)
-    static constexpr int NREC = CPB >= 8 ? 528 : (CPB >= 6 ? 704 : (CPB >= 4 ? 656 : (CPB >= 2 ? TRON_ARC_NREC2 : TRON_ARC_NREC1)));
+    static constexpr int NREC = CPB >= 8 ? 560 : (CPB >= 6 ? 744 : (CPB >= 4 ? 720 : (CPB >= 2 ? TRON_ARC_NREC2 : TRON_ARC_NREC1)));
 #endif
     static constexpr int WAVES = CPB >= 6 ? 3 : (CPB >= 4 ? 4 : (CPB >= 2 ? TRON_ARC_WAVES2 : TRON_ARC_WAVES1));
 #ifdef TRON_ARC_DOUBLE_BUFFER
@@ -91,7 +96,6 @@ struct ArcLds {
     unsigned s_a[kArcMaxSpokes];           // run entry: sample index of its first record | (records run downwards) << 31
     unsigned s_b[kArcMaxSpokes];           //            ulo | len << 10 | record offset inside its batch << 17
     float2 s_cs[kArcMaxSpokes];            //            (cos, sin) of the (flipped) direction
-    float phi[kArcMaxSpokes];              //            line angle, unwrapped
     float4 d[ArcCfg<CPB>::NBUF * ArcCfg<CPB>::NREC * CPB / 2];   // samples [buffer][coil pair][record] (one coil: [buffer][re | im][record] floats)
 };
 
@@ -126,8 +130,27 @@ typedef unsigned v4u __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(3))) v4f *lds_f4p;
 typedef const __attribute__((address_space(3))) v2f *lds_f2p;
 
+// A thread's 2x2 block of its tile (the layout both kernels below use) and the block's angular window: a spoke of direction phi
+// reaches the block's footprint only if its line passes within (W + 1/2)(|cos phi| + |sin phi|) of the block centre; phi is
+// within asin((W + 1/2) sqrt(2) / R) =: D0 of the block's own direction, and |cos| + |sin| changes by at most sqrt(2) D0 over
+// that range.  Line angles are unwrapped at `wrap`, the direction perpendicular to the tile centre.
+__device__ __forceinline__ void arc_block_window(int X0, int Y0, float W, float wrap, float &tlo, float &thi)
+{
+    const float Xc = (float)X0 + 0.5f, Yc = (float)Y0 + 0.5f;
+    float T = atan2f(Yc, Xc);
+    T -= floorf(T / kPi) * kPi;
+    if (T < wrap) T += kPi;
+    const float R = sqrtf(Xc * Xc + Yc * Yc);
+    const float sd0 = (W + 0.52f) * 1.41421356f / R;
+    const float wcs = fminf(1.41421356f, (fabsf(Xc) + fabsf(Yc)) / R + 1.5f * sd0);
+    const float sd = (W + 0.52f) * wcs / R;
+    const float D = sd < 0.999f ? asinf(sd) + 2e-3f : 4.0f;
+    tlo = T - D;
+    thi = T + D;
+}
+
 // ------------------------------------------------------------------------------------------------------------------------
-// Plan-time pass: the run of every (window, tile), dealt into combs.  grid = (tiles, windows), block = 256.
+// Plan-time pass: the run of every (window, tile), dealt into combs, and every thread's window of it.  grid = (tiles, windows), block = 256.
 struct ArcPrepLds {
     unsigned s_a[kArcMaxSpokes];
     unsigned s_b[kArcMaxSpokes];
@@ -344,11 +367,42 @@ arc_prep_kernel(const ArcPrepParams p)
     const int base = L.base;
     if (base < 0) return;
     uint4 *ent = p.ent + (size_t)w * p.cap + base;
-    float *ephi = p.ephi + (size_t)w * p.cap + base;
     for (int i = tid; i < ns; i += kArcThreads) {
         const float2 cs = L.s_cs[i];
         ent[i] = make_uint4(L.s_a[i], L.s_b[i], __float_as_uint(cs.x), __float_as_uint(cs.y));
-        ephi[i] = L.phi[i];
+    }
+    // ---- every thread's own run [jlo, jhi] of the list (thread = 2x2 block, as in grid_arc_kernel) ----
+    {
+        const int X0 = x0 + 2 * (lane & 15), Y0 = y0 + 8 * wave + 2 * (lane >> 4);
+        int bandlo = 1 << 20, bandhi = -1;                      // radial band of the block's points, src/tron.cu:498-502
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int X = X0 + (q & 1), Y = Y0 + (q >> 1);
+            if (X + h < n && Y + h < n) {
+                const uint32_t bnd = p.band[(size_t)(Y + h) * n + (X + h)];
+                const int lo = (int)(bnd & 0xffffu), hi = (int)(bnd >> 16);
+                if (lo <= hi) { bandlo = min(bandlo, lo); bandhi = max(bandhi, hi); }
+            }
+        }
+        const bool has_work = bandlo <= bandhi && bandhi >= (outer ? max(p.inner_r0, 1) : 1);
+        int jlo = 1, jhi = 0;
+        if (has_work && ns > 0) {
+            float tlo, thi;
+            arc_block_window(X0, Y0, p.W, wrap, tlo, thi);
+            int lo = 0, cnt = ns;
+            while (cnt > 0) {
+                const int step = cnt >> 1;
+                if (L.phi[lo + step] < tlo) { lo += step + 1; cnt -= step + 1; } else cnt = step;
+            }
+            jlo = lo;
+            lo = 0; cnt = ns;
+            while (cnt > 0) {
+                const int step = cnt >> 1;
+                if (!(thi < L.phi[lo + step])) { lo += step + 1; cnt -= step + 1; } else cnt = step;
+            }
+            jhi = lo - 1;
+        }
+        p.win[((size_t)w * p.ntiles + tile) * kArcThreads + tid] = (uint32_t)jlo | ((uint32_t)(jhi + 1) << 16);
     }
 }
 
@@ -423,30 +477,9 @@ grid_arc_kernel(const GridParams p)
         if (Rlo[q] <= Rhi[q] && Rhi[q] - bandlo < 31) bmask[q] = (0xffffffffu >> (31 - (Rhi[q] - Rlo[q]))) << (Rlo[q] - bandlo);
     }
     const int umin_tile = outer ? max(p.inner_r0, 1) : 1;
-    const bool has_work = bandlo <= bandhi && bandhi >= umin_tile;
     const float blo_f = (float)max(bandlo, umin_tile), bhi_f = (float)bandhi;
 
-    // line angles are unwrapped at the direction perpendicular to the tile centre, like the run's (arc_prep_kernel)
-    float wrap = atan2f((float)y0 + 15.5f, (float)x0 + 15.5f) + 0.5f * kPi;
-    wrap -= floorf(wrap / kPi) * kPi;
     const float X0f = (float)X0, X1f = (float)(X0 + 1), Y0f = (float)Y0, Y1f = (float)(Y0 + 1);
-    float tlo, thi;
-    {
-        const float Xc = X0f + 0.5f, Yc = Y0f + 0.5f;
-        float T = atan2f(Yc, Xc);
-        T -= floorf(T / kPi) * kPi;
-        if (T < wrap) T += kPi;
-        const float R = sqrtf(Xc * Xc + Yc * Yc);
-        // a spoke of direction phi reaches the block's footprint only if its line passes within (W + 1/2)(|cos phi| + |sin phi|)
-        // of the block centre; phi is within asin((W + 1/2) sqrt(2) / R) =: D0 of the block's own direction, and
-        // |cos| + |sin| changes by at most sqrt(2) D0 over that range
-        const float sd0 = (p.W + 0.52f) * 1.41421356f / R;
-        const float wcs = fminf(1.41421356f, (fabsf(Xc) + fabsf(Yc)) / R + 1.5f * sd0);
-        const float sd = (p.W + 0.52f) * wcs / R;
-        const float D = sd < 0.999f ? asinf(sd) + 2e-3f : 4.0f;
-        tlo = T - D;
-        thi = T + D;
-    }
     const v2f p0v = {X0f, Y0f}, lscale2 = {p.lut_scale, p.lut_scale};
     const float We = p.W + 1e-3f;
     const float xlo = X0f - We, xhi = X1f + We, ylo = Y0f - We, yhi = Y1f + We;
@@ -479,7 +512,8 @@ grid_arc_kernel(const GridParams p)
         const int4 hdr = p.arc_hdr[win * p.ntiles + tile];
         const int ns = hdr.x, K = hdr.y;
         const uint4 *ent = p.arc_ent + win * p.arc_cap + hdr.z;
-        const float *ephi = p.arc_ephi + win * p.arc_cap + hdr.z;
+        const uint32_t wj = p.arc_win[(win * p.ntiles + tile) * kArcThreads + tid];      // this thread's run of the list: arc_prep_kernel
+        const int jlo = (int)(wj & 0xffffu), jhi = (int)(wj >> 16) - 1;
         const unsigned char *in = reinterpret_cast<const unsigned char *>(p.nudata) + ((size_t)z * (size_t)p.in_slice_stride + c0) * (HALF ? 4 : 8);
 
         v2f acc[4][CPB];
@@ -495,7 +529,6 @@ grid_arc_kernel(const GridParams p)
             L.s_a[i] = e.x;
             L.s_b[i] = e.y;
             L.s_cs[i] = make_float2(__uint_as_float(e.z), __uint_as_float(e.w));
-            L.phi[i] = ephi[i];
         }
         APROF_MARK(0);                                          // tile setup, run table
         __syncthreads();
@@ -506,59 +539,95 @@ grid_arc_kernel(const GridParams p)
         auto issue = [&](const int b) {
             const int nmem = (ns - b + K - 1) / K;
             const unsigned buf = dbase + (unsigned)(b & (C::NBUF - 1)) * kBufBytes;
-            for (int m = wave_u; m < nmem; m += 4) {
-                const int i = b + K * m;
-                const unsigned a = (unsigned)__builtin_amdgcn_readfirstlane((int)L.s_a[i]);
-                const unsigned sb = (unsigned)__builtin_amdgcn_readfirstlane((int)L.s_b[i]);
-                const int len = (int)((sb >> 10) & 127u);
-                const unsigned dst = buf + (sb >> 17) * kRecStep;
-                const unsigned first = (a & 0x7fffffffu) * nchan8;                     // byte offset of the first record's coil 0
-                if (lane < len) {
-                    const unsigned voff = (a >> 31) ? first - lane_step : first + lane_step;
-                    if constexpr (CPB == 1) {
-                        lds_dma4_s(in, voff, dst);                                     // real parts, imaginary parts
-                        lds_dma4_s(in + 4, voff, dst + (unsigned)(C::NREC * 4));
-                    } else if constexpr (HALF) {
+            // the members' run entries 64 at a time, one per lane (ONE round trip to LDS instead of one per member: the copies
+            // used to be issued at the pace of those reads), then by v_readlane
+            for (int mb = 0; mb < nmem; mb += 64) {
+                unsigned va = 0u, vsb = 0u;
+                if (mb + lane < nmem) {
+                    va = L.s_a[b + K * (mb + lane)];
+                    vsb = L.s_b[b + K * (mb + lane)];
+                }
+                const int mend = min(nmem - mb, 64);
+                for (int m = wave_u; m < mend; m += 4) {
+                    const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)va, m);
+                    const unsigned sb = (unsigned)__builtin_amdgcn_readlane((int)vsb, m);
+                    const int len = (int)((sb >> 10) & 127u);
+                    const unsigned dst = buf + (sb >> 17) * kRecStep;
+                    const unsigned first = (a & 0x7fffffffu) * nchan8;                     // byte offset of the first record's coil 0
+                    if (lane < len) {
+                        const unsigned voff = (a >> 31) ? first - lane_step : first + lane_step;
+                        if constexpr (CPB == 1) {
+                            lds_dma4_s(in, voff, dst);                                     // real parts, imaginary parts
+                            lds_dma4_s(in + 4, voff, dst + (unsigned)(C::NREC * 4));
+                        } else if constexpr (HALF) {
 #pragma unroll
-                        for (int hq = 0; hq < CPB / 4; ++hq)                           // four coils per piece, parked in coil-pair planes CPB/4 ...
-                            if (4 * hq < ncb) lds_dma16_s(in + 16 * hq, voff, dst + (unsigned)((CPB / 4 + hq) * C::NREC * 16));
-                    } else {
+                            for (int hq = 0; hq < CPB / 4; ++hq)                           // four coils per piece, parked in coil-pair planes CPB/4 ...
+                                if (4 * hq < ncb) lds_dma16_s(in + 16 * hq, voff, dst + (unsigned)((CPB / 4 + hq) * C::NREC * 16));
+                        } else {
 #pragma unroll
-                        for (int c = 0; c < CPB / 2; ++c)
-                            if (2 * c < ncb) lds_dma16_s(in + 16 * c, voff, dst + (unsigned)(c * C::NREC * 16));
+                            for (int c = 0; c < CPB / 2; ++c)
+                                if (2 * c < ncb) lds_dma16_s(in + 16 * c, voff, dst + (unsigned)(c * C::NREC * 16));
+                        }
                     }
                 }
             }
         };
-#ifndef TRON_ARC_SKIP_DMA
-        if (ns > 0) issue(0);                                   // batch 0 flies under the window search
-#endif
-        APROF_MARK(2);                                          // DMA issue
-
-        // ---- this thread's run of the list (while batch 0 flies) ----
-        int jlo = 1, jhi = 0;
-        if (has_work && ns > 0) {
-            int lo = 0, cnt = ns;
-            while (cnt > 0) {
-                const int step = cnt >> 1;
-                if (L.phi[lo + step] < tlo) { lo += step + 1; cnt -= step + 1; } else cnt = step;
-            }
-            jlo = lo;
-            lo = 0; cnt = ns;
-            while (cnt > 0) {
-                const int step = cnt >> 1;
-                if (!(thi < L.phi[lo + step])) { lo += step + 1; cnt -= step + 1; } else cnt = step;
-            }
-            jhi = lo - 1;
-        }
-        APROF_MARK(3);                                          // window search
-
+        APROF_MARK(2);
+        APROF_MARK(3);
         const float rcpK = 1.0f / (float)K;
         for (int b = 0; b < K && ns > 0; ++b) {
-            if (C::NBUF == 1 && b > 0) {
-                lds_barrier();                                  // everyone has left the buffer
+            if (C::NBUF == 1) {
+                if (b > 0) lds_barrier();                       // everyone has left the buffer
                 issue(b);
+            } else if (b == 0) {
+                issue(0);
             }
+            APROF_MARK(2);                                      // DMA issue
+            // ---- this thread's members of the comb, and the first four of them clipped while the copy flies (the clip needs the
+            // run table only) ----
+            int mlo = 0, mhi = -1;
+            if (jhi >= jlo && jhi >= b) {
+                mlo = jlo <= b ? 0 : (int)(((float)(jlo - b + K - 1) + 0.5f) * rcpK);
+                mhi = (int)(((float)(jhi - b) + 0.5f) * rcpK);
+            }
+#ifdef TRON_ARC_SKIP_OUTER
+            mhi = -1;
+#endif
+            // member -> descriptor: radii << 28 | first record << 17 | run entry << 8 | first radius - bandlo (0: no visit)
+            auto clip = [&](const int m) -> unsigned {
+                unsigned dsc = 0u;
+                if (m <= mhi) {
+#ifdef TRON_ARC_PROFILE
+                    { const unsigned long long bm_ = __ballot(1); if (lane == __builtin_ctzll(bm_)) { APROF_COUNT(12, 1); APROF_COUNT(13, __popcll(bm_)); } }
+#endif
+                    const int i = b + K * m;
+                    const float2 cs = L.s_cs[i];
+                    const unsigned sb = L.s_b[i];
+                    const int s_ulo = (int)(sb & 1023u), s_len = (int)((sb >> 10) & 127u);
+                    // 1 / 0 = inf is fine here: the box edges are never 0 (W + 1e-3 is no integer), inf clips like a huge number
+                    const float ic = __builtin_amdgcn_rcpf(cs.x), is = __builtin_amdgcn_rcpf(cs.y);
+                    // the radii whose sample lies inside the block's footprint: x0 - W < u cos < x1 + W, likewise y  (src/tron.cu:514-516)
+                    const float xa = xlo * ic, xb = xhi * ic;
+                    const float ya = ylo * is, yb = yhi * is;
+                    const float lo = fmaxf(fmaxf(fminf(xa, xb), fminf(ya, yb)), fmaxf((float)s_ulo, blo_f));
+                    const float hi = fminf(fminf(fmaxf(xa, xb), fmaxf(ya, yb)), fminf((float)(s_ulo + s_len - 1), bhi_f));
+                    const int ua = (int)ceilf(lo), ub = (int)floorf(hi);
+                    if (ua <= ub)
+                        dsc = ((unsigned)(ub - ua + 1) << 28) | ((unsigned)((int)(sb >> 17) - s_ulo + ua) << 17) | ((unsigned)i << 8) | (unsigned)(ua - bandlo);
+                }
+                return dsc;
+            };
+            int m0 = mlo;
+            const bool any_member = __ballot(m0 <= mhi) != 0ull;
+            unsigned desc[4] = {0u, 0u, 0u, 0u};
+            if (any_member) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    asm volatile("" ::: "memory");              // one clip after the other: four at once spill accumulators
+                    desc[k] = clip(m0 + k);
+                }
+            }
+            APROF_MARK(6);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's pieces of batch b have landed
             APROF_MARK(4);                                      // DMA wait
             lds_barrier();                                      // ... everyone's have; everyone has left batch b - 1's buffer
@@ -593,48 +662,12 @@ grid_arc_kernel(const GridParams p)
             const unsigned buf = dbase + (unsigned)(b & (C::NBUF - 1)) * kBufBytes;
 
             // ---- gather ----
-            int mlo = 0, mhi = -1;
-            if (jhi >= jlo && jhi >= b) {
-                mlo = jlo <= b ? 0 : (int)(((float)(jlo - b + K - 1) + 0.5f) * rcpK);
-                mhi = (int)(((float)(jhi - b) + 0.5f) * rcpK);
-            }
-#ifdef TRON_ARC_SKIP_OUTER
-            mhi = -1;
-#endif
-            // Members four at a time: clip -> descriptor (radii << 28 | first record << 17 | run entry << 8 | first radius - bandlo),
-            // sort the four descending (the radii count leads), visit.  Simulated on the metric trajectory (tools/probe/
-            // arc_util_sim.py, which reproduces the kernel's wave-level counters): radius loop 36.0 k -> 30.4 k wave iterations
-            // per slice, lanes active 0.51 -> 0.60; a flat loop over a lane's visits would reach 0.69 but pays a member switch
-            // inside the hot loop (measured in round 3: slower).
+            // Members four at a time: clipped (above / at the bottom of this loop), sorted descending by their radii count, visited.
+            // Simulated on the metric trajectory (tools/probe/arc_util_sim.py, which reproduces the kernel's wave-level counters):
+            // radius loop 36.0 k -> 30.4 k wave iterations per slice, lanes active 0.51 -> 0.60; a flat loop over a lane's visits
+            // would reach 0.69 but pays a member switch inside the hot loop (measured in round 3: slower).
             // (bottom-tested: hipcc keeps two copies of the accumulators across a top-tested loop with a wave-uniform exit)
-            int m0 = mlo;
-            if (__ballot(m0 <= mhi) != 0ull) do {
-                unsigned desc[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    desc[k] = 0u;
-                    const int m = m0 + k;
-                    asm volatile("" ::: "memory");                                            // one clip after the other: four at once spill accumulators
-                    if (m <= mhi) {
-#ifdef TRON_ARC_PROFILE
-                        { const unsigned long long bm_ = __ballot(1); if (lane == __builtin_ctzll(bm_)) { APROF_COUNT(12, 1); APROF_COUNT(13, __popcll(bm_)); } }
-#endif
-                        const int i = b + K * m;
-                        const float2 cs = L.s_cs[i];
-                        const unsigned sb = L.s_b[i];
-                        const int s_ulo = (int)(sb & 1023u), s_len = (int)((sb >> 10) & 127u);
-                        // 1 / 0 = inf is fine here: the box edges are never 0 (W + 1e-3 is no integer), inf clips like a huge number
-                        const float ic = __builtin_amdgcn_rcpf(cs.x), is = __builtin_amdgcn_rcpf(cs.y);
-                        // the radii whose sample lies inside the block's footprint: x0 - W < u cos < x1 + W, likewise y  (src/tron.cu:514-516)
-                        const float xa = xlo * ic, xb = xhi * ic;
-                        const float ya = ylo * is, yb = yhi * is;
-                        const float lo = fmaxf(fmaxf(fminf(xa, xb), fminf(ya, yb)), fmaxf((float)s_ulo, blo_f));
-                        const float hi = fminf(fminf(fmaxf(xa, xb), fmaxf(ya, yb)), fminf((float)(s_ulo + s_len - 1), bhi_f));
-                        const int ua = (int)ceilf(lo), ub = (int)floorf(hi);
-                        if (ua <= ub)
-                            desc[k] = ((unsigned)(ub - ua + 1) << 28) | ((unsigned)((int)(sb >> 17) - s_ulo + ua) << 17) | ((unsigned)i << 8) | (unsigned)(ua - bandlo);
-                    }
-                }
+            if (any_member) do {
 #ifdef TRON_ARC_SKIP_INNER
                 acc[0][0].x += (float)(desc[0] + desc[1] + desc[2] + desc[3]); desc[0] = desc[1] = desc[2] = desc[3] = 0u;
 #endif
@@ -710,7 +743,13 @@ grid_arc_kernel(const GridParams p)
                     }
                 }
                 m0 += 4;
-            } while (__ballot(m0 <= mhi) != 0ull);
+                if (__ballot(m0 <= mhi) == 0ull) break;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    asm volatile("" ::: "memory");
+                    desc[k] = clip(m0 + k);
+                }
+            } while (true);
             APROF_MARK(6);                                      // gather
         }
 
@@ -785,7 +824,7 @@ bool grid_arc_supported(int nchan, int nxos, int nro, int npe, float W, int half
 hipError_t launch_grid_arc(const GridParams &p, int half_in, int first_plain, hipStream_t s)
 {
     const int gran = half_in ? 3 : (p.nchan == 1 ? 0 : 1);
-    if (p.out_p != 1 || p.inner_r0 <= 0 || !p.arc_hdr || !p.arc_ent || !p.arc_ephi || !p.kb_lut || p.lut_entries > kArcLutEntries || (p.coil0 & gran)
+    if (p.out_p != 1 || p.inner_r0 <= 0 || !p.arc_hdr || !p.arc_ent || !p.arc_win || !p.kb_lut || p.lut_entries > kArcLutEntries || (p.coil0 & gran)
         || !grid_arc_supported(p.nchan, p.nxos, p.nro, p.npe, p.W, half_in) || (reinterpret_cast<uintptr_t>(p.nudata) & 15) != 0)
         return hipErrorInvalidValue;
     const int nc = p.nchan - p.coil0;

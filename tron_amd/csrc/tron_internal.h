@@ -56,7 +56,7 @@ struct GridParams {
     // arc kernel (tron_grid_arc.hip): per (window, tile) the run of crossing spokes, dealt into batches at plan time
     const int4 *arc_hdr;               // [window][tile] -> run length, batches, first entry, records
     const uint4 *arc_ent;              // [window][arc_cap] -> first sample index | down << 31, ulo | len << 10 | offset << 17, cos, sin
-    const float *arc_ephi;             // [window][arc_cap] -> unwrapped line angle
+    const uint32_t *arc_win;           // [window][tile][256] -> per thread of the tile's workgroup its run of the tile's list: first entry | end << 16
     int arc_cap, arc_nrec;             // entries per window; records per batch the runs were dealt for
     int arc_slice_stride;              // windows between consecutive slices: 1 (golden angle) or 0 (every slice has the same angles)
     const float2 *kb_lut;              // [3][kArcLutEntries] Kaiser-Bessel pair table: position t = d lut_scale of the signed distance d from a block's
@@ -131,7 +131,8 @@ struct ArcPrepParams {
     const float2 *cs;                  // [window][npe] (cos, sin) of that spoke
     int4 *hdr;                         // out, see GridParams::arc_hdr
     uint4 *ent;
-    float *ephi;
+    uint32_t *win;                     // out, see GridParams::arc_win
+    const uint32_t *band;              // Rlo | Rhi << 16 per grid point (build_band_table)
     int *alloc;                        // [window] entries handed out so far (zeroed by the caller)
     unsigned int *errflag;
     int nxos, nro, npe, ntiles, inner_r0, nrec, cap;

@@ -281,7 +281,7 @@ int adjoint_run_raw(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, 
                     const size_t win0 = golden ? (size_t)(zfirst + z0 - p->share_z0) : 0;     // the run tables start at the plan's first slice
                     g.arc_hdr = p->d_arc_hdr + win0 * (size_t)(d.nxos / kBinnedTile) * (d.nxos / kBinnedTile);
                     g.arc_ent = p->d_arc_ent + win0 * p->arc_cap;
-                    g.arc_ephi = p->d_arc_ephi + win0 * p->arc_cap;
+                    g.arc_win = p->d_arc_win + win0 * (size_t)(d.nxos / kBinnedTile) * (d.nxos / kBinnedTile) * 256;
                     g.arc_cap = p->arc_cap;
                     g.arc_nrec = p->arc_nrec;
                     g.arc_slice_stride = golden ? 1 : 0;

@@ -261,7 +261,7 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
                 if (!rc && hipMalloc(reinterpret_cast<void **>(&d_alloc), nwin * sizeof(int)) != hipSuccess) rc = fail(TRON_ERR_NOMEM, "arc tables");
                 if (!rc && (hipMalloc(reinterpret_cast<void **>(&p->d_arc_hdr), nwin * nt32 * sizeof(int4)) != hipSuccess ||
                             hipMalloc(reinterpret_cast<void **>(&p->d_arc_ent), nwin * p->arc_cap * sizeof(uint4)) != hipSuccess ||
-                            hipMalloc(reinterpret_cast<void **>(&p->d_arc_ephi), nwin * p->arc_cap * sizeof(float)) != hipSuccess))
+                            hipMalloc(reinterpret_cast<void **>(&p->d_arc_win), nwin * nt32 * 256 * sizeof(uint32_t)) != hipSuccess))
                     rc = fail(TRON_ERR_NOMEM, "cannot allocate the arc kernel's run tables");
                 if (rc) { drop(); return bail(rc); }
                 unsigned int zero = 0;
@@ -269,7 +269,7 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
                 hipMemset(d_alloc, 0, nwin * sizeof(int));
                 ArcPrepParams ap;
                 ap.order = d_order; ap.phi = d_phi; ap.cs = reinterpret_cast<const float2 *>(d_scs);
-                ap.hdr = p->d_arc_hdr; ap.ent = p->d_arc_ent; ap.ephi = p->d_arc_ephi; ap.alloc = d_alloc; ap.errflag = p->d_errflag;
+                ap.hdr = p->d_arc_hdr; ap.ent = p->d_arc_ent; ap.win = p->d_arc_win; ap.band = p->d_band; ap.alloc = d_alloc; ap.errflag = p->d_errflag;
                 ap.nxos = d.nxos; ap.nro = d.nro; ap.npe = npe; ap.ntiles = nt32; ap.inner_r0 = p->relief_r0; ap.nrec = p->arc_nrec;
                 ap.cap = p->arc_cap; ap.W = cfg->kernwidth;
                 hipError_t he = launch_arc_prep(ap, (int)nwin, p->stream);
@@ -280,8 +280,8 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
                 if (he != hipSuccess) return bail(fail(TRON_ERR_HIP, "arc_prep_kernel failed: %s", hipGetErrorString(he)));
                 if (flag) {   // a trajectory the arc kernel's tables cannot hold: the binned kernel takes all tiles
                     hipMemset(p->d_errflag, 0, sizeof(flag));
-                    hipFree(p->d_arc_hdr); hipFree(p->d_arc_ent); hipFree(p->d_arc_ephi);
-                    p->d_arc_hdr = nullptr; p->d_arc_ent = nullptr; p->d_arc_ephi = nullptr;
+                    hipFree(p->d_arc_hdr); hipFree(p->d_arc_ent); hipFree(p->d_arc_win);
+                    p->d_arc_hdr = nullptr; p->d_arc_ent = nullptr; p->d_arc_win = nullptr;
                     hipFree(p->d_cen_order); hipFree(p->d_cen_cs);
                     p->d_cen_order = nullptr; p->d_cen_cs = nullptr;
                     p->arc = false;
@@ -442,7 +442,7 @@ extern "C" int tron_plan_destroy(tron_plan *p)
     hipFree(p->d_cg_partial); hipFree(p->d_cg_num); hipFree(p->d_cg_coef);
     hipFree(p->d_arc_hdr);
     hipFree(p->d_arc_ent);
-    hipFree(p->d_arc_ephi);
+    hipFree(p->d_arc_win);
     hipFree(p->d_kb_lut);
     hipFree(p->d_cen_order);
     hipFree(p->d_cen_win);

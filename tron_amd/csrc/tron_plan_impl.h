@@ -91,7 +91,7 @@ struct tron_plan {
     bool arc = false;
     int4 *d_arc_hdr = nullptr;
     uint4 *d_arc_ent = nullptr;
-    float *d_arc_ephi = nullptr;
+    uint32_t *d_arc_win = nullptr;
     float2 *d_kb_lut = nullptr;
     // ... and the k-space centre's kernel (tron_grid_centre.hip): the sorted spoke lists, the block groups
     unsigned short *d_cen_order = nullptr;
