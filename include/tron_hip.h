@@ -51,8 +51,10 @@ enum {
 enum {
     TRON_KB_EXACT = 0,  /* the reference's formula op for op (src/tron.cu:304-349): IEEE sqrt/div, double Horner, and the
                            reference's summation order: bit-identical interpolation, for audits; about 2.5x slower */
-    TRON_KB_FAST  = 1   /* default: fp32 polynomial in 1-(x/W)^2 fitted at plan creation (|rel err| < 2e-7), sums in
-                           cell order; reconstructions agree with TRON_KB_EXACT to ~1e-7 relative L2 (bar: 1e-5) */
+    TRON_KB_FAST  = 1   /* default: the window from a table of quadratic pieces with the reference's exact support (gridding:
+                           arc + centre kernels; build_kb_pair_lut) or from an fp32 polynomial in 1-(x/W)^2 (binned gridding,
+                           degridding), both fitted at plan creation (error < 5e-7 of the peak), and each kernel's own summation
+                           order; reconstructions agree with TRON_KB_EXACT to ~1e-7 relative L2 (bar: 1e-5), same bits every run */
 };
 
 /* The run-time configuration: the getopt-settable globals of src/tron.cu:58-87,

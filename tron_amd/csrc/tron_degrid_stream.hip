@@ -276,13 +276,11 @@ static hipError_t launch_degrid_stream_cw(const DegridParams &p, int kb_mode, hi
     const size_t lds = sizeof(DsLds<CW>);
     static_assert(sizeof(DsLds<CW>) <= 160 * 1024, "two tile buffers and the spoke lists must fit the CU's LDS");
     if (kb_mode == TRON_KB_EXACT) {
-        static hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(degrid_stream_kernel<CW, TR, TRON_KB_EXACT>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(DsLds<CW>));
+        const hipError_t once = allow_dynamic_lds(reinterpret_cast<const void *>(degrid_stream_kernel<CW, TR, TRON_KB_EXACT>), (int)sizeof(DsLds<CW>));
         if (once != hipSuccess) return once;
         hipLaunchKernelGGL((degrid_stream_kernel<CW, TR, TRON_KB_EXACT>), grid, dim3(kDsThreads), lds, s, p);
     } else {
-        static hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(degrid_stream_kernel<CW, TR, TRON_KB_FAST>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(DsLds<CW>));
+        const hipError_t once = allow_dynamic_lds(reinterpret_cast<const void *>(degrid_stream_kernel<CW, TR, TRON_KB_FAST>), (int)sizeof(DsLds<CW>));
         if (once != hipSuccess) return once;
         hipLaunchKernelGGL((degrid_stream_kernel<CW, TR, TRON_KB_FAST>), grid, dim3(kDsThreads), lds, s, p);
     }

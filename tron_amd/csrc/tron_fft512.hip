@@ -867,8 +867,7 @@ hipError_t launch_fft512_forward(const float2 *img, float2 *tmp, float2 *out, co
         if (!rows_plain && kFKeep % (rows * kFwdRowSteps) == 0) {
             const size_t lds = ((kFwdRowThreads / 64) * kXch + kF + 2 * (size_t)rows * kFKeep * nchan) * sizeof(float2)
                                + 2 * (size_t)rows * kFKeep * sizeof(float);             // <= 146 KiB
-            static hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(fft512_fwd_rows_dma_kernel),
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            const hipError_t once = allow_dynamic_lds(reinterpret_cast<const void *>(fft512_fwd_rows_dma_kernel), 160 * 1024);
             if (once != hipSuccess) return once;
             hipLaunchKernelGGL(fft512_fwd_rows_dma_kernel, dim3(kFKeep / (rows * kFwdRowSteps), nimg), dim3(kFwdRowThreads), lds, s, p, rows);
         } else {
@@ -884,8 +883,7 @@ hipError_t launch_fft512_forward(const float2 *img, float2 *tmp, float2 *out, co
     if (cols_plain) {
         hipLaunchKernelGGL(fft512_fwd_cols_kernel, dim3(kF / kLinesPerWg, nimg * nchan), dim3(256), 0, s, p);
     } else {
-        static hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(fft512_fwd_cols_dma_kernel),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwdColLds);
+        const hipError_t once = allow_dynamic_lds(reinterpret_cast<const void *>(fft512_fwd_cols_dma_kernel), (int)kFwdColLds);
         if (once != hipSuccess) return once;
         hipLaunchKernelGGL(fft512_fwd_cols_dma_kernel, dim3(kF / kLinesPerWg / kFwdColBlocks, nimg * nchan), dim3(kFwdColThreads), kFwdColLds, s, p);
     }

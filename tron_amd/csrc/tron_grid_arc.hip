@@ -803,8 +803,7 @@ static hipError_t launch_arc_cpb(const GridParams &p, int first_plain, hipStream
     dim3 grid((unsigned)((size_t)q.ntiles * ngroups), (unsigned)chunks);
     const size_t lds = sizeof(ArcLds<CPB>);
     if (lds > 64 * 1024) {
-        static hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(grid_arc_kernel<CPB, HALF>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ArcLds<CPB>));
+        const hipError_t once = allow_dynamic_lds(reinterpret_cast<const void *>(grid_arc_kernel<CPB, HALF>), (int)sizeof(ArcLds<CPB>));
         if (once != hipSuccess) return once;
     }
     hipLaunchKernelGGL((grid_arc_kernel<CPB, HALF>), grid, dim3(kArcThreads), lds, s, q);

@@ -743,19 +743,14 @@ static hipError_t launch_binned_cpb(const GridParams &p, int half_in, hipStream_
         && (reinterpret_cast<uintptr_t>(p.nudata) & 15) == 0)
         in_mode = kInLdsDma;
 #endif
-    if (lds > 64 * 1024) {   // above the default dynamic-LDS limit: raise it once per instantiation
-        static hipError_t once = [] {
-            hipError_t e = hipSuccess;
-            const void *fns[3] = {reinterpret_cast<const void *>(grid_binned_kernel<CPB, CW, kInRegs32>),
-                                  reinterpret_cast<const void *>(grid_binned_kernel<CPB, CW, kInRegs16>),
-                                  reinterpret_cast<const void *>(grid_binned_kernel<CPB, CW, (CPB % 2 == 0 ? kInLdsDma : kInRegs32)>)};
-            for (const void *f : fns) {
-                const hipError_t e1 = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BinLds<CPB, CW>));
-                if (e == hipSuccess) e = e1;
-            }
-            return e;
-        }();
-        if (once != hipSuccess) return once;
+    if (lds > 64 * 1024) {   // above the default dynamic-LDS limit: raise it once per instantiation and device
+        const void *fns[3] = {reinterpret_cast<const void *>(grid_binned_kernel<CPB, CW, kInRegs32>),
+                              reinterpret_cast<const void *>(grid_binned_kernel<CPB, CW, kInRegs16>),
+                              reinterpret_cast<const void *>(grid_binned_kernel<CPB, CW, (CPB % 2 == 0 ? kInLdsDma : kInRegs32)>)};
+        for (const void *f : fns) {
+            const hipError_t e1 = allow_dynamic_lds(f, (int)sizeof(BinLds<CPB, CW>));
+            if (e1 != hipSuccess) return e1;
+        }
     }
     if (in_mode == kInRegs16)
         hipLaunchKernelGGL((grid_binned_kernel<CPB, CW, kInRegs16>), grid, dim3(kBinThreads), lds, s, q);

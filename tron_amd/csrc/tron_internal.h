@@ -5,9 +5,29 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <mutex>
+#include <set>
+#include <utility>
+
 #include "tron_host.h"
 
 namespace tron {
+
+// More than 64 KiB of dynamic LDS is an opt-in per kernel AND per device (hipFuncAttributeMaxDynamicSharedMemorySize): set once for
+// each (kernel, device) pair -- a `static` once per process would leave the other devices of tron_recon_radial2d_multi without it.
+inline hipError_t allow_dynamic_lds(const void *fn, int bytes)
+{
+    static std::mutex mu;
+    static std::set<std::pair<const void *, int>> done;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count({fn, dev})) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done.insert({fn, dev});
+    return e;
+}
 
 constexpr int kTile = 16;          // Cartesian tile edge owned by one workgroup (gridding)
 constexpr int kGridThreads = 64;   // one wave per tile, each lane owns 2x2 points

@@ -14,6 +14,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 #include <time.h>
 #include <unistd.h>
 
@@ -140,6 +141,22 @@ int main(int argc, char *argv[])
     uint64_t hdr_dims[5];
     memcpy(hdr_dims, hdr.dims, sizeof(hdr_dims));
     ra_free(&hdr);
+    // the FILE must hold what its header promises before anything is allocated by that promise; and an output that IS the input
+    // (the reference's read-all-then-write order allows it, src/tron.cu:887-983) must not be truncated while it is still being read
+    bool same_file = false;
+    {
+        struct stat si, so;
+        if (stat(infile, &si) != 0) {
+            fprintf(stderr, "tron: cannot stat %s\n", infile);
+            return 1;
+        }
+        const uint64_t need = (6 + 5) * sizeof(uint64_t) + dims.in_elems * (cfg.input_half ? 4 : 8);
+        if ((uint64_t)si.st_size < need) {
+            fprintf(stderr, "tron: %s is %llu bytes long, its header needs %llu\n", infile, (unsigned long long)si.st_size, (unsigned long long)need);
+            return 1;
+        }
+        same_file = stat(outfile, &so) == 0 && so.st_dev == si.st_dev && so.st_ino == si.st_ino;
+    }
 
     struct timespec t0, t1, tp;
     clock_gettime(CLOCK_MONOTONIC, &t0);
@@ -229,7 +246,7 @@ int main(int argc, char *argv[])
     double write_s = 0.0;
     bool streamed = false;
     int wrc = 0;
-    if (rc == TRON_OK && !multi_gpu && cfg.adjoint && dims.nz > 1) {
+    if (rc == TRON_OK && !multi_gpu && cfg.adjoint && dims.nz > 1 && !same_file) {
         // ---- streamed: blocks of slices, each started when its spokes have been read, each written when it is done ----
         streamed = true;
         const uint64_t out_off = ra_data_offset(&out);
@@ -278,6 +295,7 @@ int main(int argc, char *argv[])
         tron_plan_destroy(plan);
         ra_free(&in);
         ra_free(&out);
+        if (streamed) unlink(outfile);            // a header without its images is no result
         return 1;
     }
     if (rc != TRON_OK) {

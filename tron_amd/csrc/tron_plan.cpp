@@ -156,7 +156,7 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
         std::vector<int> order;
         build_tile_order(d.nxos, kBinnedTile, order);
         if ((rc = upload(&p->d_tile_order32, order.data(), order.size() * sizeof(int)))) return bail(rc);
-        if (!cfg->adjoint) {
+        if (!cfg->adjoint || cfg->niter > 0) {      // CGNR (an adjoint plan) runs the forward operator too: its centre tiles need the short runs as well
             static const int target = tuning_env("TRON_DEGRID_RUN") ? atoi(tuning_env("TRON_DEGRID_RUN")) : 24000;   // tuning knob: samples per run
             build_degrid_groups(d.nxos, kBinnedTile, d.npe1work, d.nro, target, p->dg_group_end);
         }

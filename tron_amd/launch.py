@@ -41,13 +41,13 @@ def spawn_ranks(argv, world: int, timeout=DEFAULT_TIMEOUT_S, attempts=3):
     captured (not forwarded) so the caller can decide to print it only for a complete run.
     The rendezvous port is picked by binding and closing a socket, so another process can take it before rank 0 binds it:
     a run whose rank 0 dies with "address already in use" is started again on a fresh port (up to `attempts` times)."""
-    code, out = 1, ""
+    code, out, err0 = 1, "", ""
     for _ in range(max(1, attempts)):
         code, out, err0 = _spawn_once(argv, world, timeout)
         if code == 0 or not any(t in err0 for t in ("EADDRINUSE", "Address already in use", "address already in use")):
-            if err0:
-                sys.stderr.write(err0)
             break
+    if err0:                                     # the last attempt's rank-0 stderr, also when every attempt lost its port
+        sys.stderr.write(err0)
     return code, out
 
 
