@@ -208,7 +208,7 @@ def launch_ranks(args):
     return 0
 
 
-GRID_STAGE_KERNELS = ("grid_arc_kernel", "grid_binned_kernel", "grid_tile_kernel", "grid_reduce_parts_kernel")
+GRID_STAGE_KERNELS = ("grid_arc_kernel", "grid_centre_kernel", "grid_binned_kernel", "grid_tile_kernel", "grid_reduce_parts_kernel")
 
 
 def workload_key(args):
@@ -449,7 +449,7 @@ def main():
             "config": {"workload": f"adjoint gridding recon: {per_gpu} x {nc} coils, 512 readout x {NPE} {'golden' if golden else 'linear'}-angle spokes "
                                    f"-> 512^2 oversampled grid -> 256^2 image (tron -a {'-G ' if golden else ''}-u {undersamp:.4f} -d {NPE})",
                        "coils": nc, "slices_per_gpu": nz, "kb_mode": args.kb,
-                       "kb_mode_note": ("fast = tabulated (arc kernel) / polynomial (inner tile) Kaiser-Bessel weights + its own summation order: within 1e-5 of the reference arithmetic (measured on the "
+                       "kb_mode_note": ("fast = tabulated Kaiser-Bessel weights (arc and centre kernels: quadratic pieces, the reference's exact support) + their own summation order: within 1e-5 of the reference arithmetic (measured on the "
                                         "line: parity_rel_l2_vs_oracle), NOT bit-identical; --kb exact is the bit-identical gather, ~2.7x slower"
                                         if args.kb == "fast" else "exact = the reference's expression tree and summation order, bit-identical interpolation"),
                        "parallelism": f"slices sharded over {world} GPU(s), one process each, no collective on the data path (gloo barrier only)",

@@ -25,8 +25,10 @@ buf = (ctypes.c_ulonglong * 16)()
 with lib.Plan(cfg, dims) as plan:
     d_in = lib.DeviceBuffer.from_numpy(data)
     d_out = lib.DeviceBuffer(dims.out_bytes)
-    plan.adjoint_device(d_out.ptr, d_in.ptr, 0, nz, 1); plan.sync()
-    assert fn(buf, 16) == 0                                   # clears the warm-up launch
+    for _ in range(int(os.environ.get("WARM", "1"))):         # the clock settles after tens of milliseconds of load (tools/README.md)
+        plan.adjoint_device(d_out.ptr, d_in.ptr, 0, nz, 1)
+    plan.sync()
+    assert fn(buf, 16) == 0                                   # clears the warm-up launches
     plan.adjoint_device(d_out.ptr, d_in.ptr, 0, nz, 1); plan.sync()
     assert fn(buf, 16) == 0
 tot = float(sum(buf[:8]))

@@ -42,14 +42,16 @@ TRON_BENCH_SHARE_GPU=1 python bench.py $NI --gpus 2 --scaling strong --spokes 80
   TRON_DUAL_STREAM=0 rocprofv3 --kernel-trace --stats -d $out/stats_one_lane --output-format csv -- python3 $R/bench.py --cpu-slices 0 --no-irt --no-check > $out/stats_one_lane.log 2>&1
   rocprofv3 --kernel-trace --stats -d $out/stats_forward --output-format csv -- python3 $R/bench.py --cpu-slices 0 --no-irt --no-check --forward > $out/stats_forward.log 2>&1 )
 for k in stats stats_one_lane stats_forward; do cp $(find $out/$k -name "*kernel_stats.csv" | head -1) $out/${k}.csv; done
-bash tools/pmc.sh $tag/sq tools/gridbench.py 8 128 fast 3 > /dev/null 2>&1; cp gpurun_out/$tag/sq/summary.txt $out/sq_counters.txt
+WARM=20 bash tools/pmc.sh $tag/sq tools/gridbench.py 8 128 fast 3 > /dev/null 2>&1; cp gpurun_out/$tag/sq/summary.txt $out/sq_counters.txt
 if [ -f tron_amd/lib/libtronhip_aprof.so ]; then
   cp tron_amd/lib/libtronhip.so /tmp/orig.so; cp tron_amd/lib/libtronhip_aprof.so tron_amd/lib/libtronhip.so
-  python tools/arcprof.py 8 128 > $out/phase_clock.log 2>&1; cp /tmp/orig.so tron_amd/lib/libtronhip.so
+  WARM=20 python tools/arcprof.py 8 128 > $out/phase_clock.log 2>&1; cp /tmp/orig.so tron_amd/lib/libtronhip.so
 fi
 python tools/hostbench.py 8 256 > $out/hostbench.log 2>&1
 python tools/wholebody.py /tmp > $out/wholebody_cli.log 2>&1
 python tools/fwdbench.py 8 64 fast > $out/fwdbench.log 2>&1
 for n in 8 6 4 2 1; do python tools/gridbench.py $n 128 fast 5 2>&1 | tail -1; done > $out/gridbench.log
 TRON_GRID_KERNEL=binned python tools/gridbench.py 8 128 fast 5 2>&1 | tail -1 >> $out/gridbench.log
+TRON_DUAL_STREAM=0 bash tools/ktrace.sh $tag tools/gridbench.py 8 128 fast 3 > $out/ktrace_one_lane.log 2>&1
+WARM=20 python tools/gridbench.py 8 128 fast 20 2>&1 | tail -1 > $out/gridbench_warm.log
 rm -rf $out/stats $out/stats_one_lane $out/stats_forward $out/sq
