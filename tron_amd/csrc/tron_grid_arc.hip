@@ -505,14 +505,31 @@ grid_arc_kernel(const GridParams p)
     }
 
     APROF_DECL;
+    // The run table of a slice (<= 512 entries, two per thread) and this thread's window of it are asked for one slice ahead and
+    // wait in registers: they used to be loaded when the slice began (6 % of the wave cycles, all latency).
+    uint4 pf_ent[2] = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)};
+    uint32_t pf_wj = 1u << 16;                                  // jlo = 0, jhi = 0 - ... (overwritten below)
+    int4 hdr_next = make_int4(0, 1, 0, 0);
+    auto fetch_table = [&](const int z, const int4 h) {
+        const size_t win = (size_t)z * p.arc_slice_stride;
+        const uint4 *ent = p.arc_ent + win * p.arc_cap + h.z;
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            if (tid + k * kArcThreads < h.x) pf_ent[k] = ent[tid + k * kArcThreads];
+        pf_wj = p.arc_win[(win * p.ntiles + tile) * kArcThreads + tid];                 // this thread's run of the list: arc_prep_kernel
+    };
+    if (zg * zper < p.nslices) {
+        hdr_next = p.arc_hdr[(size_t)(zg * zper) * p.arc_slice_stride * p.ntiles + tile];
+        fetch_table(zg * zper, hdr_next);
+    }
     for (int iz = 0; iz < zper; ++iz) {
         const int z = zg * zper + iz;
         if (z >= p.nslices) break;
-        const size_t win = (size_t)z * p.arc_slice_stride;                              // 0 when every slice has the same angles
-        const int4 hdr = p.arc_hdr[win * p.ntiles + tile];
+        const int4 hdr = hdr_next;
         const int ns = hdr.x, K = hdr.y;
-        const uint4 *ent = p.arc_ent + win * p.arc_cap + hdr.z;
-        const uint32_t wj = p.arc_win[(win * p.ntiles + tile) * kArcThreads + tid];      // this thread's run of the list: arc_prep_kernel
+        const bool more = iz + 1 < zper && z + 1 < p.nslices;
+        if (more) hdr_next = p.arc_hdr[(size_t)(z + 1) * p.arc_slice_stride * p.ntiles + tile];   // (wave-uniform: a scalar load, back long before it is used)
+        const uint32_t wj = pf_wj;
         const int jlo = (int)(wj & 0xffffu), jhi = (int)(wj >> 16) - 1;
         const unsigned char *in = reinterpret_cast<const unsigned char *>(p.nudata) + ((size_t)z * (size_t)p.in_slice_stride + c0) * (HALF ? 4 : 8);
 
@@ -524,11 +541,15 @@ grid_arc_kernel(const GridParams p)
 
         __syncthreads();                                        // the last slice's gather has ended: run table and buffers are free
         // ---- the tile's run -> LDS ----
-        for (int i = tid; i < ns; i += kArcThreads) {
-            const uint4 e = ent[i];
-            L.s_a[i] = e.x;
-            L.s_b[i] = e.y;
-            L.s_cs[i] = make_float2(__uint_as_float(e.z), __uint_as_float(e.w));
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = tid + k * kArcThreads;
+            if (i < ns) {
+                const uint4 e = pf_ent[k];
+                L.s_a[i] = e.x;
+                L.s_b[i] = e.y;
+                L.s_cs[i] = make_float2(__uint_as_float(e.z), __uint_as_float(e.w));
+            }
         }
         APROF_MARK(0);                                          // tile setup, run table
         __syncthreads();
@@ -660,6 +681,8 @@ grid_arc_kernel(const GridParams p)
 #endif
             APROF_MARK(2);
             const unsigned buf = dbase + (unsigned)(b & (C::NBUF - 1)) * kBufBytes;
+
+            if (b == 0 && more) fetch_table(z + 1, hdr_next);   // the next slice's table and window: on their way while this slice is gathered
 
             // ---- gather ----
             // Members four at a time: clipped (above / at the bottom of this loop), sorted descending by their radii count, visited.
