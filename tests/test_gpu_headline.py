@@ -65,6 +65,29 @@ def test_config4_shape_804_spokes_8_coils(oracle, kb):
 
 
 @pytest.mark.timeout(900)
+def test_config4_eight_workers_on_one_gpu_give_the_single_plan_bytes(tmp_path):
+    """BASELINE config 4's decomposition without an 8-GPU node: 804 spokes x 8 coils, the slices sharded over EIGHT workers
+    (threads, one plan each, contiguous slice blocks, global angle index: src/tron.cu:582-597, 735-736) that all sit on GPU 0,
+    through `tron -g 0,0,0,0,0,0,0,0` and through tron_recon_radial2d_multi: the bytes of one plan."""
+    from tron_amd import ra
+    nz = 24
+    data = synth.kspace(8, NRO, 804 * nz, seed=synth.SEED_BASE + 26)
+    flags = dict(golden_angle=1, data_undersamp=1.5704, prof_slide=804)
+    one, dims = lib.recon(data, adjoint=True, **flags)
+    assert (dims.nz, dims.npe1work) == (nz, 804)
+    multi, _ = lib.recon_multi(data, adjoint=True, devices=[0] * 8, **flags)
+    assert np.array_equal(one, multi)
+    src, a, b = (str(tmp_path / n) for n in ("in.ra", "a.ra", "b.ra"))
+    ra.write(src, data)
+    tron = os.path.join(ROOT, "tron_amd", "bin", "tron")
+    args = ["-a", "-G", "-u", "1.5704", "-d", "804", src]
+    assert subprocess.run([tron] + args + [a], timeout=300).returncode == 0
+    assert subprocess.run([tron, "-g", "0,0,0,0,0,0,0,0"] + args + [b], timeout=300).returncode == 0
+    assert open(a, "rb").read() == open(b, "rb").read()
+    assert np.array_equal(ra.read(a), one)
+
+
+@pytest.mark.timeout(900)
 def test_config5_complex_half_at_512_grid_8_coils(oracle):
     nz = 16
     data = synth.kspace(8, NRO, 402 * nz, seed=synth.SEED_BASE + 23)
