@@ -244,8 +244,42 @@ def traffic_capture(key, kernel_prefixes, units_per_launch_now):
     return None, True, "kernel not in capture"
 
 
+_BURN_IN = r"""
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import synth
+from tron_amd import lib
+if lib.device_count() < 1:
+    sys.exit(0)
+for data, adjoint, fl in ((synth.kspace(2, 64, 60, seed=1), True, dict(golden_angle=1, data_undersamp=0.5, prof_slide=14)),
+                          (synth.kspace(8, 512, 402 * 2, seed=2), True, dict(golden_angle=1, data_undersamp=0.7852, prof_slide=402)),
+                          (synth.image(2, 256, seed=4), False, dict(golden_angle=1, data_undersamp=0.125))):
+    a, _ = lib.recon(data, adjoint=adjoint, **fl)
+    b, _ = lib.recon(data, adjoint=adjoint, **fl)
+    assert np.isfinite(a).all() and np.array_equal(a, b)
+"""
+
+
+def burn_in():
+    """The first GPU process on a freshly leased box is not like the later ones (tests/conftest.py): a child process
+    runs each pipeline family twice first, so that a cold-start fault costs a retry there and not the measurement.  Untimed."""
+    import subprocess
+    for attempt in range(3):
+        try:
+            r = subprocess.run([sys.executable, "-c", _BURN_IN % (ROOT, os.path.join(ROOT, "tests"))], capture_output=True, text=True, timeout=300)
+        except subprocess.TimeoutExpired:
+            continue
+        if r.returncode == 0:
+            return
+        sys.stderr.write(f"bench.py: burn-in attempt {attempt + 1} failed (rc {r.returncode}): {r.stderr[-300:]}\n")
+
+
 def main():
     args = parse_args()
+    if "WORLD_SIZE" not in os.environ or os.environ.get("RANK", "0") == "0":
+        if os.environ.get("TRON_BENCH_NO_BURN_IN") != "1" and "TRON_BENCH_BURNT" not in os.environ:
+            burn_in()                            # before this process (or the ranks it spawns) touches the GPU
+            os.environ["TRON_BENCH_BURNT"] = "1"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
 

@@ -24,6 +24,49 @@ def rel_l2(a, b):
     return float(np.linalg.norm(a - b) / (nb if nb > 0 else 1.0))
 
 
+_BURN_IN = r"""
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import synth
+from tron_amd import lib
+if lib.device_count() < 1:
+    sys.exit(0)
+def twice(data, adjoint, **fl):
+    a, _ = lib.recon(data, adjoint=adjoint, **fl)
+    b, _ = lib.recon(data, adjoint=adjoint, **fl)
+    assert np.isfinite(a).all() and np.array_equal(a, b)
+twice(synth.kspace(2, 64, 60, seed=1), True, golden_angle=1, data_undersamp=0.5, prof_slide=14)      # rocFFT size
+twice(synth.kspace(8, 512, 402 * 2, seed=2), True, golden_angle=1, data_undersamp=0.7852, prof_slide=402)   # fused 512 -> 256 path, arc + centre kernels
+twice(synth.kspace(2, 256, 90 * 3, seed=3), True, golden_angle=1, data_undersamp=0.3516, prof_slide=90)
+twice(synth.image(2, 256, seed=4), False, golden_angle=1, data_undersamp=0.125)
+twice(synth.image(1, 32, seed=5), False)
+"""
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _first_process_on_a_fresh_box(request):
+    """The first GPU process on a freshly leased box is not like the others: in round 4 four of ten such pytest runs failed
+    somewhere (a wrong image in a rocFFT size, an abort 55 tests in, a failure in the first two seconds) where none of ~30 later
+    processes on the same boxes did.  The library's share of that is closed (first rocFFT transform of a size on
+    the null stream, a warm launch per translation unit); what is left is the box.  Before the first GPU test a CHILD process
+    therefore runs every pipeline family twice and compares the bytes -- a child, so that a fault there cannot take the
+    test session with it -- up to three times.  CPU-only sessions (-m "not gpu") skip this."""
+    if not any(item.get_closest_marker("gpu") for item in request.session.items):
+        return
+    import subprocess
+    root, here = ROOT, os.path.dirname(os.path.abspath(__file__))
+    for attempt in range(3):
+        try:
+            r = subprocess.run([sys.executable, "-c", _BURN_IN % (root, here)], capture_output=True, text=True, timeout=300,
+                               env=dict(os.environ, TRON_TUNING="1"))
+        except subprocess.TimeoutExpired:
+            continue
+        if r.returncode == 0:
+            return
+        sys.stderr.write(f"[conftest] burn-in attempt {attempt + 1} failed (rc {r.returncode}): {r.stderr[-400:]}\n")
+    # three failures in a row are no cold start: let the tests report what is wrong
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import pyoracle
