@@ -119,6 +119,7 @@ for ty in range(16):
         cnt, inwin, K = r["cnt"], r["inwin"], r["K"]
         tot["tiles"] += 1; tot["K"] += K
         tot["visits"] += cnt.sum()
+        per_wave = np.zeros((4, K))
         for w in range(4):
             lanes = wv == w
             cw, iw = cnt[lanes], inwin[lanes]
@@ -143,10 +144,16 @@ for ty in range(16):
                         mx = ch.max(0)
                         tot[f"s{mm}_it"] = tot.get(f"s{mm}_it", 0) + mx.sum()
                         tot[f"s{mm}_mem"] = tot.get(f"s{mm}_mem", 0) + (mx > 0).sum()
+                        if mm == 4:
+                            per_wave[w, b] += mx.sum()
+        tot["wg_sum"] = tot.get("wg_sum", 0) + per_wave.sum()
+        tot["wg_max"] = tot.get("wg_max", 0) + 4 * per_wave.max(0).sum()
 v = tot["visits"]
 print(f"NREC {NREC} shape {SHAPE} npe {npe}: tiles {tot['tiles']}, batches {tot['K']}, visits {v}")
 print(f"  member loop  {tot['mem_it']} wave iterations, lanes active {tot['mem_act'] / (64 * tot['mem_it']):.3f}")
 for k, name in (("rad_it", "base"), ("sorted_it", "sorted"), ("flat_it", "flat"), ("whole_it", "whole")):
     print(f"  radius loop {name:7s} {tot[k]:7d} wave iterations, lanes active {v / (64 * tot[k]):.3f}")
+print(f"  waves of a workgroup meet at a barrier after every batch: sum of their iterations {tot['wg_sum']:.0f}, 4 x the slowest wave's {tot['wg_max']:.0f} "
+      f"-> {tot['wg_sum'] / tot['wg_max']:.3f} of the workgroup's gather time is work")
 for mm in (3, 4, 6):
     print(f"  sorted in chunks of {mm}: {tot[f's{mm}_it']:7d} wave iterations, lanes active {v / (64 * tot[f's{mm}_it']):.3f}; member visits {tot[f's{mm}_mem']}")

@@ -22,6 +22,8 @@ t nc8_npe804_nz256 --spokes 804
 t nc8_npe804_nz32 --spokes 804 --slices 32
 t nc8_npe402_nz32 --slices 32
 t forward_nc8 --forward
+t nc1_npe402_nz256_linear --linear --coils 1
+t nc8_npe402_nz256_exact --kb exact
 b default
 NI="--cpu-slices 0 --no-irt"
 b nc6 $NI --coils 6
