@@ -54,6 +54,9 @@ CASES = [
     (2, 256, 120, 2, dict(golden_angle=1, kernwidth=3.0)),          # W = 3
     (4, 256, 90, 2, dict(golden_angle=1, kernwidth=2.5)),           # fractional W
     (8, 1024, 60, 1, dict(golden_angle=1)),                       # 1024^2 grid, few spokes
+    (12, 256, 100, 2, dict(golden_angle=1)),                      # two coil chunks (6 + 6; centre kernel 8 + 4)
+    (10, 256, 80, 2, dict(golden_angle=1)),                       # a partial last chunk (6 + 4; centre kernel 8 + 2)
+    (16, 256, 60, 1, dict(golden_angle=0)),                       # 8 + 8, linear angles
 ]
 
 

@@ -106,6 +106,12 @@ def wave_of(shape, bx, by, x0, y0):
         return bx // 4
     if shape == "8x8":
         return (by // 8) * 2 + bx // 8
+    if shape == "rows4":                      # wave w owns the block rows w, w + 4, w + 8, w + 12 (interleaved strips)
+        return by % 4
+    if shape == "cols4":
+        return bx % 4
+    if shape == "checker":                    # 2x2 super-blocks dealt round the four waves
+        return (by % 2) * 2 + bx % 2
     raise ValueError(shape)
 
 

@@ -74,7 +74,11 @@ struct ArcCfg {
     // for 3 / 4 / 5 (a first build of this table at 54 144 bytes ran TWO workgroups per CU, not three, and hid a 25 % saving)
     static constexpr int NREC = CPB >= 8 ? 560 : (CPB >= 6 ? 744 : (CPB >= 4 ? 720 : (CPB >= 2 ? TRON_ARC_NREC2 : TRON_ARC_NREC1)));
 #endif
+#ifdef TRON_ARC_WAVES
+    static constexpr int WAVES = TRON_ARC_WAVES;               // (experiments: fewer, larger workgroups per CU beside an FFT workgroup)
+#else
     static constexpr int WAVES = CPB >= 6 ? 3 : (CPB >= 4 ? 4 : (CPB >= 2 ? TRON_ARC_WAVES2 : TRON_ARC_WAVES1));
+#endif
 #ifdef TRON_ARC_DOUBLE_BUFFER
     static constexpr int NBUF = 2;
 #else
