@@ -49,7 +49,7 @@ if [ -f tron_amd/lib/libtronhip_aprof.so ]; then
   cp tron_amd/lib/libtronhip.so /tmp/orig.so; cp tron_amd/lib/libtronhip_aprof.so tron_amd/lib/libtronhip.so
   WARM=20 python tools/arcprof.py 8 128 > $out/phase_clock.log 2>&1; cp /tmp/orig.so tron_amd/lib/libtronhip.so
 fi
-python tools/hostbench.py 8 256 > $out/hostbench.log 2>&1
+python tools/hostbench.py 8 256 > $out/hostbench.log 2>&1; python tools/hostbench.py 8 256 --half >> $out/hostbench.log 2>&1
 python tools/wholebody.py /tmp > $out/wholebody_cli.log 2>&1
 python tools/fwdbench.py 8 64 fast > $out/fwdbench.log 2>&1
 for n in 8 6 4 2 1; do python tools/gridbench.py $n 128 fast 5 2>&1 | tail -1; done > $out/gridbench.log
