@@ -28,9 +28,10 @@
 //           (found by arc_prep_kernel, once per plan, by binary search on the line angles: 1 KB per tile and slice);
 //   batch   the comb's samples are copied global -> LDS by global_load_lds_dwordx4 (one wave instruction per spoke
 //           segment and coil pair; everything but the lane's byte offset in scalar registers, the segments' table entries read 64
-//           at a time).  What a copy costs is the ISSUE of its instructions, 270-360 cycles each whatever they carry: record-major
-//           copies (16 samples x 4 coil pairs per instruction: a quarter of the cache lines per instruction, three instructions
-//           per segment instead of four) and an L2 prefetch of the next batch were built and measured in round 4: +-0;
+//           at a time).  The LDS-DMA path moves ~8 bytes per clock and CU (a batch of 34 KB: 4.3 k cycles, 16 % of the wave
+//           cycles) however the bytes are packed into instructions -- measured in round 4, all +-1 %: record-major copies (16
+//           samples x 4 coil pairs per instruction, a quad of lanes = one 64-byte line), an L2 prefetch of the next batch, and
+//           full-lane instructions over a per-record source table in LDS (36 instead of ~60 instructions per batch);
 //   gather  thread: its comb members four at a time: clip each spoke against the 2x2 block + footprint (a packed descriptor:
 //           radii, first record, run entry), sort the four by chord length in registers (a wave runs the longest chord of
 //           its lanes: with every lane's longest first the k-th chords of a wave match far better), then per chord and radius:
