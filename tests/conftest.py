@@ -46,11 +46,11 @@ twice(synth.image(1, 32, seed=5), False)
 @pytest.fixture(scope="session", autouse=True)
 def _first_process_on_a_fresh_box(request):
     """The first GPU process on a freshly leased box is not like the others: in round 4 four of ten such pytest runs failed
-    somewhere (a wrong image in a rocFFT size, an abort 55 tests in, a failure in the first two seconds) where none of ~30 later
-    processes on the same boxes did.  The library's share of that is closed (first rocFFT transform of a size on
-    the null stream, a warm launch per translation unit); what is left is the box.  Before the first GPU test a CHILD process
-    therefore runs every pipeline family twice and compares the bytes -- a child, so that a fault there cannot take the
-    test session with it -- up to three times.  CPU-only sessions (-m "not gpu") skip this."""
+    somewhere where none of ~30 later processes on the same boxes did.  The cause found was the library's (a
+    null-stream memset racing a kernel on a non-blocking stream, fixed; first rocFFT transform of a size on the null stream; a
+    warm launch per translation unit).  Belt and braces: before the first GPU test a CHILD process runs every pipeline family
+    twice and compares the bytes -- a child, so that a cold-start fault there cannot take the test session with it -- up to
+    three times.  CPU-only sessions (-m "not gpu") skip this."""
     if not any(item.get_closest_marker("gpu") for item in request.session.items):
         return
     import subprocess

@@ -148,7 +148,10 @@ int ensure_work(tron_plan *p, int units)
     p->work_units = 0;
     if (hipMalloc(reinterpret_cast<void **>(&p->d_grid), (size_t)units * per_unit) != hipSuccess)
         return fail(TRON_ERR_NOMEM, "cannot allocate %zu bytes of Cartesian work space", (size_t)units * per_unit);
-    if (p->poison) hipMemset(p->d_grid, 0xff, (size_t)units * per_unit);
+    if (p->poison) {                                            // (on the plan's stream: see the note at arc_prep_kernel's launch in tron_plan.cpp)
+        HIP_TRY(hipMemsetAsync(p->d_grid, 0xff, (size_t)units * per_unit, p->stream));
+        HIP_TRY(hipStreamSynchronize(p->stream));
+    }
     if (p->fft512 && hipMalloc(reinterpret_cast<void **>(&p->d_fft_tmp), (size_t)units * p->nchan * 256 * 512 * sizeof(float2)) != hipSuccess)
         return fail(TRON_ERR_NOMEM, "cannot allocate the FFT intermediate buffer");
     if (p->dual && hipMalloc(reinterpret_cast<void **>(&p->d_grid2), (size_t)units * per_unit) != hipSuccess)
@@ -587,7 +590,8 @@ int check_errflag(tron_plan *p)
     unsigned int flag = 0;
     HIP_TRY(hipMemcpy(&flag, p->d_errflag, sizeof(flag), hipMemcpyDeviceToHost));
     if (flag) {
-        HIP_TRY(hipMemset(p->d_errflag, 0, sizeof(flag)));
+        HIP_TRY(hipMemsetAsync(p->d_errflag, 0, sizeof(flag), p->stream));
+        HIP_TRY(hipStreamSynchronize(p->stream));
         return fail(TRON_ERR_HIP, "gridding kernel reported an internal overflow (flag %u)", flag);
     }
     return TRON_OK;

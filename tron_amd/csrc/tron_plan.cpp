@@ -266,7 +266,11 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
                 if (rc) { drop(); return bail(rc); }
                 unsigned int zero = 0;
                 if ((rc = upload(&p->d_errflag, &zero, sizeof(zero)))) { drop(); return bail(rc); }
-                hipMemset(d_alloc, 0, nwin * sizeof(int));
+                // ON THE PLAN'S STREAM: a memset of device memory on the null stream returns before it has run, and a non-blocking stream
+                // does not wait for it -- arc_prep_kernel then handed out run-table space from whatever the allocation held (round 3's
+                // `hipMemset`: tables that overlapped, or an overflow flag and a silent fall-back to the binned kernel; one first process
+                // in three on a fresh box, most runs with eight plans being created at once)
+                if (hipMemsetAsync(d_alloc, 0, nwin * sizeof(int), p->stream) != hipSuccess) { drop(); return bail(fail(TRON_ERR_HIP, "hipMemsetAsync failed")); }
                 ArcPrepParams ap;
                 ap.order = d_order; ap.phi = d_phi; ap.cs = reinterpret_cast<const float2 *>(d_scs);
                 ap.hdr = p->d_arc_hdr; ap.ent = p->d_arc_ent; ap.win = p->d_arc_win; ap.band = p->d_band; ap.alloc = d_alloc; ap.errflag = p->d_errflag;
@@ -279,7 +283,8 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
                 drop();
                 if (he != hipSuccess) return bail(fail(TRON_ERR_HIP, "arc_prep_kernel failed: %s", hipGetErrorString(he)));
                 if (flag) {   // a trajectory the arc kernel's tables cannot hold: the binned kernel takes all tiles
-                    hipMemset(p->d_errflag, 0, sizeof(flag));
+                    hipMemsetAsync(p->d_errflag, 0, sizeof(flag), p->stream);
+                    hipStreamSynchronize(p->stream);
                     hipFree(p->d_arc_hdr); hipFree(p->d_arc_ent); hipFree(p->d_arc_win);
                     p->d_arc_hdr = nullptr; p->d_arc_ent = nullptr; p->d_arc_win = nullptr;
                     hipFree(p->d_cen_order); hipFree(p->d_cen_cs);
