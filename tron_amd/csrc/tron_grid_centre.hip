@@ -7,27 +7,49 @@
 //
 // Near the origin every spoke passes every point: a 2x2 block there meets ~400 spokes where a block of the arc kernel meets 6, so
 // "thread = block" (arc kernel) starves and "sort the samples by cell" (binned kernel, which did this job until round 3 at 0.30
-// lanes active and 0.28 ms per 1 024 coil-slices for 5 % of the samples) spends its time sorting.  Here one WAVE owns one 2x2
-// block of one slice and its lanes share out the block's VISITS (sample, block):
+// lanes active and 0.28 ms per 1 024 coil-slices for 5 % of the samples) spends its time sorting.  Here one WAVE works on one 2x2
+// block of one slice at a time (an ITEM) and its lanes share out the block's VISITS (sample, block):
+//   items   the workgroups stay for the launch (as many as the chip holds) and every wave draws its items from a counter of its
+//           XCD; the next draw is asked for when an item starts and read when it ends;
 //   window  the block's run of the angle-sorted spoke list (the arc kernel's rule; worked out by the host at plan creation);
-//   chunk   64 spokes of the run, one per lane: clip against the block's footprint in SIGNED r (so no run ever "wraps"; |r| <
-//           inner_r0); an exclusive scan of the chord lengths numbers the chunk's visits, and every spoke writes its record and
-//           its lane number under each of its visits into the wave's LDS;
+//   chunk   64 spokes of the run, one per lane (the chunk after it already requested): clip against the block's footprint in SIGNED
+//           r (so no run ever "wraps"; |r| < inner_r0); an exclusive scan of the chord lengths (DPP) numbers the chunk's visits, and
+//           every spoke writes its record and its lane number under each of its visits into the wave's LDS;
 //   weights 64 visits at a time, one per lane: owner -> spoke record -> (kx, ky) -> the arc kernel's weights (pair table in LDS,
 //           band masks, density compensation, r = 0 doubled): the four point weights and the sample's address go to LDS;
 //   sums    the same 64 visits, LPV lanes per visit (one coil pair each, 16 bytes: the LPV lanes of a visit read ONE 64-byte
-//           line, 16 lines per wave instruction instead of 64 -- this work is bound by the texture addresser, not by arithmetic:
-//           a version with one lane per visit and all coils per lane spent 450 addresser cycles per 64 visits and ran at the
-//           binned kernel's 0.2-0.3 ms), all loads of the group in flight together, 8 packed FMAs per visit and lane;
-//   end     the lanes of a coil pair are summed by shuffles and the block is ADDED to what the arc kernel stored: this kernel
-//           runs behind it on the same stream.  No atomics, no partial tiles in HBM, the same sums in the same order every run.
+//           line, 16 lines per wave instruction instead of 64 -- a version with one lane per visit and all coils per lane spent 450
+//           addresser cycles per 64 visits and ran at the binned kernel's 0.2-0.3 ms), all loads of the group in flight together,
+//           8 packed FMAs per visit and lane;
+//   end     the lanes' partial blocks cross the lanes through the wave's LDS, one lane per value sums them in lane order and ADDS
+//           the sum to what the arc kernel stored: this kernel runs behind it on the same stream.  No floating-point atomics, no
+//           partial tiles in HBM, the same sums in the same order every run.
+// The work is a chain of latencies per wave (phase clock, tools/cenprof.py: ~2 000 clocks per chunk, ~2 500-3 000 per group of
+// 64 visits, 25 000-35 000 per item), so what counts is how many waves a CU holds and that none of them idles: everything
+// wave-uniform is kept in scalar registers (a wave index read from threadIdx is not, unless told).  Round 4, per 128 slices of 8
+// coils: one workgroup per four items 153 us (126 registers, 4 waves per SIMD); 84 registers, 5 waves 122; as above 117, and
+// 55 instead of 68 for 32 slices.
+#include <algorithm>
+
 #include "tron_device.h"
-#include "tron_grid_store.h"
+#include "tron_host.h"
 
 namespace tron {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
+#ifndef TRON_CEN_GOLD_EARLY
+#define TRON_CEN_GOLD_EARLY 0
+#endif
+#ifdef TRON_CEN_OCC
+#define TRON_CEN_OCC_ATTR __attribute__((amdgpu_waves_per_eu(TRON_CEN_OCC)))     // (measured for the 8-coil form, 98 registers: held to 96 for a fifth wave per SIMD, no faster)
+#else
+#define TRON_CEN_OCC_ATTR
+#endif
+#ifndef TRON_CEN_BATCH
+#define TRON_CEN_BATCH 1
+#endif
+constexpr unsigned kCenBatch = TRON_CEN_BATCH;                // items per draw from the XCD's counter
 constexpr int kCenWaves = 4;                                   // waves per workgroup, each on its own (block, slice)
 
 struct CenWaveLds {
@@ -43,86 +65,156 @@ struct CenLds {
 };
 
 // LPV lanes per visit, each with one coil pair (16 bytes of the sample; one coil: LPV = 1, 8 bytes): chunks of 2 LPV coils
+// Phase clock (-DTRON_CEN_PROFILE builds only, tools/cenprof.py): shader-clock cycles per wave and phase, summed over the launch
+#ifdef TRON_CEN_PROFILE
+constexpr int kCenProfCopies = 256;
+__device__ unsigned long long g_cen_prof[kCenProfCopies * 16];
+#define CPROF_DECL unsigned cprof[16] = {}; unsigned long long cprof_t = __builtin_readcyclecounter(); const unsigned long long cprof_0 = cprof_t, cprof_r0 = __builtin_amdgcn_s_memrealtime()
+#define CPROF_MARK(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_readcyclecounter(); cprof[i] += (unsigned)(t_ - cprof_t); cprof_t = t_; } while (0)
+#define CPROF_COUNT(i, v) do { cprof[i] += (unsigned)(v); } while (0)
+#define CPROF_FLUSH do { cprof[5] = (unsigned)(__builtin_readcyclecounter() - cprof_0); cprof[12] = 1; cprof[10] = (unsigned)(__builtin_amdgcn_s_memrealtime() - cprof_r0); if (lane == 0) for (int i_ = 0; i_ < 16; ++i_) if (cprof[i_]) atomicAdd(&g_cen_prof[((blockIdx.x * 4 + wave) % kCenProfCopies) * 16 + i_], (unsigned long long)cprof[i_]); } while (0)
+#else
+#define CPROF_DECL
+#define CPROF_MARK(i)
+#define CPROF_COUNT(i, v)
+#define CPROF_FLUSH
+#endif
+
+// inclusive prefix sum over the 64 lanes on the DPP path (row shifts, then the row broadcasts of gfx9): 6 VALU instructions where
+// __shfl_up is a round trip through the LDS crossbar each
+__device__ __forceinline__ int wave_incl_scan_add(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);     // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);     // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);     // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);     // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);     // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);     // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
 template <int LPV, bool ONE, bool HALF>
-__global__ void __launch_bounds__(64 * kCenWaves)
+__global__ void __launch_bounds__(64 * kCenWaves) TRON_CEN_OCC_ATTR
 grid_centre_kernel(const GridParams p)
 {
     static_assert(LPV == 1 || LPV == 2 || LPV == 4, "lanes per visit");
     static_assert(!ONE || LPV == 1, "one coil: one lane per visit");
     constexpr int NC = ONE ? 1 : 2;                             // coils per lane
     constexpr int VPS = 64 / LPV;                               // visits per sub-step
+    constexpr int NV = 8 * NC;                                  // sums per lane: 4 points x NC coils x (re, im)
+    static_assert(8 * (64 + LPV) * sizeof(float) <= sizeof(CenWaveLds), "the block's sums cross the lanes through the wave's list area");
     __shared__ CenLds lds;
+    CPROF_DECL;
     const int lane = threadIdx.x & 63;
-    CenWaveLds &L = lds.w[threadIdx.x >> 6];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (scalar: what follows from it -- block, slice, window -- stays out of the vector registers)
+    CenWaveLds &L = lds.w[wave];
     for (int i = threadIdx.x; i < 3 * kArcLutEntries; i += 64 * kCenWaves) lds.lut[i] = p.kb_lut[i];
-    __syncthreads();                                            // (the only barrier: every wave takes part before it may leave)
-    // work item -> (block, slice): slice z lives on XCD z % 8 (workgroups go round the 8 XCDs), and its blocks follow each other in
-    // time there, the block nearest the origin (most visits) first: the slice's samples are fetched into that XCD's L2 once
-    const int wg = blockIdx.x;
-    const int xcd = wg & 7;
-    const long long seq = (long long)(wg >> 3) * kCenWaves + (threadIdx.x >> 6);       // position in that XCD's sequence
-    const int z = (int)(seq / p.cen_ngroups) * 8 + xcd;
-    if (z >= p.nslices) return;                                 // (padding of the last workgroups)
-    const int gi = (int)(seq % p.cen_ngroups);
-    const int grp = p.cen_groups[gi];                               // block: (col | row << 8) of the origin-centred 32 x 32 square, nearest first
+    __syncthreads();                                            // (the only barrier: once per workgroup, which then stays for the launch)
+    // Work items (block, slice, coil chunk) are handed out per XCD through a ticket counter: slice z lives on XCD z % 8
+    // (workgroups go round the 8 XCDs).  Block-major, the block nearest the origin (most visits: 400 spokes against 50 at the rim)
+    // first, so that the launch ends on its cheapest items; the slices of a block run side by side, and neighbouring blocks, which
+    // share most of their samples, follow each other.  (Measured per 128 slices of 8 coils: slice-major 190 us; the 32 nearest
+    // blocks of every slice, then the rest, each pass slice-major, 132; block-major 117.  Draws of 2 / 4 / 8 items: 127 / 192 / 283.)
+    const int xcd = blockIdx.x & 7;
+    const int per_chunk = ONE ? 1 : 2 * LPV;
+    const unsigned chunks = (unsigned)((p.nchan - p.coil0 + per_chunk - 1) / per_chunk);
+    const unsigned ngroups = (unsigned)p.cen_ngroups;
+    const unsigned zc = xcd < p.nslices ? (unsigned)((p.nslices - xcd + 7) / 8) * chunks : 0u;     // (slice, chunk) pairs of this XCD
+    const unsigned magic_zc = p.cen_magic_zc[xcd < (p.nslices & 7) ? 0 : 1];
+    const unsigned nitems = zc * ngroups;
+    unsigned *const ticket = p.cen_ticket + 16 * xcd;
     const int cp = lane % LPV;                                  // this lane's coil pair of the chunk
-    const int c0 = p.coil0 + blockIdx.y * (2 * LPV) + 2 * cp;   // ... its first coil
-    const int ncl = ONE ? 1 : min(2, p.nchan - c0);             // coils this lane really has (<= 0: none)
     const int n = p.nxos, h = n / 2;
-    const int X0 = 2 * (grp & 255) - 16, Y0 = 2 * (grp >> 8) - 16;
-    const int rcap0 = p.inner_r0 - 1;
-
-    unsigned bmask[4];                                          // band per point as a mask over |r| (|r| <= 13 here), src/tron.cu:498-502
-    int bandhi = -1, bandlo = 1 << 20;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int X = X0 + (q & 1), Y = Y0 + (q >> 1);
-        const uint32_t bnd = p.band[(size_t)(Y + h) * n + (X + h)];
-        const int lo = (int)(bnd & 0xffffu), hi = min((int)(bnd >> 16), 31);
-        bmask[q] = 0u;
-        if (lo <= hi) {
-            bmask[q] = (0xffffffffu >> (31 - (hi - lo))) << lo;
-            bandhi = max(bandhi, hi);
-            bandlo = min(bandlo, lo);
-        }
-    }
-    const int rcap = min(rcap0, bandhi);
-    if (bandlo > rcap) return;                                  // no sample |r| < inner_r0 reaches this block (wave-uniform)
-
     const int npe = p.npe;
+    const v2f lscale2 = {p.lut_scale, p.lut_scale};
+    const float We = p.W + 1e-3f;
+    const float dcf_a = p.apply_dcf ? p.dcf_a : 0.0f, dcf_b = p.apply_dcf ? p.dcf_b : 1.0f;
+    const float2 *lut = lds.lut + p.lut_bias;                   // entry of table position 0
+    const unsigned nchan8 = (unsigned)p.nchan * (HALF ? 4u : 8u);
+    CPROF_MARK(0);                                              // table
+
+    // a wave's first item is its own number on the XCD, the tickets go on from there: no wave waits for the counter before it starts
+    const unsigned nwaves = (gridDim.x >> 3) * kCenWaves;
+    unsigned draw = (blockIdx.x >> 3) * kCenWaves + (unsigned)wave, sub = 0u;              // a draw = kCenBatch items in a row
+    unsigned item = draw * kCenBatch;
+    unsigned tk = 0u;
+    while (item < nitems) {
+    if (sub == 0u && lane == 0) tk = nwaves + atomicAdd(ticket, 1u);                     // the next draw: on its way while this one is worked on
+    const int gi = (int)(zc > 1 ? __umulhi(item, magic_zc) : item);               // item = block * (slices of this XCD * chunks) + slice * chunks + chunk; scalar arithmetic
+    const unsigned rest = item - (unsigned)gi * zc;
+    const unsigned zi = chunks > 1 ? __umulhi(rest, p.cen_magic_chunks) : rest;
+    const int z = (int)zi * 8 + xcd;
+    const int cbase = p.coil0 + (int)(rest - zi * chunks) * per_chunk;                     // the chunk's first coil (scalar); this lane's: + 2 * cp
+    const bool have = ONE || cbase + 2 * cp < p.nchan;          // this lane has a coil at all
+    // block record (build at plan creation from the band table, src/tron.cu:498-502): (col | row << 8) of the origin-centred
+    // 32 x 32 square, the largest |r| < inner_r0 that reaches it; the band of its four points as masks over |r|
+    const uint4 g0 = p.cen_grec[2 * gi], g1 = p.cen_grec[2 * gi + 1];
+    const int grp = (int)g0.x, rcap = (int)g0.y;
+    const unsigned bmask[4] = {g1.x, g1.y, g1.z, g1.w};
+    const int X0 = 2 * (grp & 255) - 16, Y0 = 2 * (grp >> 8) - 16;
+
+    // where this lane's share of the block lies in the grid (the first NV * LPV lanes end up with one sum each)
+    auto grid_point = [&]() -> float * {
+        if (lane >= NV * LPV) return nullptr;
+        const int k = lane / LPV, q = k / (2 * NC), cbit = ONE ? 0 : (k >> 1) & 1;
+        const int X = X0 + (q & 1), Y = Y0 + (q >> 1);
+        const int c0 = cbase + (ONE ? 0 : 2 * cp);
+        if (c0 + cbit >= p.nchan || X + h >= n || Y + h >= n) return nullptr;
+        const int row = p.out_shift ? (Y < 0 ? Y + n : Y) : Y + h;         // both fftshifts of src/tron.cu:631 folded in (store_point_pair)
+        const int col = p.out_shift ? (X < 0 ? X + n : X) : X + h;
+        return reinterpret_cast<float *>(p.udata + (size_t)z * p.out_z + ((size_t)row * n + col) * p.out_p + (size_t)(c0 + cbit) * p.out_c) + (k & 1);
+    };
+#if TRON_CEN_GOLD_EARLY
+    float *const gpt = grid_point();                            // what the arc kernel stored there: asked for now, added at the end
+    const float gold = gpt ? *gpt : 0.f;
+#endif
+
     const size_t win = (size_t)z * p.arc_slice_stride;
     const unsigned short *order = p.cen_order + win * npe;
     const float2 *scs = p.cen_cs + win * npe;
     const unsigned wnd = p.cen_win[win * p.cen_ngroups + gi];    // first spoke | spokes << 16 (build_centre_windows, at plan creation)
     const int jstart = (int)(wnd & 0xffffu), cnt = (int)(wnd >> 16);
 
-    const float X0f = (float)X0, Y0f = (float)Y0;
-    const v2f p0v = {X0f, Y0f}, lscale2 = {p.lut_scale, p.lut_scale};
-    const float We = p.W + 1e-3f;
-    const float xlo = X0f - We, xhi = X0f + 1.0f + We, ylo = Y0f - We, yhi = Y0f + 1.0f + We;
-    const float rcap_f = (float)rcap;
-    const float dcf_a = p.apply_dcf ? p.dcf_a : 0.0f, dcf_b = p.apply_dcf ? p.dcf_b : 1.0f;
-    const float2 *lut = lds.lut + p.lut_bias;                   // entry of table position 0
-    const unsigned nchan8 = (unsigned)p.nchan * (HALF ? 4u : 8u);
-    const unsigned char *in = reinterpret_cast<const unsigned char *>(p.nudata) + ((size_t)z * (size_t)p.in_slice_stride + c0) * (HALF ? 4 : 8);
+    // (wave-uniform floats: a conversion or an addition is a vector instruction whatever its operands, so its result is moved to a
+    // scalar register by hand; seven vector registers less over the item)
+    auto uni = [](float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); };
+    const float X0f = uni((float)X0), Y0f = uni((float)Y0);
+    const v2f p0v = {X0f, Y0f};
+    const float xlo = uni(X0f - We), xhi = uni(X0f + 1.0f + We), ylo = uni(Y0f - We), yhi = uni(Y0f + 1.0f + We);
+    const float rcap_f = uni((float)rcap);
+    const unsigned char *in = reinterpret_cast<const unsigned char *>(p.nudata) + (size_t)z * (size_t)p.in_slice_stride * (HALF ? 4 : 8);   // (scalar)
+    const unsigned coff = (unsigned)(cbase + (ONE ? 0 : 2 * cp)) * (HALF ? 4u : 8u);      // this lane's first coil within a sample
 
     v2f acc[4][NC];
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int c = 0; c < NC; ++c) acc[q][c] = (v2f){0.f, 0.f};
+    CPROF_MARK(11);                                             // item: ticket, block record, window
 
-    for (int t0 = 0; t0 < cnt; t0 += 64) {
-        // ---- this lane's spoke of the chunk: clip, number its visits ----
+    // The visits of the window are taken 64 at a time (a GROUP: one visit per lane for the weights, LPV lanes per visit for the sums).
+    // (Requesting a group's samples and summing the group before it meanwhile -- two register sets -- was measured: 135-175 us per 128
+    // slices against 123; it costs a wave per SIMD, and the waves are what hides this kernel's latencies.)
+    int t0 = -64, v0 = 0, total = 0;                            // chunk (64 spokes of the window), group, visits of the chunk
+    // ---- next chunk: this lane's spoke, clipped; its visits numbered ----
+    float2 cs_next = make_float2(1.f, 0.f);
+    unsigned pe_next = 0u;
+    auto fetch_spoke = [&](const int tc) {
+        if (tc + lane < cnt) {
+            int j = jstart + tc + lane;
+            if (j >= npe) j -= npe;
+            cs_next = scs[j];
+            pe_next = order[j];
+        }
+    };
+    fetch_spoke(0);
+    auto clip_chunk = [&]() {
         const int t = t0 + lane;
         int len = 0, ra = 0;
-        unsigned pe = 0u;
-        float2 cs = make_float2(1.f, 0.f);
+        const float2 cs = cs_next;
+        const unsigned pe = pe_next;
+        fetch_spoke(t0 + 64);                                                                 // the chunk after this one: in flight over this chunk's groups
         if (t < cnt) {
-            int j = jstart + t;
-            if (j >= npe) j -= npe;
-            cs = scs[j];
-            pe = order[j];
             const float ic = __builtin_amdgcn_rcpf(cs.x), is = __builtin_amdgcn_rcpf(cs.y);   // (1 / 0 = inf clips like a huge number; the box edges are never 0)
             const float xa = xlo * ic, xb = xhi * ic;
             const float ya = ylo * is, yb = yhi * is;
@@ -132,137 +224,186 @@ grid_centre_kernel(const GridParams p)
             const int rb = (int)floorf(hi);
             len = rb >= ra ? min(rb - ra + 1, 12) : 0;                                       // (never cuts: see CenWaveLds::owner)
         }
-        int incl = len;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int up = __shfl_up(incl, o);
-            if (lane >= o) incl += up;
-        }
+        const int incl = wave_incl_scan_add(len);
         const int excl = incl - len;
-        const int total = __builtin_amdgcn_readlane(incl, 63);
+        total = __builtin_amdgcn_readlane(incl, 63);
         L.rec[lane] = make_uint4(__float_as_uint(cs.x), __float_as_uint(cs.y), (unsigned)excl, ((unsigned)(ra + 32) << 16) | pe);
         for (int i = 0; i < len; ++i) L.owner[excl + i] = (unsigned char)lane;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (one wave: its own LDS writes are visible once they have completed)
-
-        for (int v0 = 0; v0 < total; v0 += 64) {
-            // ---- weights of visits v0 .. v0 + 63, one per lane ----
-            const int v = v0 + lane;
-            float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            unsigned off = 0u;
-            if (v < total) {
-                const uint4 rec = L.rec[L.owner[v]];
-                const int ri = (int)((rec.w >> 16) & 63u) - 32 + (v - (int)rec.z);
-                // sample of radius r on spoke pe: nudata[nchan * (nro * pe + r + nro / 2) + c]   src/tron.cu:517,519 (nro == nxos)
-                off = (unsigned)(p.nro * (int)(rec.w & 0xffffu) + p.nro / 2 + ri) * nchan8;
-                // (kx, ky) = r (cos, sin) and the distances to the block's first column / row, op for op src/tron.cu:514-516
-                const float rf = (float)ri;
-                const v2f kxy = (v2f){rf, rf} * (v2f){__uint_as_float(rec.x), __uint_as_float(rec.y)};
-                const v2f tp = (kxy - p0v) * lscale2;
-                const v2f tt = {__builtin_truncf(tp.x), __builtin_truncf(tp.y)};
-                const v2f fv = tp - tt;
-                const float2 *lx = lut + (int)tt.x, *ly = lut + (int)tt.y;
-                const float2 x0c = lx[0], x1c = lx[kArcLutEntries], x2c = lx[2 * kArcLutEntries];
-                const float2 y0c = ly[0], y1c = ly[kArcLutEntries], y2c = ly[2 * kArcLutEntries];
-                const int ar = ri < 0 ? -ri : ri;
-                // src/tron.cu:412 (|ro - nro/2| = |r|); r = 0 is visited by both loops of the reference where the band starts at 0
-                const float sdc = fmaf(dcf_a, fabsf(rf), dcf_b) * (ri == 0 ? 2.0f : 1.0f);
-                const v2f fxv = {fv.x, fv.x}, fyv = {fv.y, fv.y}, sdcv = {sdc, sdc};
-                const v2f wx = __builtin_elementwise_fma(fxv, __builtin_elementwise_fma(fxv, (v2f){x2c.x, x2c.y}, (v2f){x1c.x, x1c.y}), (v2f){x0c.x, x0c.y});
-                const v2f wy = __builtin_elementwise_fma(fyv, __builtin_elementwise_fma(fyv, (v2f){y2c.x, y2c.y}, (v2f){y1c.x, y1c.y}), (v2f){y0c.x, y0c.y}) * sdcv;
-                const v2f w01 = wx * (v2f){wy.x, wy.x}, w23 = wx * (v2f){wy.y, wy.y};    // src/tron.cu:516
-                float wq[4] = {w01.x, w01.y, w23.x, w23.y};
-#pragma unroll
-                for (int q = 0; q < 4; ++q)                                                // src/tron.cu:512,521: Rlo <= |r| <= Rhi
-                    wq[q] = __uint_as_float(__float_as_uint(wq[q]) & (unsigned)__builtin_amdgcn_sbfe((int)bmask[q], ar, 1));
-                w4 = make_float4(wq[0], wq[1], wq[2], wq[3]);
-            }
-            L.wq[lane] = w4;
-            L.off[lane] = off;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-
-            // ---- sums: LPV lanes per visit, every load of the group first ----
-            v4f dd[LPV];
-            float4 ww[LPV];
-#pragma unroll
-            for (int s = 0; s < LPV; ++s) {
-                const int vi = s * VPS + lane / LPV;
-                ww[s] = L.wq[vi];
-                const unsigned o = L.off[vi];
-                dd[s] = (v4f){0.f, 0.f, 0.f, 0.f};
-                if (ncl > 0 && v0 + vi < total) {
-                    if constexpr (ONE) {
-                        const float2 s0 = load_sample<HALF>(in + o, 0);
-                        dd[s] = (v4f){s0.x, s0.y, 0.f, 0.f};
-                    } else if constexpr (HALF) {
-                        const float2 s0 = load_sample<true>(in + o, 0), s1 = load_sample<true>(in + o, 1);
-                        dd[s] = (v4f){s0.x, s0.y, s1.x, s1.y};
-                    } else {
-                        dd[s] = *reinterpret_cast<const v4f *>(in + o);
-                    }
-                }
-            }
-#pragma unroll
-            for (int s = 0; s < LPV; ++s) {
-                const float wq[4] = {ww[s].x, ww[s].y, ww[s].z, ww[s].w};
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    acc[q][0].x = fmaf(dd[s].x, wq[q], acc[q][0].x);                      // src/tron.cu:519
-                    acc[q][0].y = fmaf(dd[s].y, wq[q], acc[q][0].y);
-                    if constexpr (!ONE) {
-                        acc[q][1].x = fmaf(dd[s].z, wq[q], acc[q][1].x);
-                        acc[q][1].y = fmaf(dd[s].w, wq[q], acc[q][1].y);
-                    }
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the group's weights have been read: the next group may overwrite them
+        CPROF_MARK(1); CPROF_COUNT(6, 1); CPROF_COUNT(9, total);
+    };
+    // the next group with visits in it (false: the window is done); wave-uniform
+    auto next_group = [&]() -> bool {
+        v0 += 64;
+        while (v0 >= total) {
+            t0 += 64;
+            if (t0 >= cnt) return false;
+            clip_chunk();
+            v0 = 0;
         }
+        return true;
+    };
+    // ---- weights of visits v0 .. v0 + 63, one per lane; then, LPV lanes per visit, the samples are requested ----
+    auto issue = [&](v4f (&dd)[LPV]) {
+        const int v = v0 + lane;
+        float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        unsigned off = 0u;
+        if (v < total) {
+            const uint4 rec = L.rec[L.owner[v]];
+            const int ri = (int)((rec.w >> 16) & 63u) - 32 + (v - (int)rec.z);
+            // sample of radius r on spoke pe: nudata[nchan * (nro * pe + r + nro / 2) + c]   src/tron.cu:517,519 (nro == nxos)
+            off = (unsigned)(p.nro * (int)(rec.w & 0xffffu) + p.nro / 2 + ri) * nchan8;
+            // (kx, ky) = r (cos, sin) and the distances to the block's first column / row, op for op src/tron.cu:514-516
+            const float rf = (float)ri;
+            const v2f kxy = (v2f){rf, rf} * (v2f){__uint_as_float(rec.x), __uint_as_float(rec.y)};
+            const v2f tp = (kxy - p0v) * lscale2;
+            const v2f tt = {__builtin_truncf(tp.x), __builtin_truncf(tp.y)};
+            const v2f fv = tp - tt;
+            const float2 *lx = lut + (int)tt.x, *ly = lut + (int)tt.y;
+            const float2 x0c = lx[0], x1c = lx[kArcLutEntries], x2c = lx[2 * kArcLutEntries];
+            const float2 y0c = ly[0], y1c = ly[kArcLutEntries], y2c = ly[2 * kArcLutEntries];
+            const int ar = ri < 0 ? -ri : ri;
+            // src/tron.cu:412 (|ro - nro/2| = |r|); r = 0 is visited by both loops of the reference where the band starts at 0
+            const float sdc = fmaf(dcf_a, fabsf(rf), dcf_b) * (ri == 0 ? 2.0f : 1.0f);
+            const v2f fxv = {fv.x, fv.x}, fyv = {fv.y, fv.y}, sdcv = {sdc, sdc};
+            const v2f wx = __builtin_elementwise_fma(fxv, __builtin_elementwise_fma(fxv, (v2f){x2c.x, x2c.y}, (v2f){x1c.x, x1c.y}), (v2f){x0c.x, x0c.y});
+            const v2f wy = __builtin_elementwise_fma(fyv, __builtin_elementwise_fma(fyv, (v2f){y2c.x, y2c.y}, (v2f){y1c.x, y1c.y}), (v2f){y0c.x, y0c.y}) * sdcv;
+            const v2f w01 = wx * (v2f){wy.x, wy.x}, w23 = wx * (v2f){wy.y, wy.y};    // src/tron.cu:516
+            float wq[4] = {w01.x, w01.y, w23.x, w23.y};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)                                                // src/tron.cu:512,521: Rlo <= |r| <= Rhi
+                wq[q] = __uint_as_float(__float_as_uint(wq[q]) & (unsigned)__builtin_amdgcn_sbfe((int)bmask[q], ar, 1));
+            w4 = make_float4(wq[0], wq[1], wq[2], wq[3]);
+        }
+        L.wq[lane] = w4;
+        L.off[lane] = off;
+        asm volatile("" ::: "memory");                          // (a wave's LDS operations complete in the order they were issued)
+        unsigned o[LPV];
+#pragma unroll
+        for (int s = 0; s < LPV; ++s) o[s] = L.off[s * VPS + lane / LPV] + coff;
+#pragma unroll
+        for (int s = 0; s < LPV; ++s) {
+            const int vi = s * VPS + lane / LPV;
+            dd[s] = (v4f){0.f, 0.f, 0.f, 0.f};
+            if (have && v0 + vi < total) {
+                if constexpr (ONE) {
+                    const float2 s0 = load_sample<HALF>(in + o[s], 0);
+                    dd[s] = (v4f){s0.x, s0.y, 0.f, 0.f};
+                } else if constexpr (HALF) {
+                    const float2 s0 = load_sample<true>(in + o[s], 0), s1 = load_sample<true>(in + o[s], 1);
+                    dd[s] = (v4f){s0.x, s0.y, s1.x, s1.y};
+                } else {
+                    dd[s] = *reinterpret_cast<const v4f *>(in + o[s]);
+                }
+            }
+        }
+        asm volatile("" ::: "memory");
+        CPROF_MARK(2); CPROF_COUNT(7, 1);
+    };
+    // ---- sums of a group whose samples were requested one group ago ----
+    auto consume = [&](const v4f (&dd)[LPV]) {
+#pragma unroll
+        for (int s = 0; s < LPV; ++s) {
+            const float4 ww = L.wq[s * VPS + lane / LPV];
+            const float wq[4] = {ww.x, ww.y, ww.z, ww.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc[q][0].x = fmaf(dd[s].x, wq[q], acc[q][0].x);                      // src/tron.cu:519
+                acc[q][0].y = fmaf(dd[s].y, wq[q], acc[q][0].y);
+                if constexpr (!ONE) {
+                    acc[q][1].x = fmaf(dd[s].z, wq[q], acc[q][1].x);
+                    acc[q][1].y = fmaf(dd[s].w, wq[q], acc[q][1].y);
+                }
+            }
+        }
+        CPROF_MARK(3);
+    };
+    {
+        v4f dd[LPV];
+        while (next_group()) { issue(dd); consume(dd); }
     }
 
-    // ---- the lanes of a coil pair (lane % LPV) hold partial blocks: sum them, the first LPV lanes add theirs to the grid ----
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            float vx = acc[q][c].x, vy = acc[q][c].y;
-#pragma unroll
-            for (int o = 32; o >= LPV; o >>= 1) {
-                vx += __shfl_xor(vx, o);
-                vy += __shfl_xor(vy, o);
-            }
-            acc[q][c] = (v2f){vx, vy};
-        }
-    if (lane < LPV) {
-#pragma unroll
-        for (int c = 0; c < NC; ++c)
-            if (c < ncl) {
-#pragma unroll
-                for (int qy = 0; qy < 2; ++qy) {
-                    float4 v;
-                    v.x = acc[2 * qy][c].x * p.scale;                       // src/tron.cu:532-534
-                    v.y = acc[2 * qy][c].y * p.scale;
-                    v.z = acc[2 * qy + 1][c].x * p.scale;
-                    v.w = acc[2 * qy + 1][c].y * p.scale;
-                    store_point_pair<true>(p, z, c0 + c, X0, Y0 + qy, v);
-                }
-            }
+    // ---- the lanes of a coil pair (lane % LPV) hold partial blocks: the sums cross the lanes through the wave's LDS (its lists are
+    //      done with), eight values at a time, value k of lane l at [k][l] of rows 64 + LPV floats long, so that neither the writes
+    //      nor the reads below meet on a bank; lane (k, coil pair) adds the 64 / LPV partial sums of value k in lane order and adds
+    //      the result to the grid
+    if (++sub == kCenBatch) {
+        sub = 0u;
+        draw = (unsigned)__builtin_amdgcn_readfirstlane((int)tk);                         // (asked for kCenBatch items ago)
     }
+    item = draw * kCenBatch + sub;
+    {
+        constexpr int ROW = 64 + LPV;
+        float *sc = reinterpret_cast<float *>(&L);
+        float sum = 0.f;
+#pragma unroll
+        for (int half = 0; half < NV / 8; ++half) {
+            asm volatile("" ::: "memory");                      // (a wave's LDS operations complete in the order they were issued)
+#pragma unroll
+            for (int k8 = 0; k8 < 8; ++k8) {
+                const int k = 8 * half + k8;
+                const v2f a = acc[k / (2 * NC)][(k >> 1) % NC];
+                sc[k8 * ROW + lane] = (k & 1) ? a.y : a.x;
+            }
+            asm volatile("" ::: "memory");
+            if (lane / (8 * LPV) == half) {
+                const float *row = sc + ((lane / LPV) & 7) * ROW + cp;
+#pragma unroll 1
+                for (int j0 = 0; j0 < VPS; j0 += 16)              // (16 reads in flight at a time: all 64 of the one-coil-pair form cost 60 registers)
+#pragma unroll
+                    for (int j = j0; j < j0 + 16; ++j) sum += row[j * LPV];
+            }
+        }
+        asm volatile("" ::: "memory");
+        if (lane < NV * LPV) {
+#if !TRON_CEN_GOLD_EARLY
+            float *const gpt = grid_point();
+            const float gold = gpt ? *gpt : 0.f;                // what the arc kernel stored there (three registers less over the item than asking early)
+#endif
+            if (gpt) *gpt = fmaf(sum, p.scale, gold);           // src/tron.cu:532-534
+        }
+    }
+    CPROF_MARK(4);
+    CPROF_COUNT(8, 1);
+    }   // items
+    CPROF_FLUSH;
 }
 
 template <int LPV, bool ONE, bool HALF>
 static hipError_t launch_centre_lpv(const GridParams &p, hipStream_t s)
 {
+    // as many workgroups as the chip holds at once (they stay and draw items), fewer when the launch has fewer items
+    static int wgs_per_xcd[16] = {};                                                      // per device
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    dev &= 15;
+    if (wgs_per_xcd[dev] == 0) {
+        int occ = 0, cus = 0;
+        if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, grid_centre_kernel<LPV, ONE, HALF>, 64 * kCenWaves, 0)) != hipSuccess) return e;
+        if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
+        if (const char *e = tuning_env("TRON_CEN_WGS")) { fprintf(stderr, "centre kernel <%d,%d,%d>: %d workgroups per CU by the occupancy query, %d CUs; TRON_CEN_WGS=%s\n", LPV, (int)ONE, (int)HALF, occ, cus, e); occ = atoi(e); }   // tuning knob
+        wgs_per_xcd[dev] = std::max(1, occ) * std::max(1, cus / 8);
+    }
     const int per_chunk = ONE ? 1 : 2 * LPV;
     const int chunks = (p.nchan - p.coil0 + per_chunk - 1) / per_chunk;
-    const long long per_xcd = (long long)p.cen_ngroups * ((p.nslices + 7) / 8);           // (block, slice) pairs of one XCD: slice z lives on XCD z % 8
-    dim3 grid((unsigned)(8 * ((per_xcd + kCenWaves - 1) / kCenWaves)), (unsigned)chunks);
-    hipLaunchKernelGGL((grid_centre_kernel<LPV, ONE, HALF>), grid, dim3(64 * kCenWaves), 0, s, p);
+    const long long per_xcd = (long long)p.cen_ngroups * chunks * ((p.nslices + 7) / 8);   // items of the busiest XCD: slice z lives on XCD z % 8
+    const long long wgs = std::min<long long>(wgs_per_xcd[dev], (per_xcd + kCenWaves * kCenBatch - 1) / (kCenWaves * kCenBatch));
+    if ((e = hipMemsetAsync(p.cen_ticket, 0, 8 * 16 * sizeof(unsigned), s)) != hipSuccess) return e;
+    GridParams q = p;
+    for (int i = 0; i < 2; ++i) {                               // XCDs below nslices % 8 hold one slice more than the others
+        const unsigned zc = (unsigned)(p.nslices / 8 + 1 - i) * (unsigned)chunks;
+        q.cen_magic_zc[i] = zc > 1 ? (unsigned)(0x100000000ull / zc) + 1u : 0u;               // x / d = mulhi(x, 2^32 / d + 1) for x d < 2^32
+    }
+    q.cen_magic_chunks = chunks > 1 ? (unsigned)(0x100000000ull / (unsigned)chunks) + 1u : 0u;     // (d = 1: see the kernel)
+    hipLaunchKernelGGL((grid_centre_kernel<LPV, ONE, HALF>), dim3((unsigned)(8 * wgs)), dim3(64 * kCenWaves), 0, s, q);
     return hipGetLastError();
 }
 
 // Adds the samples |r| < p.inner_r0 to the grid the arc kernel has stored (same stream, behind it); the same plans as the arc kernel.
 hipError_t launch_grid_centre(const GridParams &p, int half_in, hipStream_t s)
 {
-    if (p.out_p != 1 || p.inner_r0 <= 0 || p.inner_r0 > 16 || p.W > 3.0f || !p.cen_win || !p.cen_order || !p.cen_cs || !p.cen_groups || !p.kb_lut || p.nro != p.nxos || p.npe > 65535)
+    if (p.out_p != 1 || p.inner_r0 <= 0 || p.inner_r0 > 16 || p.W > 3.0f || !p.cen_win || !p.cen_order || !p.cen_cs || !p.cen_grec || !p.cen_ticket || !p.kb_lut || p.nro != p.nxos || p.npe > 65535)
         return hipErrorInvalidValue;
     const int nc = p.nchan - p.coil0;
     if (nc == 1) return half_in ? launch_centre_lpv<1, true, true>(p, s) : launch_centre_lpv<1, true, false>(p, s);
@@ -270,6 +411,17 @@ hipError_t launch_grid_centre(const GridParams &p, int half_in, hipStream_t s)
     if (nc <= 4) return half_in ? launch_centre_lpv<2, false, true>(p, s) : launch_centre_lpv<2, false, false>(p, s);
     return half_in ? launch_centre_lpv<4, false, true>(p, s) : launch_centre_lpv<4, false, false>(p, s);
 }
+
+#ifdef TRON_CEN_PROFILE
+extern "C" __attribute__((visibility("default"))) int tron_debug_cen_profile(unsigned long long *out)   // reads and clears the phase clock (16 slots)
+{
+    static unsigned long long h[kCenProfCopies * 16];
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(h, HIP_SYMBOL(g_cen_prof), sizeof(h)) != hipSuccess) return 1;
+    for (int i = 0; i < 16; ++i) out[i] = 0;
+    for (int i = 0; i < kCenProfCopies * 16; ++i) { out[i % 16] += h[i]; h[i] = 0; }
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_cen_prof), h, sizeof(h)) != hipSuccess;
+}
+#endif
 
 __global__ void warm_grid_centre_tu() {}
 

@@ -88,7 +88,10 @@ struct GridParams {
     const unsigned short *cen_order;   // [window][npe] window-relative spoke index, ascending line angle (mod pi)
     const uint32_t *cen_win;           // [window][cen_ngroups] the block's run of that list: first entry | entries << 16 (circular)
     const float2 *cen_cs;              // [window][npe] (cos, sin) of that spoke
-    const int *cen_groups;             // base blocks (col | row << 8) of the quadrant x, y >= 0 of the origin-centred 32 x 32 square, nearest first
+    const uint4 *cen_grec;             // [cen_ngroups][2] blocks of the origin-centred 32 x 32 square a sample |r| < inner_r0 reaches, nearest first:
+                                       // (col | row << 8, largest such |r|, -, -), (band of the four points as masks over |r|)
+    unsigned cen_magic_zc[2], cen_magic_chunks;    // set by the launcher: division by an XCD's (slice, chunk) pairs / by the coil chunks as a multiplication
+    unsigned *cen_ticket;              // [8][16] work counters of the centre kernel, one per XCD (zeroed by its launcher)
     int cen_ngroups;
 };
 

@@ -300,7 +300,8 @@ int adjoint_run_raw(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, 
                         g.cen_order = p->d_cen_order + woff;
                         g.cen_win = p->d_cen_win + win0 * (size_t)p->cen_ngroups;
                         g.cen_cs = p->d_cen_cs + woff;
-                        g.cen_groups = p->d_cen_groups;
+                        g.cen_grec = p->d_cen_grec;
+                        g.cen_ticket = p->d_cen_ticket;
                         g.cen_ngroups = p->cen_ngroups;
                         HIP_TRY(launch_grid_centre(g, p->cfg.input_half, st));
                     } else {

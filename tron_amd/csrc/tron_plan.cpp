@@ -235,8 +235,38 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
                             if (ax * ax + ay * ay <= reach * reach) groups.push_back(i | (j << 8));
                         }
                     std::stable_sort(groups.begin(), groups.end(), [&](int a, int b) { return d2(a) < d2(b); });
+                    // per block: the band of its four points (src/tron.cu:498-502) as masks over |r| and the largest |r| < inner_r0
+                    // inside it; a block no such sample reaches is dropped
+                    std::vector<uint32_t> grec;
+                    {
+                        std::vector<int> kept;
+                        const int n = d.nxos, h = n / 2;
+                        for (int g : groups) {
+                            const int X0 = 2 * (g & 255) - 16, Y0 = 2 * (g >> 8) - 16;
+                            uint32_t bm[4];
+                            int bandhi = -1, bandlo = 1 << 20;
+                            for (int q = 0; q < 4; ++q) {
+                                const int X = X0 + (q & 1), Y = Y0 + (q >> 1);
+                                const uint32_t bnd = band[(size_t)(Y + h) * n + (X + h)];
+                                const int lo = (int)(bnd & 0xffffu), hi = std::min((int)(bnd >> 16), 31);
+                                bm[q] = 0u;
+                                if (lo <= hi) {
+                                    bm[q] = (0xffffffffu >> (31 - (hi - lo))) << lo;
+                                    bandhi = std::max(bandhi, hi);
+                                    bandlo = std::min(bandlo, lo);
+                                }
+                            }
+                            const int rcap = std::min(p->relief_r0 - 1, bandhi);
+                            if (bandlo > rcap) continue;
+                            kept.push_back(g);
+                            const uint32_t rec[8] = {(uint32_t)g, (uint32_t)rcap, 0u, 0u, bm[0], bm[1], bm[2], bm[3]};
+                            grec.insert(grec.end(), rec, rec + 8);
+                        }
+                        groups.swap(kept);
+                    }
                     p->cen_ngroups = (int)groups.size();
-                    if ((rc = upload(&p->d_cen_groups, groups.data(), groups.size() * sizeof(int)))) return bail(rc);
+                    if ((rc = upload(&p->d_cen_grec, grec.data(), grec.size() * sizeof(uint32_t)))) return bail(rc);
+                    if (hipMalloc(reinterpret_cast<void **>(&p->d_cen_ticket), 8 * 16 * sizeof(unsigned)) != hipSuccess) return bail(fail(TRON_ERR_NOMEM, "centre kernel work counters"));
                     std::vector<uint32_t> wnd(nwin * groups.size());
                     build_centre_windows(phi.data(), nwin, npe, groups.data(), (int)groups.size(), cfg->kernwidth, wnd.data());
                     if ((rc = upload(&p->d_cen_win, wnd.data(), wnd.size() * sizeof(uint32_t)))) return bail(rc);
@@ -452,7 +482,8 @@ extern "C" int tron_plan_destroy(tron_plan *p)
     hipFree(p->d_cen_order);
     hipFree(p->d_cen_win);
     hipFree(p->d_cen_cs);
-    hipFree(p->d_cen_groups);
+    hipFree(p->d_cen_grec);
+    hipFree(p->d_cen_ticket);
     hipFree(p->d_tile_order32_split);
     hipFree(p->d_split_slots);
     hipFree(p->d_partial);

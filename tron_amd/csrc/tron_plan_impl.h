@@ -97,7 +97,8 @@ struct tron_plan {
     unsigned short *d_cen_order = nullptr;
     uint32_t *d_cen_win = nullptr;
     float2 *d_cen_cs = nullptr;
-    int *d_cen_groups = nullptr;
+    uint4 *d_cen_grec = nullptr;
+    unsigned *d_cen_ticket = nullptr;
     int cen_ngroups = 0;
     bool centre_kernel = true;            // TRON_CENTRE_KERNEL=binned (A/B): the inner tile on the binned kernel + grid_reduce_parts_kernel, as in round 3
     int arc_cap = 0, arc_nrec = 0, arc_zper = 1;
