@@ -57,6 +57,15 @@ CASES = [
     (12, 256, 100, 2, dict(golden_angle=1)),                      # two coil chunks (6 + 6; centre kernel 8 + 4)
     (10, 256, 80, 2, dict(golden_angle=1)),                       # a partial last chunk (6 + 4; centre kernel 8 + 2)
     (16, 256, 60, 1, dict(golden_angle=0)),                       # 8 + 8, linear angles
+    # nro != nxos (-o other than 2): radius r reads sample (r nro) / nxos, truncating towards zero (src/tron.cu:517)
+    (2, 256, 100, 2, dict(golden_angle=1, gridos=1.5)),           # 192^2 grid: four samples per three radii (every fourth sample unused)
+    (8, 256, 120, 2, dict(golden_angle=1, gridos=3.0)),           # 384^2 grid: two samples per three radii (a sample gridded twice)
+    (4, 256, 90, 2, dict(golden_angle=0, gridos=2.5)),            # 320^2 grid, linear angles
+    (1, 256, 100, 2, dict(golden_angle=1, gridos=1.5)),           # one coil
+    # more than 1 024 spokes per window: the arc kernel runs in passes over <= 1 024 spokes, the later ones adding to the grid
+    (2, 256, 1300, 2, dict(golden_angle=1)),                      # two passes of 650
+    (8, 128, 2100, 2, dict(golden_angle=1, prof_slide=700)),      # three passes of 700, sliding windows
+    (4, 256, 1030, 1, dict(golden_angle=0)),                      # two passes of 515, linear angles
 ]
 
 
@@ -79,23 +88,24 @@ def test_arc_kernel_vs_oracle_and_binned(oracle, nc, nro, npe, nz, flags):
 
 
 def test_arc_kernel_half_input_and_determinism(oracle):
-    """complex-half k-space, 4 and 8 coils (the halves are converted in LDS, in place); identical bits run to run."""
-    for nc in (4, 8):
+    """complex-half k-space, 4 and 8 coils (the halves are converted in LDS, in place); identical bits run to run.  The third case
+    has nro != nxos (src/tron.cu:517)."""
+    for nc, extra in ((4, {}), (8, {}), (4, dict(gridos=3.0))):
         data = synth.kspace(nc, 256, 140 * 2, seed=9100 + nc)
         h = np.stack([data.real, data.imag]).astype(np.float16)
-        fl = dict(golden_angle=1, data_undersamp=0.547, prof_slide=140)
+        fl = dict(golden_angle=1, data_undersamp=0.547, prof_slide=140, **extra)
+        assert "grid_arc_kernel" in _kernel_name(data.shape, input_half=1, **fl)
         a, dims = lib.recon(h, adjoint=True, input_half=1, **fl)
         b, _ = lib.recon(h, adjoint=True, input_half=1, **fl)
         assert np.array_equal(a, b)
         rounded = (h[0].astype(np.float32) + 1j * h[1].astype(np.float32)).astype(np.complex64)
-        want, _ = oracle.recon(rounded, adjoint=1, golden=1, data_undersamp=0.547, prof_slide=140)
+        want, _ = oracle.recon(rounded, adjoint=1, golden=1, data_undersamp=0.547, prof_slide=140, **extra)
         assert rel_l2(a, want) <= 1e-5
 
 
 @pytest.mark.parametrize("shape,flags,why", [
     ((1, 3, 256, 100, 1), dict(golden_angle=1, data_undersamp=0.39), "odd channel count (1 coil x 3 repetitions; the reference takes 1 or an even number of coils)"),
     ((2, 1, 160, 100, 1), dict(golden_angle=1, data_undersamp=0.63), "grid centre inside a tile (nxos 160)"),
-    ((2, 1, 256, 100, 1), dict(golden_angle=1, data_undersamp=0.39, gridos=1.5), "nro != nxos"),
     ((2, 1, 64, 40, 1), dict(golden_angle=1, data_undersamp=0.625), "grid smaller than 4 x 4 tiles"),
     ((8, 1, 256, 120, 1), dict(golden_angle=1, data_undersamp=0.47, kernwidth=1.0), "W = 1: window B's support starts at the table's origin (build_kb_pair_lut)"),
     ((2, 1, 256, 120, 1), dict(golden_angle=1, data_undersamp=0.47, kernwidth=0.5), "W < 1: no Kaiser-Bessel pair table (the round-3 table was read out of bounds here)"),

@@ -161,4 +161,13 @@ __device__ __forceinline__ float2 load_sample(const void *base, size_t idx)
     }
 }
 
+// (u nro) / nxos of src/tron.cu:517 (the truncating resample of the readout when nro != nxos) for a radius 0 <= u < nxos / 2, in float
+// arithmetic: u nro + 1/2 is exact, and the half keeps the quotient 1 / (2 nxos) away from the integers, more than the product's
+// rounding moves it (checked for every u of a plan by arc_resample_exact before a plan takes the arc path).  nro_f = nro, inv_nxos =
+// 1.0f / nxos; nro == nxos gives u itself.
+__host__ __device__ __forceinline__ float arc_sample_of(float u, float nro_f, float inv_nxos)
+{
+    return truncf(fmaf(u, nro_f, 0.5f) * inv_nxos);
+}
+
 }  // namespace tron

@@ -47,7 +47,6 @@ namespace tron {
 
 constexpr int kArcTile = 32;
 constexpr int kArcThreads = 256;
-constexpr int kArcMaxNpe = 1024;       // spokes per window (prep: thread = spoke, four per thread)
 constexpr int kArcMaxSpokes = 512;     // spokes of one tile's run
 constexpr int kArcMaxBatches = 96;
 constexpr int kArcSeg = 64;            // longest spoke segment through tile + halo: (32 + 2 * 3) sqrt(2) = 54
@@ -248,7 +247,9 @@ arc_prep_kernel(const ArcPrepParams p)
                 c_pos[k] = j + (wrapped ? p.npe : 0);
                 c_phi[k] = ph + (wrapped ? kPi : 0.f);
                 // sample of radius r on spoke pe: nudata[nchan * (nro * pe + r + nro / 2) + c]   src/tron.cu:517,519 (nro == nxos)
-                c_src[k] = (int)((unsigned)(p.nro * pe + p.nro / 2 + (neg ? -ulo : ulo)) | ((unsigned)neg << 31));
+                // nro != nxos: radius r reads sample nro / 2 + (r nro) / nxos (:517, truncating towards zero): the entry then names the
+                // spoke's centre sample and the copy works out every radius' own sample (arc_sample_of)
+                c_src[k] = (int)((unsigned)(p.nro * pe + p.nro / 2 + (p.nro == p.nxos ? (neg ? -ulo : ulo) : 0)) | ((unsigned)neg << 31));
                 c_seg[k] = ulo | (len << 10);
                 c_cs[k] = neg ? make_float2(-cs.x, -cs.y) : cs;
                 if (len > 0) {
@@ -422,7 +423,17 @@ hipError_t launch_arc_prep(const ArcPrepParams &p, int nwindows, hipStream_t s)
 // HALF: k-space stored as complex-half.  The copy brings the halves into the upper half of each record's fp32 slots (four
 // coils per 16 bytes) and one pass over the records converts them in place -- each thread reads all of a record's halves,
 // then writes its floats, so no record is touched by two threads -- and the gather is the fp32 one.
-template <int CPB, bool HALF>
+bool arc_resample_exact(int nxos, int nro)
+{
+    const float nro_f = (float)nro, inv = 1.0f / (float)nxos;
+    for (int u = 0; u < nxos / 2; ++u)
+        if ((int)arc_sample_of((float)u, nro_f, inv) != (int)(((long long)u * nro) / nxos)) return false;
+    return true;
+}
+
+// RS: nro != nxos, the truncating resample of the readout (src/tron.cu:517, 526): the copy fetches every radius' own sample (one
+// record per radius as ever, so the gather indexes as before) and the density compensation follows the sample, not the radius.
+template <int CPB, bool HALF, bool RS>
 __global__ void __launch_bounds__(kArcThreads, ArcCfg<CPB>::WAVES)
 grid_arc_kernel(const GridParams p)
 {
@@ -495,6 +506,7 @@ grid_arc_kernel(const GridParams p)
     constexpr unsigned kBufBytes = (unsigned)(C::NREC * CPB * 8);
     constexpr unsigned kRecStep = CPB == 1 ? 4u : 16u;              // bytes between consecutive records of one plane
     const float dcf_a = p.apply_dcf ? p.dcf_a : 0.0f, dcf_b = p.apply_dcf ? p.dcf_b : 1.0f;
+    const float rs_nro = (float)p.nro, rs_inv = 1.0f / (float)p.nxos;
 
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const unsigned nchan8 = (unsigned)p.nchan * (HALF ? 4u : 8u);       // bytes per sample (all coils)
@@ -581,7 +593,13 @@ grid_arc_kernel(const GridParams p)
                     const unsigned dst = buf + (sb >> 17) * kRecStep;
                     const unsigned first = (a & 0x7fffffffu) * nchan8;                     // byte offset of the first record's coil 0
                     if (lane < len) {
-                        const unsigned voff = (a >> 31) ? first - lane_step : first + lane_step;
+                        unsigned voff;
+                        if constexpr (RS) {                                                    // `first` is the spoke's centre sample here
+                            const unsigned so = (unsigned)(int)arc_sample_of((float)((int)(sb & 1023u) + lane), rs_nro, rs_inv) * nchan8;
+                            voff = (a >> 31) ? first - so : first + so;
+                        } else {
+                            voff = (a >> 31) ? first - lane_step : first + lane_step;
+                        }
                         if constexpr (CPB == 1) {
                             lds_dma4_s(in, voff, dst);                                     // real parts, imaginary parts
                             lds_dma4_s(in + 4, voff, dst + (unsigned)(C::NREC * 4));
@@ -737,7 +755,7 @@ grid_arc_kernel(const GridParams p)
 #pragma unroll
                                 for (int c = 0; c < CPB / 2; ++c) dd[c] = *(lds_f4p)(size_t)(addr + (unsigned)(c * C::NREC * 16));
                             }
-                            const float sdc = fmaf(dcf_a, ufv.x, dcf_b);                              // src/tron.cu:412 (|ro - nro/2| = u)
+                            const float sdc = fmaf(dcf_a, RS ? arc_sample_of(ufv.x, rs_nro, rs_inv) : ufv.x, dcf_b);   // src/tron.cu:412 (|ro - nro/2| = u, or u's sample)
                             const v2f fxv = {fv.x, fv.x}, fyv = {fv.y, fv.y}, sdcv = {sdc, sdc};
                             const v2f wx = __builtin_elementwise_fma(fxv, __builtin_elementwise_fma(fxv, x2c, x1c), x0c);
                             const v2f wy = __builtin_elementwise_fma(fyv, __builtin_elementwise_fma(fyv, y2c, y1c), y0c) * sdcv;
@@ -793,7 +811,12 @@ grid_arc_kernel(const GridParams p)
                         v.y = acc[2 * qy][c].y * p.scale;
                         v.z = acc[2 * qy + 1][c].x * p.scale;
                         v.w = acc[2 * qy + 1][c].y * p.scale;
-                        *reinterpret_cast<float4 *>(zbase + (size_t)c * p.out_c * 8 + out_off[qy]) = v;
+                        float4 *const o = reinterpret_cast<float4 *>(zbase + (size_t)c * p.out_c * 8 + out_off[qy]);
+                        if (p.arc_accumulate) {                             // a later pass over more than kArcMaxNpe spokes per window
+                            const float4 old = *o;
+                            v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
+                        }
+                        *o = v;
                     }
                 }
         }
@@ -816,8 +839,8 @@ extern "C" __attribute__((visibility("default"))) int tron_debug_arc_profile(uns
 }
 #endif
 
-template <int CPB, bool HALF>
-static hipError_t launch_arc_cpb(const GridParams &p, int first_plain, hipStream_t s)
+template <int CPB, bool HALF, bool RS>
+static hipError_t launch_arc_rs(const GridParams &p, int first_plain, hipStream_t s)
 {
     if (p.arc_nrec != ArcCfg<CPB>::NREC) return hipErrorInvalidValue;       // the run tables were dealt for another batch size
     const int tpr = (p.nxos + kArcTile - 1) / kArcTile;
@@ -831,11 +854,17 @@ static hipError_t launch_arc_cpb(const GridParams &p, int first_plain, hipStream
     dim3 grid((unsigned)((size_t)q.ntiles * ngroups), (unsigned)chunks);
     const size_t lds = sizeof(ArcLds<CPB>);
     if (lds > 64 * 1024) {
-        const hipError_t once = allow_dynamic_lds(reinterpret_cast<const void *>(grid_arc_kernel<CPB, HALF>), (int)sizeof(ArcLds<CPB>));
+        const hipError_t once = allow_dynamic_lds(reinterpret_cast<const void *>(grid_arc_kernel<CPB, HALF, RS>), (int)sizeof(ArcLds<CPB>));
         if (once != hipSuccess) return once;
     }
-    hipLaunchKernelGGL((grid_arc_kernel<CPB, HALF>), grid, dim3(kArcThreads), lds, s, q);
+    hipLaunchKernelGGL((grid_arc_kernel<CPB, HALF, RS>), grid, dim3(kArcThreads), lds, s, q);
     return hipGetLastError();
+}
+
+template <int CPB, bool HALF>
+static hipError_t launch_arc_cpb(const GridParams &p, int first_plain, hipStream_t s)
+{
+    return p.nro != p.nxos ? launch_arc_rs<CPB, HALF, true>(p, first_plain, s) : launch_arc_rs<CPB, HALF, false>(p, first_plain, s);
 }
 
 // fp32 k-space: one coil or an even coil count (16-byte coil pairs); complex-half: a multiple of four coils (16 bytes)
@@ -843,7 +872,8 @@ bool grid_arc_supported(int nchan, int nxos, int nro, int npe, float W, int half
 {
     const bool coils = half_in ? (nchan >= 4 && (nchan & 3) == 0) : (nchan == 1 || (nchan & 1) == 0);
     // widths without a Kaiser-Bessel pair table (W <= 1, W 2^k no integer; build_kb_pair_lut) stay on the binned kernel
-    return nchan >= 1 && coils && nro == nxos && nxos <= 2048 && npe <= kArcMaxNpe && W <= 3.0f && kb_pair_lut_scale(W, kArcLutEntries) > 0
+    // nro != nxos (any -o but 2): the truncating resample of src/tron.cu:517, where its float form is exact (it is for every size tried)
+    return nchan >= 1 && coils && (nro == nxos || (nro >= 2 && arc_resample_exact(nxos, nro))) && nxos <= 2048 && npe <= kArcMaxPasses * kArcMaxNpe && W <= 3.0f && kb_pair_lut_scale(W, kArcLutEntries) > 0
            && (nxos / 2) % kArcTile == 0 && nxos >= 4 * kArcTile && (long long)nro * npe * nchan < (1ll << 28);
 }
 
@@ -852,7 +882,7 @@ hipError_t launch_grid_arc(const GridParams &p, int half_in, int first_plain, hi
 {
     const int gran = half_in ? 3 : (p.nchan == 1 ? 0 : 1);
     if (p.out_p != 1 || p.inner_r0 <= 0 || !p.arc_hdr || !p.arc_ent || !p.arc_win || !p.kb_lut || p.lut_entries > kArcLutEntries || (p.coil0 & gran)
-        || !grid_arc_supported(p.nchan, p.nxos, p.nro, p.npe, p.W, half_in) || (reinterpret_cast<uintptr_t>(p.nudata) & 15) != 0)
+        || p.npe > kArcMaxNpe || !grid_arc_supported(p.nchan, p.nxos, p.nro, p.npe, p.W, half_in) || (reinterpret_cast<uintptr_t>(p.nudata) & 15) != 0)
         return hipErrorInvalidValue;
     const int nc = p.nchan - p.coil0;
     if (half_in) return nc >= 5 ? launch_arc_cpb<8, true>(p, first_plain, s) : launch_arc_cpb<4, true>(p, first_plain, s);

@@ -131,6 +131,7 @@ grid_centre_kernel(const GridParams p)
     const float dcf_a = p.apply_dcf ? p.dcf_a : 0.0f, dcf_b = p.apply_dcf ? p.dcf_b : 1.0f;
     const float2 *lut = lds.lut + p.lut_bias;                   // entry of table position 0
     const unsigned nchan8 = (unsigned)p.nchan * (HALF ? 4u : 8u);
+    const float rs_nro = (float)p.nro, rs_inv = 1.0f / (float)p.nxos;
     CPROF_MARK(0);                                              // table
 
     // a wave's first item is its own number on the XCD, the tickets go on from there: no wave waits for the counter before it starts
@@ -251,10 +252,12 @@ grid_centre_kernel(const GridParams p)
         if (v < total) {
             const uint4 rec = L.rec[L.owner[v]];
             const int ri = (int)((rec.w >> 16) & 63u) - 32 + (v - (int)rec.z);
-            // sample of radius r on spoke pe: nudata[nchan * (nro * pe + r + nro / 2) + c]   src/tron.cu:517,519 (nro == nxos)
-            off = (unsigned)(p.nro * (int)(rec.w & 0xffffu) + p.nro / 2 + ri) * nchan8;
-            // (kx, ky) = r (cos, sin) and the distances to the block's first column / row, op for op src/tron.cu:514-516
+            // sample of radius r on spoke pe: nudata[nchan * (nro * pe + (r nro) / nxos + nro / 2) + c]   src/tron.cu:517,519 (truncating
+            // towards zero; r itself when nro == nxos)
             const float rf = (float)ri;
+            const float sf = arc_sample_of(fabsf(rf), rs_nro, rs_inv);
+            off = (unsigned)(p.nro * (int)(rec.w & 0xffffu) + p.nro / 2 + (ri < 0 ? -(int)sf : (int)sf)) * nchan8;
+            // (kx, ky) = r (cos, sin) and the distances to the block's first column / row, op for op src/tron.cu:514-516
             const v2f kxy = (v2f){rf, rf} * (v2f){__uint_as_float(rec.x), __uint_as_float(rec.y)};
             const v2f tp = (kxy - p0v) * lscale2;
             const v2f tt = {__builtin_truncf(tp.x), __builtin_truncf(tp.y)};
@@ -263,8 +266,8 @@ grid_centre_kernel(const GridParams p)
             const float2 x0c = lx[0], x1c = lx[kArcLutEntries], x2c = lx[2 * kArcLutEntries];
             const float2 y0c = ly[0], y1c = ly[kArcLutEntries], y2c = ly[2 * kArcLutEntries];
             const int ar = ri < 0 ? -ri : ri;
-            // src/tron.cu:412 (|ro - nro/2| = |r|); r = 0 is visited by both loops of the reference where the band starts at 0
-            const float sdc = fmaf(dcf_a, fabsf(rf), dcf_b) * (ri == 0 ? 2.0f : 1.0f);
+            // src/tron.cu:412 (|ro - nro/2|); r = 0 is visited by both loops of the reference where the band starts at 0
+            const float sdc = fmaf(dcf_a, sf, dcf_b) * (ri == 0 ? 2.0f : 1.0f);
             const v2f fxv = {fv.x, fv.x}, fyv = {fv.y, fv.y}, sdcv = {sdc, sdc};
             const v2f wx = __builtin_elementwise_fma(fxv, __builtin_elementwise_fma(fxv, (v2f){x2c.x, x2c.y}, (v2f){x1c.x, x1c.y}), (v2f){x0c.x, x0c.y});
             const v2f wy = __builtin_elementwise_fma(fyv, __builtin_elementwise_fma(fyv, (v2f){y2c.x, y2c.y}, (v2f){y1c.x, y1c.y}), (v2f){y0c.x, y0c.y}) * sdcv;
@@ -403,7 +406,7 @@ static hipError_t launch_centre_lpv(const GridParams &p, hipStream_t s)
 // Adds the samples |r| < p.inner_r0 to the grid the arc kernel has stored (same stream, behind it); the same plans as the arc kernel.
 hipError_t launch_grid_centre(const GridParams &p, int half_in, hipStream_t s)
 {
-    if (p.out_p != 1 || p.inner_r0 <= 0 || p.inner_r0 > 16 || p.W > 3.0f || !p.cen_win || !p.cen_order || !p.cen_cs || !p.cen_grec || !p.cen_ticket || !p.kb_lut || p.nro != p.nxos || p.npe > 65535)
+    if (p.out_p != 1 || p.inner_r0 <= 0 || p.inner_r0 > 16 || p.W > 3.0f || !p.cen_win || !p.cen_order || !p.cen_cs || !p.cen_grec || !p.cen_ticket || !p.kb_lut || p.npe > 65535)
         return hipErrorInvalidValue;
     const int nc = p.nchan - p.coil0;
     if (nc == 1) return half_in ? launch_centre_lpv<1, true, true>(p, s) : launch_centre_lpv<1, true, false>(p, s);

@@ -78,6 +78,7 @@ struct GridParams {
     const uint4 *arc_ent;              // [window][arc_cap] -> first sample index | down << 31, ulo | len << 10 | offset << 17, cos, sin
     const uint32_t *arc_win;           // [window][tile][256] -> per thread of the tile's workgroup its run of the tile's list: first entry | end << 16
     int arc_cap, arc_nrec;             // entries per window; records per batch the runs were dealt for
+    int arc_accumulate;                // the arc kernel adds to the grid instead of storing (passes after the first, npe > kArcMaxNpe)
     int arc_slice_stride;              // windows between consecutive slices: 1 (golden angle) or 0 (every slice has the same angles)
     const float2 *kb_lut;              // [3][kArcLutEntries] Kaiser-Bessel pair table: position t = d lut_scale of the signed distance d from a block's
                                        // first column, entry trunc(t) + lut_bias: c0 + f (c1 + f c2) for that column (.x) and the next (.y); zero from |x| = W on
@@ -144,6 +145,8 @@ hipError_t launch_grid_reduce(const GridParams &p, hipStream_t s);
 // the samples |r| < p.inner_r0 ADDED to the grid the arc kernel has stored (tron_grid_centre.hip): same stream, behind launch_grid_arc
 hipError_t launch_grid_centre(const GridParams &p, int half_in, hipStream_t s);
 hipError_t warm_grid_centre();
+constexpr int kArcMaxNpe = 1024;       // spokes of one window the arc kernel's run tables hold (arc_prep_kernel: thread = spoke, four per thread)
+constexpr int kArcMaxPasses = 4;       // windows of more spokes are gridded in passes of <= kArcMaxNpe, the later ones adding to the grid
 bool grid_arc_supported(int nchan, int nxos, int nro, int npe, float W, int half_in);
 int grid_arc_nrec(int nchan, int half_in);
 constexpr int kArcLutEntries = 400;    // Kaiser-Bessel pair-table entries held in LDS (build_kb_pair_lut: (2 W + 1) s + 4 of them, s a power of two, W > 1)

@@ -282,9 +282,7 @@ int adjoint_run_raw(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, 
                         HIP_TRY(launch_grid_binned(gi, p->cfg.input_half, st));
                     }
                     const size_t win0 = golden ? (size_t)(zfirst + z0 - p->share_z0) : 0;     // the run tables start at the plan's first slice
-                    g.arc_hdr = p->d_arc_hdr + win0 * (size_t)(d.nxos / kBinnedTile) * (d.nxos / kBinnedTile);
-                    g.arc_ent = p->d_arc_ent + win0 * p->arc_cap;
-                    g.arc_win = p->d_arc_win + win0 * (size_t)(d.nxos / kBinnedTile) * (d.nxos / kBinnedTile) * 256;
+                    const size_t nt32 = (size_t)(d.nxos / kBinnedTile) * (d.nxos / kBinnedTile);
                     g.arc_cap = p->arc_cap;
                     g.arc_nrec = p->arc_nrec;
                     g.arc_slice_stride = golden ? 1 : 0;
@@ -294,7 +292,16 @@ int adjoint_run_raw(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, 
                     g.lut_bias = p->lut_bias;
                     // slices one workgroup grids in turn (tile geometry and the window table are set up once per workgroup)
                     g.arc_zper = p->arc_zper > 0 ? p->arc_zper : (cz >= 64 ? 4 : (cz >= 32 ? 2 : 1));
-                    HIP_TRY(launch_grid_arc(g, p->cfg.input_half, relief_parts, st));
+                    for (int q = 0; q < p->arc_passes; ++q) {      // (one pass unless a window holds more than kArcMaxNpe spokes)
+                        GridParams ga = g;
+                        const size_t tab = (size_t)q * p->arc_nwin + win0;
+                        ga.arc_hdr = p->d_arc_hdr + tab * nt32;
+                        ga.arc_ent = p->d_arc_ent + tab * p->arc_cap;
+                        ga.arc_win = p->d_arc_win + tab * nt32 * 256;
+                        ga.npe = std::min(d.npe1work, (q + 1) * p->arc_pass_npe) - q * p->arc_pass_npe;
+                        ga.arc_accumulate = q > 0;
+                        HIP_TRY(launch_grid_arc(ga, p->cfg.input_half, relief_parts, st));
+                    }
                     if (p->centre_kernel) {
                         const size_t woff = win0 * (size_t)d.npe1work;
                         g.cen_order = p->d_cen_order + woff;

@@ -278,39 +278,82 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
                         scs[2 * (w * npe + k)] = trig[2 * src];
                         scs[2 * (w * npe + k) + 1] = trig[2 * src + 1];
                     }
+                // Windows of more than kArcMaxNpe spokes: the run tables are built, and the arc kernel run, once per PASS over the spokes
+                // [q sub, (q + 1) sub) of every window (each pass's list = the sorted list with the other spokes left out); the passes
+                // after the first add to the grid.  The centre kernel takes the whole window at once.
+                const int npass = (npe + kArcMaxNpe - 1) / kArcMaxNpe, sub = (npe + npass - 1) / npass;
+                p->arc_passes = npass;
+                p->arc_nwin = nwin;
+                p->arc_pass_npe = sub;
                 unsigned short *d_order = nullptr;
-                float *d_phi = nullptr, *d_scs = nullptr;
-                int *d_alloc = nullptr;
-                auto drop = [&]() { hipFree(d_alloc); hipFree(d_phi); p->d_cen_order = d_order; p->d_cen_cs = reinterpret_cast<float2 *>(d_scs); };   // the sorted lists stay: centre kernel
+                float *d_scs = nullptr;
                 // a spoke crosses at most 2 * nxos / 32 + 3 tiles (+ their halos): 56 run entries per spoke bound every window
-                p->arc_cap = npe * (2 * (d.nxos / kBinnedTile) + 24);
+                p->arc_cap = sub * (2 * (d.nxos / kBinnedTile) + 24);
                 p->arc_nrec = grid_arc_nrec(p->nchan, cfg->input_half);
                 rc = upload(&d_order, order.data(), order.size() * sizeof(unsigned short));
-                if (!rc) rc = upload(&d_phi, phi.data(), phi.size() * sizeof(float));
                 if (!rc) rc = upload(&d_scs, scs.data(), scs.size() * sizeof(float));
-                if (!rc && hipMalloc(reinterpret_cast<void **>(&d_alloc), nwin * sizeof(int)) != hipSuccess) rc = fail(TRON_ERR_NOMEM, "arc tables");
-                if (!rc && (hipMalloc(reinterpret_cast<void **>(&p->d_arc_hdr), nwin * nt32 * sizeof(int4)) != hipSuccess ||
-                            hipMalloc(reinterpret_cast<void **>(&p->d_arc_ent), nwin * p->arc_cap * sizeof(uint4)) != hipSuccess ||
-                            hipMalloc(reinterpret_cast<void **>(&p->d_arc_win), nwin * nt32 * 256 * sizeof(uint32_t)) != hipSuccess))
+                p->d_cen_order = d_order;                       // the sorted lists stay: centre kernel
+                p->d_cen_cs = reinterpret_cast<float2 *>(d_scs);
+                const size_t ntab = nwin * (size_t)npass;       // tables [pass][window]
+                if (!rc && (hipMalloc(reinterpret_cast<void **>(&p->d_arc_hdr), ntab * nt32 * sizeof(int4)) != hipSuccess ||
+                            hipMalloc(reinterpret_cast<void **>(&p->d_arc_ent), ntab * p->arc_cap * sizeof(uint4)) != hipSuccess ||
+                            hipMalloc(reinterpret_cast<void **>(&p->d_arc_win), ntab * nt32 * 256 * sizeof(uint32_t)) != hipSuccess))
                     rc = fail(TRON_ERR_NOMEM, "cannot allocate the arc kernel's run tables");
-                if (rc) { drop(); return bail(rc); }
+                if (rc) return bail(rc);
                 unsigned int zero = 0;
-                if ((rc = upload(&p->d_errflag, &zero, sizeof(zero)))) { drop(); return bail(rc); }
-                // ON THE PLAN'S STREAM: a memset of device memory on the null stream returns before it has run, and a non-blocking stream
-                // does not wait for it -- arc_prep_kernel then handed out run-table space from whatever the allocation held (round 3's
-                // `hipMemset`: tables that overlapped, or an overflow flag and a silent fall-back to the binned kernel; one first process
-                // in three on a fresh box, most runs with eight plans being created at once)
-                if (hipMemsetAsync(d_alloc, 0, nwin * sizeof(int), p->stream) != hipSuccess) { drop(); return bail(fail(TRON_ERR_HIP, "hipMemsetAsync failed")); }
-                ArcPrepParams ap;
-                ap.order = d_order; ap.phi = d_phi; ap.cs = reinterpret_cast<const float2 *>(d_scs);
-                ap.hdr = p->d_arc_hdr; ap.ent = p->d_arc_ent; ap.win = p->d_arc_win; ap.band = p->d_band; ap.alloc = d_alloc; ap.errflag = p->d_errflag;
-                ap.nxos = d.nxos; ap.nro = d.nro; ap.npe = npe; ap.ntiles = nt32; ap.inner_r0 = p->relief_r0; ap.nrec = p->arc_nrec;
-                ap.cap = p->arc_cap; ap.W = cfg->kernwidth;
-                hipError_t he = launch_arc_prep(ap, (int)nwin, p->stream);
-                if (he == hipSuccess) he = hipStreamSynchronize(p->stream);
+                if ((rc = upload(&p->d_errflag, &zero, sizeof(zero)))) return bail(rc);
+                hipError_t he = hipSuccess;
+                for (int q = 0; q < npass && he == hipSuccess && !rc; ++q) {
+                    const int lo = q * sub, hi = std::min(npe, lo + sub), nq = hi - lo;
+                    std::vector<unsigned short> order_q;
+                    std::vector<float> phi_q, scs_q;
+                    const unsigned short *ho = order.data();
+                    const float *hp = phi.data(), *hs = scs.data();
+                    if (npass > 1) {
+                        order_q.resize(nwin * nq); phi_q.resize(nwin * nq); scs_q.resize(2 * nwin * nq);
+                        for (size_t w = 0; w < nwin; ++w) {
+                            size_t o = w * nq;
+                            for (int k = 0; k < npe; ++k) {
+                                const unsigned short pe = order[w * npe + k];
+                                if (pe < lo || pe >= hi) continue;
+                                order_q[o] = pe; phi_q[o] = phi[w * npe + k];
+                                scs_q[2 * o] = scs[2 * (w * npe + k)]; scs_q[2 * o + 1] = scs[2 * (w * npe + k) + 1];
+                                ++o;
+                            }
+                        }
+                        ho = order_q.data(); hp = phi_q.data(); hs = scs_q.data();
+                    }
+                    unsigned short *dq_order = nullptr;
+                    float *dq_phi = nullptr, *dq_scs = nullptr;
+                    int *d_alloc = nullptr;
+                    auto drop = [&]() { hipFree(d_alloc); hipFree(dq_phi); if (npass > 1) { hipFree(dq_order); hipFree(dq_scs); } };
+                    if (npass > 1) {
+                        rc = upload(&dq_order, ho, nwin * nq * sizeof(unsigned short));
+                        if (!rc) rc = upload(&dq_scs, hs, 2 * nwin * nq * sizeof(float));
+                    } else {
+                        dq_order = d_order; dq_scs = d_scs;
+                    }
+                    if (!rc) rc = upload(&dq_phi, hp, nwin * nq * sizeof(float));
+                    if (!rc && hipMalloc(reinterpret_cast<void **>(&d_alloc), nwin * sizeof(int)) != hipSuccess) rc = fail(TRON_ERR_NOMEM, "arc tables");
+                    if (rc) { drop(); break; }
+                    // ON THE PLAN'S STREAM: a memset of device memory on the null stream returns before it has run, and a non-blocking stream
+                    // does not wait for it -- arc_prep_kernel then handed out run-table space from whatever the allocation held (round 3's
+                    // `hipMemset`: tables that overlapped, or an overflow flag and a silent fall-back to the binned kernel; one first process
+                    // in three on a fresh box, most runs with eight plans being created at once)
+                    if (hipMemsetAsync(d_alloc, 0, nwin * sizeof(int), p->stream) != hipSuccess) { drop(); rc = fail(TRON_ERR_HIP, "hipMemsetAsync failed"); break; }
+                    ArcPrepParams ap;
+                    ap.order = dq_order; ap.phi = dq_phi; ap.cs = reinterpret_cast<const float2 *>(dq_scs);
+                    ap.hdr = p->d_arc_hdr + (size_t)q * nwin * nt32; ap.ent = p->d_arc_ent + (size_t)q * nwin * p->arc_cap;
+                    ap.win = p->d_arc_win + (size_t)q * nwin * nt32 * 256; ap.band = p->d_band; ap.alloc = d_alloc; ap.errflag = p->d_errflag;
+                    ap.nxos = d.nxos; ap.nro = d.nro; ap.npe = nq; ap.ntiles = nt32; ap.inner_r0 = p->relief_r0; ap.nrec = p->arc_nrec;
+                    ap.cap = p->arc_cap; ap.W = cfg->kernwidth;
+                    he = launch_arc_prep(ap, (int)nwin, p->stream);
+                    if (he == hipSuccess) he = hipStreamSynchronize(p->stream);
+                    drop();
+                }
+                if (rc) return bail(rc);
                 unsigned int flag = 0;
                 if (he == hipSuccess) he = hipMemcpy(&flag, p->d_errflag, sizeof(flag), hipMemcpyDeviceToHost);
-                drop();
                 if (he != hipSuccess) return bail(fail(TRON_ERR_HIP, "arc_prep_kernel failed: %s", hipGetErrorString(he)));
                 if (flag) {   // a trajectory the arc kernel's tables cannot hold: the binned kernel takes all tiles
                     hipMemsetAsync(p->d_errflag, 0, sizeof(flag), p->stream);
@@ -386,16 +429,18 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
         p->dual = cfg->adjoint && p->nchan > 1 && p->share_nz >= 2 * p->chunk;
         if (const char *ds = tuning_env("TRON_DUAL_STREAM")) p->dual = d.nz > 1 && atoi(ds) != 0;
         if (p->dual) {
-            // TRON_CU_SPLIT=k: give the (HBM-bound) FFT lane every k-th CU and the (VALU/LDS-bound) gridding lane
-            // the rest, so the two overlap in space instead of queueing behind each other
+            // TRON_CU_SPLIT=k (tuning knob): give the FFT lane every k-th CU of every XCD and the gridding lane the rest, so the two overlap
+            // in space instead of queueing behind each other.  Bit i of a stream's CU mask is CU i / 8 of XCD i % 8, and an XCD
+            // whose bits are all clear runs on all of its CUs (tools/probe/cumask.hip): the mask is built per XCD.  Measured, round 4:
+            // no split 67.6 k slices/s, k = 3: 54.0 k -- both lanes' kernels scale with the CUs they get.
             int split = 0;
             if (const char *cs = tuning_env("TRON_CU_SPLIT")) split = atoi(cs);
             if (split >= 2) {
                 uint32_t mask_fft[8], mask_grid[8];
                 for (int w = 0; w < 8; ++w) { mask_fft[w] = 0; mask_grid[w] = 0; }
-                for (int cu = 0; cu < 256; ++cu) {
-                    if (cu % split == 0) mask_fft[cu / 32] |= 1u << (cu % 32);
-                    else mask_grid[cu / 32] |= 1u << (cu % 32);
+                for (int bit = 0; bit < 256; ++bit) {
+                    if ((bit / 8) % split == 0) mask_fft[bit / 32] |= 1u << (bit % 32);
+                    else mask_grid[bit / 32] |= 1u << (bit % 32);
                 }
                 hipStream_t masked = nullptr;
                 if (hipExtStreamCreateWithCUMask(&p->stream2, 8, mask_fft) != hipSuccess ||

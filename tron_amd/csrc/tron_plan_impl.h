@@ -102,6 +102,8 @@ struct tron_plan {
     int cen_ngroups = 0;
     bool centre_kernel = true;            // TRON_CENTRE_KERNEL=binned (A/B): the inner tile on the binned kernel + grid_reduce_parts_kernel, as in round 3
     int arc_cap = 0, arc_nrec = 0, arc_zper = 1;
+    int arc_passes = 1, arc_pass_npe = 0;       // windows of more than kArcMaxNpe spokes: passes over arc_pass_npe spokes each (tron_plan.cpp)
+    size_t arc_nwin = 0;                        // windows the run tables hold (per pass)
     float lut_scale = 0;
     int lut_entries = 0, lut_bias = 0;
     double lut_err = 0;
