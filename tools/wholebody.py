@@ -19,7 +19,7 @@ for mode in ("fast", "exact"):
         t0 = time.perf_counter()
         r = subprocess.run([os.path.join(ROOT, "tron_amd/bin/tron"), "-v", "-u", "0.4", "-d", "21", "-a", "-G", inp, out], capture_output=True, text=True, env=env)
         dt = time.perf_counter() - t0
-        el = [l for l in r.stdout.splitlines() if "time" in l]
+        el = [l for l in r.stdout.splitlines() if "time" in l or "start-up" in l]
         print(f"KB {mode} run {rep}: rc={r.returncode} wall {dt:.2f} s  ({956/dt:.0f} slices/s end to end incl. file I/O); {el}")
 h = ra.read_header(out)
 print("output dims", h.dims, "bytes", os.path.getsize(out))

@@ -11,6 +11,8 @@
 // block of one slice at a time (an ITEM) and its lanes share out the block's VISITS (sample, block):
 //   items   the workgroups stay for the launch (as many as the chip holds) and every wave draws its items from a counter of its
 //           XCD; the next draw is asked for when an item starts and read when it ends;
+//           a busy block (every spoke passes the ones at the origin, 50 the ones at the rim) is up to four items in launches of few
+//           slices, one per run of its window: each leaves its sums in a slot, the last to finish adds them up in part order;
 //   window  the block's run of the angle-sorted spoke list (the arc kernel's rule; worked out by the host at plan creation);
 //   chunk   64 spokes of the run, one per lane (the chunk after it already requested): clip against the block's footprint in SIGNED
 //           r (so no run ever "wraps"; |r| < inner_r0); an exclusive scan of the chord lengths (DPP) numbers the chunk's visits, and
@@ -38,18 +40,12 @@ namespace tron {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-#ifndef TRON_CEN_GOLD_EARLY
-#define TRON_CEN_GOLD_EARLY 0
-#endif
 #ifdef TRON_CEN_OCC
 #define TRON_CEN_OCC_ATTR __attribute__((amdgpu_waves_per_eu(TRON_CEN_OCC)))     // (measured for the 8-coil form, 98 registers: held to 96 for a fifth wave per SIMD, no faster)
 #else
 #define TRON_CEN_OCC_ATTR
 #endif
-#ifndef TRON_CEN_BATCH
-#define TRON_CEN_BATCH 1
-#endif
-constexpr unsigned kCenBatch = TRON_CEN_BATCH;                // items per draw from the XCD's counter
+constexpr int kCenTicketWords = 8 * 16;                         // GridParams::cen_ticket: a counter per XCD, 64 bytes apart; then one per busy (slice, chunk, block)
 constexpr int kCenWaves = 4;                                   // waves per workgroup, each on its own (block, slice)
 
 struct CenWaveLds {
@@ -136,11 +132,10 @@ grid_centre_kernel(const GridParams p)
 
     // a wave's first item is its own number on the XCD, the tickets go on from there: no wave waits for the counter before it starts
     const unsigned nwaves = (gridDim.x >> 3) * kCenWaves;
-    unsigned draw = (blockIdx.x >> 3) * kCenWaves + (unsigned)wave, sub = 0u;              // a draw = kCenBatch items in a row
-    unsigned item = draw * kCenBatch;
+    unsigned item = (blockIdx.x >> 3) * kCenWaves + (unsigned)wave;
     unsigned tk = 0u;
     while (item < nitems) {
-    if (sub == 0u && lane == 0) tk = nwaves + atomicAdd(ticket, 1u);                     // the next draw: on its way while this one is worked on
+    if (lane == 0) tk = nwaves + atomicAdd(ticket, 1u);         // the next item's ticket: on its way while this item is worked on
     const int gi = (int)(zc > 1 ? __umulhi(item, magic_zc) : item);               // item = block * (slices of this XCD * chunks) + slice * chunks + chunk; scalar arithmetic
     const unsigned rest = item - (unsigned)gi * zc;
     const unsigned zi = chunks > 1 ? __umulhi(rest, p.cen_magic_chunks) : rest;
@@ -151,6 +146,7 @@ grid_centre_kernel(const GridParams p)
     // 32 x 32 square, the largest |r| < inner_r0 that reaches it; the band of its four points as masks over |r|
     const uint4 g0 = p.cen_grec[2 * gi], g1 = p.cen_grec[2 * gi + 1];
     const int grp = (int)g0.x, rcap = (int)g0.y;
+    const int part = (int)(g0.z & 255u), nparts = (int)((g0.z >> 8) & 255u), heavy = (int)(g0.z >> 16), greal = (int)g0.w;
     const unsigned bmask[4] = {g1.x, g1.y, g1.z, g1.w};
     const int X0 = 2 * (grp & 255) - 16, Y0 = 2 * (grp >> 8) - 16;
 
@@ -165,16 +161,18 @@ grid_centre_kernel(const GridParams p)
         const int col = p.out_shift ? (X < 0 ? X + n : X) : X + h;
         return reinterpret_cast<float *>(p.udata + (size_t)z * p.out_z + ((size_t)row * n + col) * p.out_p + (size_t)(c0 + cbit) * p.out_c) + (k & 1);
     };
-#if TRON_CEN_GOLD_EARLY
-    float *const gpt = grid_point();                            // what the arc kernel stored there: asked for now, added at the end
-    const float gold = gpt ? *gpt : 0.f;
-#endif
 
     const size_t win = (size_t)z * p.arc_slice_stride;
     const unsigned short *order = p.cen_order + win * npe;
     const float2 *scs = p.cen_cs + win * npe;
-    const unsigned wnd = p.cen_win[win * p.cen_ngroups + gi];    // first spoke | spokes << 16 (build_centre_windows, at plan creation)
-    const int jstart = (int)(wnd & 0xffffu), cnt = (int)(wnd >> 16);
+    const unsigned wnd = p.cen_win[win * p.cen_nblocks + greal];  // first spoke | spokes << 16 (build_centre_windows, at plan creation)
+    int jstart = (int)(wnd & 0xffffu), cnt = (int)(wnd >> 16);
+    if (nparts > 1) {                                           // this item's share of the block's window: part `part` of `nparts` equal runs
+        const int per = (cnt + nparts - 1) / nparts;            // (nparts <= 4: a handful of scalar instructions)
+        jstart += part * per;
+        if (jstart >= npe) jstart -= npe;
+        cnt = max(0, min(per, cnt - part * per));
+    }
 
     // (wave-uniform floats: a conversion or an addition is a vector instruction whatever its operands, so its result is moved to a
     // scalar register by hand; seven vector registers less over the item)
@@ -330,11 +328,7 @@ grid_centre_kernel(const GridParams p)
     //      done with), eight values at a time, value k of lane l at [k][l] of rows 64 + LPV floats long, so that neither the writes
     //      nor the reads below meet on a bank; lane (k, coil pair) adds the 64 / LPV partial sums of value k in lane order and adds
     //      the result to the grid
-    if (++sub == kCenBatch) {
-        sub = 0u;
-        draw = (unsigned)__builtin_amdgcn_readfirstlane((int)tk);                         // (asked for kCenBatch items ago)
-    }
-    item = draw * kCenBatch + sub;
+    item = (unsigned)__builtin_amdgcn_readfirstlane((int)tk);   // (the next ticket: asked for a whole item ago)
     {
         constexpr int ROW = 64 + LPV;
         float *sc = reinterpret_cast<float *>(&L);
@@ -358,12 +352,31 @@ grid_centre_kernel(const GridParams p)
             }
         }
         asm volatile("" ::: "memory");
-        if (lane < NV * LPV) {
-#if !TRON_CEN_GOLD_EARLY
+        if (nparts > 1) {
+            // A busy block is worked on as `nparts` items (runs of its window): each leaves its sums in a slot of its own, and
+            // whichever finishes LAST adds all of them up in part order and adds the total to the grid -- the same bits whatever the
+            // order the parts finished in.  (The parts of a block are drawn from one XCD's counter: one L2.)
+            const size_t slot = ((size_t)z * chunks + (rest - zi * chunks)) * (size_t)p.cen_nheavy + (size_t)heavy;
+            float *const ps = p.cen_parts + slot * (4 * 64);
+            // (device-scope stores and loads, which pass the caches that are not coherent across the chip, and a wait for the stores'
+            // acknowledgement before the counter is touched.  A release fence would do the same and write back the whole L2 besides,
+            // the grid lines this kernel has just dirtied included: measured 872 us per launch instead of 104.)
+            if (lane < NV * LPV) __hip_atomic_store(ps + part * 64 + lane, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            unsigned done = 0u;
+            if (lane == 0) done = atomicAdd(p.cen_ticket + kCenTicketWords + slot, 1u);
+            done = (unsigned)__builtin_amdgcn_readfirstlane((int)done);
+            if (done + 1u == (unsigned)nparts) {
+                if (lane < NV * LPV) {
+                    float total = 0.f;
+                    for (int q = 0; q < nparts; ++q) total += __hip_atomic_load(ps + q * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    float *const gpt = grid_point();
+                    if (gpt) *gpt = fmaf(total, p.scale, *gpt);     // src/tron.cu:532-534
+                }
+            }
+        } else if (lane < NV * LPV) {
             float *const gpt = grid_point();
-            const float gold = gpt ? *gpt : 0.f;                // what the arc kernel stored there (three registers less over the item than asking early)
-#endif
-            if (gpt) *gpt = fmaf(sum, p.scale, gold);           // src/tron.cu:532-534
+            if (gpt) *gpt = fmaf(sum, p.scale, *gpt);               // src/tron.cu:532-534; what the arc kernel stored there + this block
         }
     }
     CPROF_MARK(4);
@@ -391,8 +404,8 @@ static hipError_t launch_centre_lpv(const GridParams &p, hipStream_t s)
     const int per_chunk = ONE ? 1 : 2 * LPV;
     const int chunks = (p.nchan - p.coil0 + per_chunk - 1) / per_chunk;
     const long long per_xcd = (long long)p.cen_ngroups * chunks * ((p.nslices + 7) / 8);   // items of the busiest XCD: slice z lives on XCD z % 8
-    const long long wgs = std::min<long long>(wgs_per_xcd[dev], (per_xcd + kCenWaves * kCenBatch - 1) / (kCenWaves * kCenBatch));
-    if ((e = hipMemsetAsync(p.cen_ticket, 0, 8 * 16 * sizeof(unsigned), s)) != hipSuccess) return e;
+    const long long wgs = std::min<long long>(wgs_per_xcd[dev], (per_xcd + kCenWaves - 1) / kCenWaves);
+    if ((e = hipMemsetAsync(p.cen_ticket, 0, (kCenTicketWords + (size_t)p.nslices * chunks * p.cen_nheavy) * sizeof(unsigned), s)) != hipSuccess) return e;
     GridParams q = p;
     for (int i = 0; i < 2; ++i) {                               // XCDs below nslices % 8 hold one slice more than the others
         const unsigned zc = (unsigned)(p.nslices / 8 + 1 - i) * (unsigned)chunks;
@@ -406,7 +419,7 @@ static hipError_t launch_centre_lpv(const GridParams &p, hipStream_t s)
 // Adds the samples |r| < p.inner_r0 to the grid the arc kernel has stored (same stream, behind it); the same plans as the arc kernel.
 hipError_t launch_grid_centre(const GridParams &p, int half_in, hipStream_t s)
 {
-    if (p.out_p != 1 || p.inner_r0 <= 0 || p.inner_r0 > 16 || p.W > 3.0f || !p.cen_win || !p.cen_order || !p.cen_cs || !p.cen_grec || !p.cen_ticket || !p.kb_lut || p.npe > 65535)
+    if (p.out_p != 1 || p.inner_r0 <= 0 || p.inner_r0 > 16 || p.W > 3.0f || !p.cen_win || !p.cen_order || !p.cen_cs || !p.cen_grec || !p.cen_ticket || (p.cen_nheavy > 0 && !p.cen_parts) || !p.kb_lut || p.npe > 65535)
         return hipErrorInvalidValue;
     const int nc = p.nchan - p.coil0;
     if (nc == 1) return half_in ? launch_centre_lpv<1, true, true>(p, s) : launch_centre_lpv<1, true, false>(p, s);

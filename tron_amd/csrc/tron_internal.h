@@ -89,10 +89,13 @@ struct GridParams {
     const unsigned short *cen_order;   // [window][npe] window-relative spoke index, ascending line angle (mod pi)
     const uint32_t *cen_win;           // [window][cen_ngroups] the block's run of that list: first entry | entries << 16 (circular)
     const float2 *cen_cs;              // [window][npe] (cos, sin) of that spoke
-    const uint4 *cen_grec;             // [cen_ngroups][2] blocks of the origin-centred 32 x 32 square a sample |r| < inner_r0 reaches, nearest first:
-                                       // (col | row << 8, largest such |r|, -, -), (band of the four points as masks over |r|)
+    const uint4 *cen_grec;             // [cen_ngroups][2] work units of the centre kernel, busiest first: a 2x2 block of the origin-centred 32 x 32 square that
+                                       // a sample |r| < inner_r0 reaches, or one of up to four parts of a busy block's window:
+                                       // (col | row << 8, largest such |r|, part | parts << 8 | busy-block index << 16, block index), (band of the four points as masks over |r|)
+    int cen_nblocks, cen_nheavy;       // blocks (cen_win's row length), blocks worked on in parts
+    float *cen_parts;                  // [slice][coil chunk][busy block][4][64] the parts' sums until the last one adds them up
     unsigned cen_magic_zc[2], cen_magic_chunks;    // set by the launcher: division by an XCD's (slice, chunk) pairs / by the coil chunks as a multiplication
-    unsigned *cen_ticket;              // [8][16] work counters of the centre kernel, one per XCD (zeroed by its launcher)
+    unsigned *cen_ticket;              // [8][16] work counters of the centre kernel, one per XCD, then [slice][coil chunk][busy block] parts done (zeroed by its launcher)
     int cen_ngroups;
 };
 

@@ -305,11 +305,15 @@ int adjoint_run_raw(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, 
                     if (p->centre_kernel) {
                         const size_t woff = win0 * (size_t)d.npe1work;
                         g.cen_order = p->d_cen_order + woff;
-                        g.cen_win = p->d_cen_win + win0 * (size_t)p->cen_ngroups;
+                        g.cen_win = p->d_cen_win + win0 * (size_t)p->cen_nblocks;
                         g.cen_cs = p->d_cen_cs + woff;
-                        g.cen_grec = p->d_cen_grec;
+                        const bool parts = cz < p->cen_parts_below && p->cen_nheavy > 0;      // small launch: the busy blocks in parts
+                        g.cen_grec = parts ? p->d_cen_grec_parts : p->d_cen_grec;
                         g.cen_ticket = p->d_cen_ticket;
-                        g.cen_ngroups = p->cen_ngroups;
+                        g.cen_parts = p->d_cen_parts;
+                        g.cen_nblocks = p->cen_nblocks;
+                        g.cen_nheavy = parts ? p->cen_nheavy : 0;
+                        g.cen_ngroups = parts ? p->cen_nunits_parts : p->cen_ngroups;
                         HIP_TRY(launch_grid_centre(g, p->cfg.input_half, st));
                     } else {
                         if (p->inner_beside) HIP_TRY(hipStreamWaitEvent(st, p->ev_inner[1], 0));

@@ -97,6 +97,8 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
         return fail(TRON_ERR_HIP, "device %d requested but %d HIP device(s) present", cfg->device, ndev);
     HIP_TRY(hipSetDevice(cfg->device));
     (void)hipGetLastError();       // a stale error of an earlier, failed call must not be reported by this one
+    HIP_TRY(hipFree(nullptr));     // (the runtime's own start-up, timed apart from the code objects)
+    const double t_hipinit = since();
     // make every code object resident before anything is queued on a non-blocking stream
     HIP_TRY(warm_kernels());
     HIP_TRY(warm_grid_binned());
@@ -264,12 +266,43 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
                         }
                         groups.swap(kept);
                     }
-                    p->cen_ngroups = (int)groups.size();
-                    if ((rc = upload(&p->d_cen_grec, grec.data(), grec.size() * sizeof(uint32_t)))) return bail(rc);
-                    if (hipMalloc(reinterpret_cast<void **>(&p->d_cen_ticket), 8 * 16 * sizeof(unsigned)) != hipSuccess) return bail(fail(TRON_ERR_NOMEM, "centre kernel work counters"));
                     std::vector<uint32_t> wnd(nwin * groups.size());
                     build_centre_windows(phi.data(), nwin, npe, groups.data(), (int)groups.size(), cfg->kernwidth, wnd.data());
                     if ((rc = upload(&p->d_cen_win, wnd.data(), wnd.size() * sizeof(uint32_t)))) return bail(rc);
+                    // A block next to the origin meets every spoke, one at the rim 50: a busy block is worked on in up to four PARTS (runs
+                    // of its window, ~128 spokes each), so that no work item is much longer than the others -- the longest one is the
+                    // floor under a launch (40 us for a whole window of 400 spokes, against 55 us for a launch of 32 slices).
+                    // Launches of fewer than 64 slices only (TRON_CEN_PART_BELOW): 32 slices 56 -> 41 us; a launch of 128 has enough
+                    // items to hide its longest ones and pays for the parts' hand-over instead (115 -> 122 us), so it takes whole blocks.
+                    const int nblocks = (int)groups.size();
+                    std::vector<uint32_t> units, whole;
+                    int nheavy = 0;
+                    for (int g = 0; g < nblocks; ++g) {
+                        double mean = 0.0;
+                        for (size_t w = 0; w < nwin; ++w) mean += (double)(wnd[w * nblocks + g] >> 16);
+                        mean /= (double)nwin;
+                        static const int per_part = tuning_env("TRON_CEN_PART") ? std::max(16, atoi(tuning_env("TRON_CEN_PART"))) : 200;   // tuning knob
+                        const int parts = std::max(1, std::min(4, (int)ceil(mean / per_part)));
+                        const int heavy = parts > 1 ? nheavy++ : 0;
+                        const uint32_t *r = &grec[8 * (size_t)g];
+                        for (int q = 0; q < parts; ++q) {
+                            const uint32_t rec[8] = {r[0], r[1], (uint32_t)q | ((uint32_t)parts << 8) | ((uint32_t)heavy << 16), (uint32_t)g, r[4], r[5], r[6], r[7]};
+                            units.insert(units.end(), rec, rec + 8);
+                        }
+                        const uint32_t rec[8] = {r[0], r[1], 1u << 8, (uint32_t)g, r[4], r[5], r[6], r[7]};
+                        whole.insert(whole.end(), rec, rec + 8);
+                    }
+                    p->cen_nblocks = nblocks;
+                    p->cen_nheavy = nheavy;
+                    p->cen_ngroups = nblocks;
+                    p->cen_nunits_parts = (int)(units.size() / 8);
+                    if ((rc = upload(&p->d_cen_grec, whole.data(), whole.size() * sizeof(uint32_t)))) return bail(rc);
+                    if ((rc = upload(&p->d_cen_grec_parts, units.data(), units.size() * sizeof(uint32_t)))) return bail(rc);
+                    if (const char *e = tuning_env("TRON_CEN_PART_BELOW")) p->cen_parts_below = atoi(e);
+                    const size_t slots = (size_t)p->chunk_cap * (size_t)(p->nchan <= 4 ? 1 : (p->nchan + 7) / 8) * (size_t)nheavy;
+                    if (hipMalloc(reinterpret_cast<void **>(&p->d_cen_ticket), (8 * 16 + slots) * sizeof(unsigned)) != hipSuccess ||
+                        (slots > 0 && hipMalloc(reinterpret_cast<void **>(&p->d_cen_parts), slots * 4 * 64 * sizeof(float)) != hipSuccess))
+                        return bail(fail(TRON_ERR_NOMEM, "centre kernel work counters"));
                 }
                 std::vector<float> scs(2 * order.size());
                 for (size_t w = 0; w < nwin; ++w)
@@ -483,6 +516,7 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
         printf("tronhip: gridding kernel: %s\n", tron_plan_grid_kernel_name(p));
         printf("tronhip: plan %.3f s = HIP runtime + code objects %.3f, tables %.3f (of which the arc kernel's run tables %.3f), work buffers %.3f\n",
                since(), t_runtime, t_tables - t_runtime, t_arc1 - t_arc0, t_work - t_tables);
+    if (cfg->verbose) printf("tronhip: of the start-up, the HIP runtime itself %.3f s, loading the code objects %.3f s\n", t_hipinit, t_runtime - t_hipinit);
     }
     if (const char *se = tuning_env("TRON_SYNC_EACH")) p->sync_each = atoi(se) != 0;
     p->debug_skip = 0;
@@ -528,7 +562,9 @@ extern "C" int tron_plan_destroy(tron_plan *p)
     hipFree(p->d_cen_win);
     hipFree(p->d_cen_cs);
     hipFree(p->d_cen_grec);
+    hipFree(p->d_cen_grec_parts);
     hipFree(p->d_cen_ticket);
+    hipFree(p->d_cen_parts);
     hipFree(p->d_tile_order32_split);
     hipFree(p->d_split_slots);
     hipFree(p->d_partial);

@@ -99,6 +99,9 @@ struct tron_plan {
     float2 *d_cen_cs = nullptr;
     uint4 *d_cen_grec = nullptr;
     unsigned *d_cen_ticket = nullptr;
+    float *d_cen_parts = nullptr;
+    uint4 *d_cen_grec_parts = nullptr;          // the work units with the busy blocks in parts (launches of fewer than cen_parts_below slices)
+    int cen_nblocks = 0, cen_nheavy = 0, cen_nunits_parts = 0, cen_parts_below = 64;
     int cen_ngroups = 0;
     bool centre_kernel = true;            // TRON_CENTRE_KERNEL=binned (A/B): the inner tile on the binned kernel + grid_reduce_parts_kernel, as in round 3
     int arc_cap = 0, arc_nrec = 0, arc_zper = 1;
