@@ -49,10 +49,15 @@ if [ -f tron_amd/lib/libtronhip_aprof.so ]; then
   cp tron_amd/lib/libtronhip.so /tmp/orig.so; cp tron_amd/lib/libtronhip_aprof.so tron_amd/lib/libtronhip.so
   WARM=20 python tools/arcprof.py 8 128 > $out/phase_clock.log 2>&1; cp /tmp/orig.so tron_amd/lib/libtronhip.so
 fi
+if [ -f tron_amd/lib/libtronhip_cprof.so ]; then
+  cp tron_amd/lib/libtronhip.so /tmp/orig.so; cp tron_amd/lib/libtronhip_cprof.so tron_amd/lib/libtronhip.so
+  python tools/cenprof.py 8 128 > $out/centre_phase_clock.log 2>&1; python tools/cenprof.py 8 32 >> $out/centre_phase_clock.log 2>&1; cp /tmp/orig.so tron_amd/lib/libtronhip.so
+fi
 python tools/hostbench.py 8 256 > $out/hostbench.log 2>&1; python tools/hostbench.py 8 256 --half >> $out/hostbench.log 2>&1
 python tools/wholebody.py /tmp > $out/wholebody_cli.log 2>&1
 python tools/fwdbench.py 8 64 fast > $out/fwdbench.log 2>&1
 for n in 8 6 4 2 1; do python tools/gridbench.py $n 128 fast 5 2>&1 | tail -1; done > $out/gridbench.log
+timeout 120 tools/probe/cumask_main > $out/cu_mask_probe.txt 2>&1
 TRON_GRID_KERNEL=binned python tools/gridbench.py 8 128 fast 5 2>&1 | tail -1 >> $out/gridbench.log
 TRON_DUAL_STREAM=0 bash tools/ktrace.sh $tag tools/gridbench.py 8 128 fast 3 > $out/ktrace_one_lane.log 2>&1
 WARM=20 python tools/gridbench.py 8 128 fast 20 2>&1 | tail -1 > $out/gridbench_warm.log
