@@ -81,39 +81,129 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+#ifndef TRON_FFT_PLAIN
+// The butterflies in packed fp32 (one v_pk_* instruction per complex operation), with the half swaps and sign flips of the
+// multiplications by +-i, (1 + i) / sqrt2 and by a twiddle expressed as operand modifiers (op_sel / neg) instead of moves: hipcc
+// packs the plain complex adds by itself but spent 52 v_mov and 64 unpacked operations per 512-point line on the rest
+// (315 -> 170 VALU instructions per line).  Every result is the same float operation on the same operands as in dft8_inv /
+// cmul above: bit-identical output.
+__device__ __forceinline__ v2f pk_add_i(const v2f a, const v2f b)          // a + i b = (a.x - b.y, a.y + b.x)
+{
+    v2f d;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ v2f pk_sub_i(const v2f a, const v2f b)          // a - i b = (a.x + b.y, a.y - b.x)
+{
+    v2f d;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ v2f pk_xmy_xpy(const v2f a)                     // (a.x - a.y, a.x + a.y)
+{
+    v2f d;
+    asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[0,1]" : "=v"(d) : "v"(a));
+    return d;
+}
+__device__ __forceinline__ v2f pk_xpy_xmy(const v2f a)                     // (a.x + a.y, a.x - a.y)
+{
+    v2f d;
+    asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a));
+    return d;
+}
+__device__ __forceinline__ v2f pk_scale(const v2f a, const float h)        // (h a.x, h a.y)
+{
+    v2f d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(d) : "v"(a), "v"((v2f){h, h}));
+    return d;
+}
+__device__ __forceinline__ v2f pk_scale_nlo(const v2f a, const float h)    // (-h a.x, h a.y)
+{
+    v2f d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(d) : "v"(a), "v"((v2f){h, h}));
+    return d;
+}
+__device__ __forceinline__ v2f pk_cmul(const v2f a, const v2f w)           // (a.x w.x - a.y w.y, a.x w.y + a.y w.x), rounded as cmul
+{
+    v2f p, d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(p) : "v"(a), "v"(w));                              // (a.y w.y, a.y w.x)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] neg_lo:[0,0,1]" : "=v"(d) : "v"(a), "v"(w), "v"(p));             // (a.x w.x - p.x, a.x w.y + p.y)
+    return d;
+}
+
+__device__ __forceinline__ void dft8_inv_pk(v2f v[8])
+{
+    const float h = 0.70710678118654752440f;
+    const v2f e0 = v[0] + v[4], e1 = v[0] - v[4], e2 = v[2] + v[6], d26 = v[2] - v[6];
+    const v2f o0 = v[1] + v[5], o1 = v[1] - v[5], o2 = v[3] + v[7], d37 = v[3] - v[7];
+    const v2f E0 = e0 + e2, E2 = e0 - e2, E1 = pk_add_i(e1, d26), E3 = pk_sub_i(e1, d26);
+    const v2f O0 = o0 + o2, O2 = o0 - o2, O1 = pk_add_i(o1, d37), O3 = pk_sub_i(o1, d37);
+    const v2f T1 = pk_scale(pk_xmy_xpy(O1), h);                                // O1 (1 + i) / sqrt2
+    const v2f T3 = pk_scale_nlo(pk_xpy_xmy(O3), h);                            // O3 (-1 + i) / sqrt2
+    v[0] = E0 + O0; v[4] = E0 - O0;
+    v[1] = E1 + T1; v[5] = E1 - T1;
+    v[2] = pk_add_i(E2, O2); v[6] = pk_sub_i(E2, O2);
+    v[3] = E3 + T3; v[7] = E3 - T3;
+}
+#endif
+
 // 512-point inverse DFT of one line held as v[q] = x[64*q + lane]; returns v[j2] = X[lane + 64*j2].
 // tw[k] = exp(+2*pi*i*k/512).  xch: this wave's private LDS exchange region.
-__device__ __forceinline__ void fft512_inv(float2 v[8], float2 *xch, const float2 *__restrict__ tw, const int lane)
+__device__ __forceinline__ void fft512_inv(float2 vf[8], float2 *xch, const float2 *__restrict__ tw, const int lane)
 {
+#ifndef TRON_FFT_PLAIN
+    v2f v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = (v2f){vf[q].x, vf[q].y};
+    auto twv = [&](const int i) { const float2 t = tw[i]; return (v2f){t.x, t.y}; };
+#define TRON_DFT8(x) dft8_inv_pk(x)
+#define TRON_CMUL(a, i) pk_cmul(a, twv(i))
+#define TRON_ST(i, a) xch[i] = make_float2((a).x, (a).y)
+#define TRON_LD(a) ([&]() { const float2 t_ = lds_ld64(a); return (v2f){t_.x, t_.y}; }())
+#else
+    float2 *v = vf;
+#define TRON_DFT8(x) dft8_inv(x)
+#define TRON_CMUL(a, i) cmul(a, tw[i])
+#define TRON_ST(i, a) xch[i] = (a)
+#define TRON_LD(a) lds_ld64(a)
+#endif
     // stage A: DFT over n1 (stride 64), twiddle w512^(n2*k1), exchange
-    dft8_inv(v);
+    TRON_DFT8(v);
 #pragma unroll
-    for (int k1 = 1; k1 < 8; ++k1) v[k1] = cmul(v[k1], tw[(lane * k1) & 511]);
+    for (int k1 = 1; k1 < 8; ++k1) v[k1] = TRON_CMUL(v[k1], (lane * k1) & 511);
 #pragma unroll
-    for (int k1 = 0; k1 < 8; ++k1) xch[k1 * kPA + lane] = v[k1];
+    for (int k1 = 0; k1 < 8; ++k1) TRON_ST(k1 * kPA + lane, v[k1]);
     wave_lds_fence();
     const unsigned xa = lds_addr(xch);
     // stage B: thread (k1 = lane>>3, m2 = lane&7): DFT over m1, twiddle w64^(m2*j1)
     {
         const int k1 = lane >> 3, m2 = lane & 7;
 #pragma unroll
-        for (int m1 = 0; m1 < 8; ++m1) v[m1] = lds_ld64(xa + (unsigned)((k1 * kPA + m1 * 8 + m2) * (int)sizeof(float2)));
+        for (int m1 = 0; m1 < 8; ++m1) v[m1] = TRON_LD(xa + (unsigned)((k1 * kPA + m1 * 8 + m2) * (int)sizeof(float2)));
         wave_lds_fence();                                                  // stage B's stores reuse the region at another pitch
-        dft8_inv(v);
+        TRON_DFT8(v);
 #pragma unroll
-        for (int j1 = 1; j1 < 8; ++j1) v[j1] = cmul(v[j1], tw[(8 * m2 * j1) & 511]);
+        for (int j1 = 1; j1 < 8; ++j1) v[j1] = TRON_CMUL(v[j1], (8 * m2 * j1) & 511);
 #pragma unroll
-        for (int j1 = 0; j1 < 8; ++j1) xch[xch2_index(j1, k1, m2)] = v[j1];   // B[j1][k1*8 + m2]
+        for (int j1 = 0; j1 < 8; ++j1) TRON_ST(xch2_index(j1, k1, m2), v[j1]);   // B[j1][k1*8 + m2]
     }
     wave_lds_fence();
     // stage C: thread (k1 = lane&7, j1 = lane>>3): DFT over m2 -> X[k1 + 8*j1 + 64*j2]
     {
         const int k1 = lane & 7, j1 = lane >> 3;
 #pragma unroll
-        for (int m2 = 0; m2 < 8; ++m2) v[m2] = lds_ld64(xa + (unsigned)(xch2_index(j1, k1, m2) * (int)sizeof(float2)));
+        for (int m2 = 0; m2 < 8; ++m2) v[m2] = TRON_LD(xa + (unsigned)(xch2_index(j1, k1, m2) * (int)sizeof(float2)));
         wave_lds_fence();                                                  // the next line's stage A stores come after these loads
-        dft8_inv(v);
+        TRON_DFT8(v);
     }
+#ifndef TRON_FFT_PLAIN
+#pragma unroll
+    for (int q = 0; q < 8; ++q) vf[q] = make_float2(v[q].x, v[q].y);
+#endif
+#undef TRON_DFT8
+#undef TRON_CMUL
+#undef TRON_ST
+#undef TRON_LD
 }
 
 struct Fft512Params {
