@@ -15,6 +15,7 @@
 // exchanges through a private 4.6 KiB LDS region; LDS instructions of one wave execute in order, so
 // the line needs no barrier.
 #include "tron_device.h"
+#include "tron_host.h"
 
 namespace tron {
 
@@ -81,12 +82,11 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-#ifndef TRON_FFT_PLAIN
 // The butterflies in packed fp32 (one v_pk_* instruction per complex operation), with the half swaps and sign flips of the
 // multiplications by +-i, (1 + i) / sqrt2 and by a twiddle expressed as operand modifiers (op_sel / neg) instead of moves: hipcc
 // packs the plain complex adds by itself but spent 52 v_mov and 64 unpacked operations per 512-point line on the rest
 // (315 -> 170 VALU instructions per line).  Every result is the same float operation on the same operands as in dft8_inv /
-// cmul above: bit-identical output.
+// cmul above: bit-identical output (dft8_inv / cmul stay as the readable statement of what is computed).
 __device__ __forceinline__ v2f pk_add_i(const v2f a, const v2f b)          // a + i b = (a.x - b.y, a.y + b.x)
 {
     v2f d;
@@ -145,65 +145,70 @@ __device__ __forceinline__ void dft8_inv_pk(v2f v[8])
     v[2] = pk_add_i(E2, O2); v[6] = pk_sub_i(E2, O2);
     v[3] = E3 + T3; v[7] = E3 - T3;
 }
-#endif
 
-// 512-point inverse DFT of one line held as v[q] = x[64*q + lane]; returns v[j2] = X[lane + 64*j2].
-// tw[k] = exp(+2*pi*i*k/512).  xch: this wave's private LDS exchange region.
-__device__ __forceinline__ void fft512_inv(float2 vf[8], float2 *xch, const float2 *__restrict__ tw, const int lane)
+// 512-point inverse DFT of one line held as v[q] = x[64*q + lane]; returns v[j2] = X[lane + 64*j2].  xch: this wave's private
+// LDS exchange region.  twa(k1) = w512^(lane k1), twb(j1) = w512^(8 (lane & 7) j1), w512 = exp(+2 pi i / 512): both depend on
+// the lane only, so a kernel that transforms many lines per wave can keep them in registers (fft512_lane_twiddles).
+template <class TwA, class TwB>
+__device__ __forceinline__ void fft512_inv_tw(float2 vf[8], float2 *xch, const TwA &twa, const TwB &twb, const int lane)
 {
-#ifndef TRON_FFT_PLAIN
     v2f v[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) v[q] = (v2f){vf[q].x, vf[q].y};
-    auto twv = [&](const int i) { const float2 t = tw[i]; return (v2f){t.x, t.y}; };
-#define TRON_DFT8(x) dft8_inv_pk(x)
-#define TRON_CMUL(a, i) pk_cmul(a, twv(i))
-#define TRON_ST(i, a) xch[i] = make_float2((a).x, (a).y)
-#define TRON_LD(a) ([&]() { const float2 t_ = lds_ld64(a); return (v2f){t_.x, t_.y}; }())
-#else
-    float2 *v = vf;
-#define TRON_DFT8(x) dft8_inv(x)
-#define TRON_CMUL(a, i) cmul(a, tw[i])
-#define TRON_ST(i, a) xch[i] = (a)
-#define TRON_LD(a) lds_ld64(a)
-#endif
+    auto st = [&](const int i, const v2f a) { xch[i] = make_float2(a.x, a.y); };
+    auto ld = [&](const unsigned a) { const float2 t = lds_ld64(a); return (v2f){t.x, t.y}; };
     // stage A: DFT over n1 (stride 64), twiddle w512^(n2*k1), exchange
-    TRON_DFT8(v);
+    dft8_inv_pk(v);
 #pragma unroll
-    for (int k1 = 1; k1 < 8; ++k1) v[k1] = TRON_CMUL(v[k1], (lane * k1) & 511);
+    for (int k1 = 1; k1 < 8; ++k1) v[k1] = pk_cmul(v[k1], twa(k1));
 #pragma unroll
-    for (int k1 = 0; k1 < 8; ++k1) TRON_ST(k1 * kPA + lane, v[k1]);
+    for (int k1 = 0; k1 < 8; ++k1) st(k1 * kPA + lane, v[k1]);
     wave_lds_fence();
     const unsigned xa = lds_addr(xch);
     // stage B: thread (k1 = lane>>3, m2 = lane&7): DFT over m1, twiddle w64^(m2*j1)
     {
         const int k1 = lane >> 3, m2 = lane & 7;
 #pragma unroll
-        for (int m1 = 0; m1 < 8; ++m1) v[m1] = TRON_LD(xa + (unsigned)((k1 * kPA + m1 * 8 + m2) * (int)sizeof(float2)));
+        for (int m1 = 0; m1 < 8; ++m1) v[m1] = ld(xa + (unsigned)((k1 * kPA + m1 * 8 + m2) * (int)sizeof(float2)));
         wave_lds_fence();                                                  // stage B's stores reuse the region at another pitch
-        TRON_DFT8(v);
+        dft8_inv_pk(v);
 #pragma unroll
-        for (int j1 = 1; j1 < 8; ++j1) v[j1] = TRON_CMUL(v[j1], (8 * m2 * j1) & 511);
+        for (int j1 = 1; j1 < 8; ++j1) v[j1] = pk_cmul(v[j1], twb(j1));
 #pragma unroll
-        for (int j1 = 0; j1 < 8; ++j1) TRON_ST(xch2_index(j1, k1, m2), v[j1]);   // B[j1][k1*8 + m2]
+        for (int j1 = 0; j1 < 8; ++j1) st(xch2_index(j1, k1, m2), v[j1]);  // B[j1][k1*8 + m2]
     }
     wave_lds_fence();
     // stage C: thread (k1 = lane&7, j1 = lane>>3): DFT over m2 -> X[k1 + 8*j1 + 64*j2]
     {
         const int k1 = lane & 7, j1 = lane >> 3;
 #pragma unroll
-        for (int m2 = 0; m2 < 8; ++m2) v[m2] = TRON_LD(xa + (unsigned)(xch2_index(j1, k1, m2) * (int)sizeof(float2)));
+        for (int m2 = 0; m2 < 8; ++m2) v[m2] = ld(xa + (unsigned)(xch2_index(j1, k1, m2) * (int)sizeof(float2)));
         wave_lds_fence();                                                  // the next line's stage A stores come after these loads
-        TRON_DFT8(v);
+        dft8_inv_pk(v);
     }
-#ifndef TRON_FFT_PLAIN
 #pragma unroll
     for (int q = 0; q < 8; ++q) vf[q] = make_float2(v[q].x, v[q].y);
-#endif
-#undef TRON_DFT8
-#undef TRON_CMUL
-#undef TRON_ST
-#undef TRON_LD
+}
+
+// ... with the twiddles read from the table tw[k] = exp(+2*pi*i*k/512) (LDS or global memory) as they are needed
+__device__ __forceinline__ void fft512_inv(float2 vf[8], float2 *xch, const float2 *__restrict__ tw, const int lane)
+{
+    auto twv = [&](const int i) { const float2 t = tw[i & 511]; return (v2f){t.x, t.y}; };
+    const int m2 = lane & 7;
+    fft512_inv_tw(vf, xch, [&](const int k1) { return twv(lane * k1); }, [&](const int j1) { return twv(8 * m2 * j1); }, lane);
+}
+
+// the fourteen twiddles of a lane: twa[k1], twb[j1] for fft512_inv_tw (index 0 unused)
+__device__ __forceinline__ void fft512_lane_twiddles(const float2 *__restrict__ tw, const int lane, v2f (&twa)[8], v2f (&twb)[8])
+{
+    const int m2 = lane & 7;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+        const float2 a = tw[(lane * k) & 511], b = tw[(8 * m2 * k) & 511];
+        twa[k] = (v2f){a.x, a.y};
+        twb[k] = (v2f){b.x, b.y};
+    }
+    twa[0] = twb[0] = (v2f){1.f, 0.f};
 }
 
 struct Fft512Params {
@@ -380,14 +385,13 @@ __global__ void __launch_bounds__(256) fft512_rows_kernel(const Fft512Params p)
 // column block get workgroup ids 8 apart -- the same XCD, close in time -- so that XCD's L2 merges their 8-byte pieces of a
 // pixel's nchan * 8 bytes before they reach HBM.
 template <bool SINGLE, int LPW, bool COILS = false>
-__global__ void __launch_bounds__(256, 4) fft512_cols_post_kernel(const Fft512Params p)
+__global__ void __launch_bounds__(256, 3) fft512_cols_post_kernel(const Fft512Params p)
 {
     static_assert(!COILS || SINGLE, "uncombined output keeps the complex value");
     constexpr int kCols = 4 * LPW;
     constexpr int kTileElems = kFKeep * (kCols + 1);       // [kept row][col in block], +1 pad
-    constexpr int kLdsElems = kTileElems > 4 * kXch + 4 * kF ? kTileElems : 4 * kXch + 4 * kF;
-    __shared__ float2 s_t[kLdsElems];                      // exchange regions | line buffers, then the output tile
-    __shared__ float2 s_tw[kF];
+    constexpr int kLdsElems = kTileElems > 4 * kXch + 8 * kF ? kTileElems : 4 * kXch + 8 * kF;
+    __shared__ float2 s_t[kLdsElems];                      // exchange regions | two line buffers per wave, then the output tile
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int z = blockIdx.y;
     // COILS: blockIdx.x = (column block & 7) | coil << 3 | (column block >> 3) * 8 nchan
@@ -396,7 +400,7 @@ __global__ void __launch_bounds__(256, 4) fft512_cols_post_kernel(const Fft512Pa
     const int col0 = cblk * kCols;
     const int nloop = COILS ? 1 : p.nchan;
     float2 *xch = s_t + wave * kXch;
-    float2 *lbuf = s_t + 4 * kXch + wave * kF;
+    const unsigned lbuf = lds_addr(s_t + 4 * kXch + wave * 2 * kF);           // this wave's two line buffers
     float val[LPW][4];
     float2 single[SINGLE ? LPW : 1][4];
 #pragma unroll
@@ -406,36 +410,45 @@ __global__ void __launch_bounds__(256, 4) fft512_cols_post_kernel(const Fft512Pa
             val[j][jj] = 0.f;
             if (SINGLE) single[j][jj] = make_float2(0.f, 0.f);
         }
+    // The pass is bound by memory latency, not arithmetic (packed butterflies: -27 % instructions, -1 % time): every wave keeps TWO
+    // lines (4 KiB each, contiguous) on their way global -> LDS by LDS-DMA while it transforms a third.  The LDS for the second
+    // buffer comes from the twiddle table, whose fourteen entries per lane wait in registers instead (no load between a copy's
+    // issue and its use: the counters are in-order), and from running three workgroups per CU, not four.
+    v2f twa[8], twb[8];
+    fft512_lane_twiddles(p.tw, lane, twa, twb);
     const float2 *base = p.in + ((size_t)z * p.nchan + coil) * (size_t)kFKeep * kF + (size_t)(col0 + wave * LPW) * kF;
-    auto copy_line = [&](const float2 *line) {
+    const int nlines = nloop * LPW;                         // line i = (coil i / LPW, column i % LPW) of this wave
+    auto copy_line = [&](const int i) {
         // the intermediate is written once by pass 1 and read once here: streaming (non-temporal) accesses on both sides
+        const float2 *line = base + (size_t)(i / LPW) * kFKeep * kF + (size_t)(i % LPW) * kF;
+        const unsigned dst = lbuf + (unsigned)((i & 1) * kF * (int)sizeof(float2));
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
 #ifndef TRON_FFT_NO_NT
-            lds_dma16_nt(line + k * 128 + 2 * lane, lds_addr(lbuf) + (unsigned)(k * 128 * sizeof(float2)));
+            lds_dma16_nt(line + k * 128 + 2 * lane, dst + (unsigned)(k * 128 * sizeof(float2)));
 #else
-            lds_dma16(line + k * 128 + 2 * lane, lds_addr(lbuf) + (unsigned)(k * 128 * sizeof(float2)));
+            lds_dma16(line + k * 128 + 2 * lane, dst + (unsigned)(k * 128 * sizeof(float2)));
 #endif
         }
     };
-    copy_line(base);
-    for (int i = threadIdx.x; i < kF; i += 256) s_tw[i] = p.tw[i];
-    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the twiddles are in: from here on only the copies count
+    copy_line(0);
+    if (nlines > 1) copy_line(1);
     for (int c = 0; c < nloop; ++c) {
 #pragma unroll
         for (int j = 0; j < LPW; ++j) {
+            const int i = c * LPW + j;
             float2 v[8];
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this line has landed
+            if (i + 1 < nlines) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // line i has landed (the four pieces of line i + 1 may still fly)
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned src = lbuf + (unsigned)((i & 1) * kF * (int)sizeof(float2));
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = lds_ld64(lds_addr(lbuf) + (unsigned)((q * 64 + lane) * (int)sizeof(float2)));
-            {
-                const int jn = (j + 1) % LPW, cn = c + (j == LPW - 1 ? 1 : 0);
-                if (cn < nloop) {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the buffer has been read
-                    copy_line(base + (size_t)cn * kFKeep * kF + (size_t)jn * kF);
-                }
+            for (int q = 0; q < 8; ++q) v[q] = lds_ld64(src + (unsigned)((q * 64 + lane) * (int)sizeof(float2)));
+            if (i + 2 < nlines) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the buffer has been read
+                copy_line(i + 2);
             }
-            fft512_inv(v, xch, s_tw, lane);
+            fft512_inv_tw(v, xch, [&](const int k) { return twa[k]; }, [&](const int k) { return twb[k]; }, lane);
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
                 const int j2 = jj < 2 ? jj : jj + 4;
@@ -573,8 +586,11 @@ hipError_t launch_fft512_adjoint(const float2 *grid, float2 *tmp, float2 *out, c
     if (e != hipSuccess) return e;
     p.in = tmp;
 #ifndef TRON_FFT_COLS_NO_DMA
-    // enough workgroups to fill the chip (4 per CU x 256 CUs): 16 columns each from 64 slices on, 8 from 32, else 4
-    const int lpw = nslices >= 64 ? 4 : (nslices >= 32 ? 2 : 1);
+    // 8 columns per workgroup (4 from launches of fewer than 32 slices on, so that the chip is still full): three workgroups per CU hold
+    // 768 at a time, and 16 columns each made a 128-slice launch 2.67 rounds of them (221 us; 8 columns: 196, 4 columns: 224)
+    int lpw = nslices >= 32 ? 2 : 1;
+    if (nchan == 1) lpw = nslices >= 64 ? 4 : lpw;          // one channel: a wave's lines are its columns only, 16 per workgroup amortise its set-up
+    if (const char *e = tuning_env("TRON_FFT_LPW")) lpw = atoi(e) == 4 ? 4 : (atoi(e) == 2 ? 2 : 1);   // tuning knob
 #else
     const int lpw = 4;
 #endif
