@@ -66,6 +66,7 @@ CASES = [
     (2, 256, 1300, 2, dict(golden_angle=1)),                      # two passes of 650
     (8, 128, 2100, 2, dict(golden_angle=1, prof_slide=700)),      # three passes of 700, sliding windows
     (4, 256, 1030, 1, dict(golden_angle=0)),                      # two passes of 515, linear angles
+    (2, 256, 1100, 1, dict(golden_angle=1, gridos=1.5)),          # passes AND a resampled readout
 ]
 
 
@@ -89,17 +90,17 @@ def test_arc_kernel_vs_oracle_and_binned(oracle, nc, nro, npe, nz, flags):
 
 def test_arc_kernel_half_input_and_determinism(oracle):
     """complex-half k-space, 4 and 8 coils (the halves are converted in LDS, in place); identical bits run to run.  The third case
-    has nro != nxos (src/tron.cu:517)."""
-    for nc, extra in ((4, {}), (8, {}), (4, dict(gridos=3.0))):
-        data = synth.kspace(nc, 256, 140 * 2, seed=9100 + nc)
+    has nro != nxos (src/tron.cu:517), the fourth more than 1 024 spokes per window."""
+    for nc, npe, extra in ((4, 140, {}), (8, 140, {}), (4, 140, dict(gridos=3.0)), (4, 1040, {})):     # the last one: two passes over the spokes
+        data = synth.kspace(nc, 256, npe * 2, seed=9100 + nc)
         h = np.stack([data.real, data.imag]).astype(np.float16)
-        fl = dict(golden_angle=1, data_undersamp=0.547, prof_slide=140, **extra)
+        fl = dict(golden_angle=1, data_undersamp=(npe + 0.5) / 256, prof_slide=npe, **extra)
         assert "grid_arc_kernel" in _kernel_name(data.shape, input_half=1, **fl)
         a, dims = lib.recon(h, adjoint=True, input_half=1, **fl)
         b, _ = lib.recon(h, adjoint=True, input_half=1, **fl)
         assert np.array_equal(a, b)
         rounded = (h[0].astype(np.float32) + 1j * h[1].astype(np.float32)).astype(np.complex64)
-        want, _ = oracle.recon(rounded, adjoint=1, golden=1, data_undersamp=0.547, prof_slide=140, **extra)
+        want, _ = oracle.recon(rounded, adjoint=1, golden=1, data_undersamp=(npe + 0.5) / 256, prof_slide=npe, **extra)
         assert rel_l2(a, want) <= 1e-5
 
 
