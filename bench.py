@@ -185,6 +185,8 @@ def parse_args(argv=None):
     ap.add_argument("--linear", action="store_true",
                     help="secondary line: linear-angle spokes (no -G): every slice shares one trajectory, so with few coils several "
                          "slices share one pass of the gridding kernel")
+    ap.add_argument("--sustain", type=float, default=3.0,
+                    help="seconds of back-to-back steps after the timed region for sustained_slices_per_s (0 = skip)")
     ap.add_argument("--no-check", action="store_true")
     return ap.parse_args(argv)
 
@@ -262,24 +264,29 @@ for data, adjoint, fl in ((synth.kspace(2, 64, 60, seed=1), True, dict(golden_an
 
 def burn_in():
     """The first GPU process on a freshly leased box is not like the later ones (tests/conftest.py): a child process
-    runs each pipeline family twice first, so that a cold-start fault costs a retry there and not the measurement.  Untimed."""
+    runs each pipeline family twice first, so that a cold-start fault costs a retry there and not the measurement.  Untimed.
+    Returns the attempts' exit codes (None = timed out), e.g. [0]: they go on the result line as burn_in_attempts, so a retry is seen."""
     import subprocess
+    codes = []
     for attempt in range(3):
         try:
             r = subprocess.run([sys.executable, "-c", _BURN_IN % (ROOT, os.path.join(ROOT, "tests"))], capture_output=True, text=True, timeout=300)
         except subprocess.TimeoutExpired:
+            codes.append(None)
             continue
+        codes.append(r.returncode)
         if r.returncode == 0:
-            return
+            break
         sys.stderr.write(f"bench.py: burn-in attempt {attempt + 1} failed (rc {r.returncode}): {r.stderr[-300:]}\n")
+    return codes
 
 
 def main():
     args = parse_args()
     if "WORLD_SIZE" not in os.environ or os.environ.get("RANK", "0") == "0":
         if os.environ.get("TRON_BENCH_NO_BURN_IN") != "1" and "TRON_BENCH_BURNT" not in os.environ:
-            burn_in()                            # before this process (or the ranks it spawns) touches the GPU
-            os.environ["TRON_BENCH_BURNT"] = "1"
+            codes = burn_in()                    # before this process (or the ranks it spawns) touches the GPU
+            os.environ["TRON_BENCH_BURNT"] = json.dumps(codes)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
 
@@ -370,6 +377,24 @@ def main():
     plan.sync()   # surfaces a device-side error flag, if any
     dt = group.max(dt)
     value = total_slices * args.steps / dt
+
+    # Sustained rate: the same step() back to back for >= --sustain seconds (the timed region above is tens of milliseconds on a
+    # chip that holds its clock by power and settles slowly), the shader clock read in-kernel (s_memtime /
+    # s_memrealtime, tron_plan_shader_clock) right behind the timed steps and right behind the sustained ones.
+    sustained = None
+    if args.sustain > 0:
+        clock0 = plan.shader_clock_mhz()
+        n_sus = max(args.steps, int(args.sustain / (dt / args.steps)) + 1)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(n_sus):
+            step()
+        clock1 = plan.shader_clock_mhz()         # queued behind the last step on the gridding stream; synchronises it
+        fence()
+        dt_sus = group.max(time.perf_counter() - t0)
+        sustained = dict(value=round(total_slices * n_sus / dt_sus, 1), seconds=round(dt_sus, 3), steps=n_sus,
+                         ratio_to_value=round(total_slices * n_sus / dt_sus / value, 4),
+                         shader_clock_mhz_start=round(clock0, 0), shader_clock_mhz_end=round(clock1, 0))
 
     # per-kernel durations, measured live with hipEvents on the library's own stream
     ab = algorithmic_bytes(nc, args.half)
@@ -492,6 +517,9 @@ def main():
             "copy_ceiling_gbps": copy_gbps, "algorithmic_frac_of_copy_ceiling": round(alg_gbps / copy_gbps, 4) if copy_gbps else None,
             "copy_ceiling_guide_gbps": 6290.0,      # MI355X_MICROARCH.md: float4 copy, 79 % of the 8 TB/s spec
             "coil_slices_per_s": round(value * nc, 1),
+            # the same step() for >= --sustain seconds right after the timed steps (value / ms_per_step above are the driver's K steps)
+            "sustained_slices_per_s": sustained["value"] if sustained else None, "sustained": sustained,
+            "burn_in_attempts": json.loads(os.environ["TRON_BENCH_BURNT"]) if os.environ.get("TRON_BENCH_BURNT", "").startswith("[") else None,
             "parity_rel_l2_vs_oracle": err,
             # plan creation is outside the timed region (value = steady state of a plan made once per trajectory); the reference's one
             # published time clocks tron_init too (src/tron.cu:973-978), so the plan's cost and the rate of ONE cold job are stated here

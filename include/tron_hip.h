@@ -194,6 +194,12 @@ const char *tron_plan_grid_kernel_name(const tron_plan *plan);
    for launches of 16 images and more on grids of whole 32x32 tiles, degrid_tile_kernel otherwise. */
 const char *tron_plan_degrid_kernel_name(const tron_plan *plan);
 
+/* Shader clock in MHz at the end of what the plan has queued: a short spin kernel behind that work reads the shader-clock counter
+   against the constant 100 MHz counter (s_memtime / s_memrealtime).  The chip holds its clock down by power, so a
+   throughput figure is only comparable with another at a similar clock; bench.py reports it beside the sustained rate.
+   Synchronises the plan's gridding stream. */
+int tron_plan_shader_clock(tron_plan *plan, double *mhz);
+
 /* Wall-clock seconds tron_plan_create spent on this plan (the reference's one published time, src/RUNME4:219, clocks tron_init
    too: src/tron.cu:973-978): [0] total, [1] HIP runtime + code objects (the first plan of a process pays for both),
    [2] host tables and their upload, [3] of [2]: the arc / centre gridding kernels' run tables (host sort by line angle +

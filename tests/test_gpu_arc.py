@@ -29,13 +29,17 @@ def _kernel_name(shape, **flags):
 
 def _binned(data, **flags):
     """The same reconstruction with the binned kernel on every tile: a child process, because the switch is read once."""
+    return _child(data, dict(TRON_GRID_KERNEL="binned"), **flags)
+
+
+def _child(data, env_extra, **flags):
     code = (
         "import sys, numpy as np; sys.path.insert(0, %r); from tron_amd import lib\n"
         "d = np.load(sys.argv[1]); out, _ = lib.recon(d, adjoint=True, **eval(sys.argv[3])); np.save(sys.argv[2], out)\n" % ROOT)
     import tempfile
     with tempfile.TemporaryDirectory() as tmp:
         np.save(os.path.join(tmp, "in.npy"), data)
-        env = dict(os.environ, TRON_TUNING="1", TRON_GRID_KERNEL="binned")
+        env = dict(os.environ, TRON_TUNING="1", **env_extra)
         r = subprocess.run([sys.executable, "-c", code, os.path.join(tmp, "in.npy"), os.path.join(tmp, "out.npy"), repr(flags)],
                            env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
@@ -135,3 +139,22 @@ def test_a_workers_plan_holds_only_its_own_run_tables():
     assert dims.nz == 9
     multi, _ = lib.recon_multi(data, adjoint=True, devices=[0, 0, 0], **fl)
     assert np.array_equal(one, multi)
+
+
+@pytest.mark.parametrize("nc,nro,npe,nz", [(8, 256, 12, 64), (2, 512, 30, 32), (1, 256, 16, 64)])
+def test_empty_runs_between_the_slices_of_one_workgroup(oracle, nc, nro, npe, nz):
+    """Few spokes per window: rim tiles that no spoke of window z crosses but some spoke of window z + 1 does.  A workgroup grids
+    2 (launches of >= 32 slices) or 4 (>= 64) consecutive slices of its tile and asks for the next slice's run table one slice
+    ahead; round 4 issued that request inside the batch loop, which an empty run never enters, and slice z + 1 of such a tile
+    was gridded with slice z's empty table.  One launch against one slice per workgroup (TRON_ARC_ZPER=1), bit
+    for bit, and against the oracle (src/tron.cu:465-536)."""
+    data = synth.kspace(nc, nro, npe * nz, seed=9400 + npe)
+    fl = dict(golden_angle=1, data_undersamp=(npe + 0.5) / nro, prof_slide=npe)
+    assert "grid_arc_kernel" in _kernel_name(data.shape, **fl)
+    got, dims = lib.recon(data, adjoint=True, **fl)
+    assert dims.nz == nz
+    one = _child(data, dict(TRON_ARC_ZPER="1"), **fl)
+    assert np.array_equal(got, one)
+    want, _ = oracle.recon(data, adjoint=1, golden=1, data_undersamp=(npe + 0.5) / nro, prof_slide=npe)
+    for z in range(nz):
+        assert rel_l2(got[..., z], want[..., z]) <= 1e-5, z

@@ -40,10 +40,15 @@ b linear_nc1 $NI --linear --coils 1
 TRON_DUAL_STREAM=0 python bench.py $NI > $out/bench_one_lane.json 2> $out/bench_one_lane.err
 TRON_GRID_KERNEL=binned python bench.py $NI > $out/bench_binned_kernel.json 2> $out/bench_binned_kernel.err
 TRON_BENCH_SHARE_GPU=1 python bench.py $NI --gpus 2 --scaling strong --spokes 804 > $out/bench_cfg4_strong_2ranks_shared_gpu.json 2> $out/bench_cfg4_strong_2ranks_shared_gpu.err
-( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $out/stats --output-format csv -- python3 $R/bench.py --cpu-slices 0 --no-irt --no-check > $out/stats.log 2>&1
+# (no burn-in child under rocprofv3: it inherits the profiler and writes a <pid>_kernel_stats.csv of its own -- round 4's forward stats
+#  file was the child's; and the CSV kept is the one with the most dispatches, i.e. the bench process's)
+( cd /tmp && export TMPDIR=/tmp TRON_BENCH_NO_BURN_IN=1 && rocprofv3 --kernel-trace --stats -d $out/stats --output-format csv -- python3 $R/bench.py --cpu-slices 0 --no-irt --no-check > $out/stats.log 2>&1
   TRON_DUAL_STREAM=0 rocprofv3 --kernel-trace --stats -d $out/stats_one_lane --output-format csv -- python3 $R/bench.py --cpu-slices 0 --no-irt --no-check > $out/stats_one_lane.log 2>&1
   rocprofv3 --kernel-trace --stats -d $out/stats_forward --output-format csv -- python3 $R/bench.py --cpu-slices 0 --no-irt --no-check --forward > $out/stats_forward.log 2>&1 )
-for k in stats stats_one_lane stats_forward; do cp $(find $out/$k -name "*kernel_stats.csv" | head -1) $out/${k}.csv; done
+for k in stats stats_one_lane stats_forward; do
+  best=$(for f in $(find $out/$k -name "*kernel_stats.csv"); do echo "$(awk -F, 'NR>1{gsub(/"/,"",$2); s+=$2} END{print s+0}' $f) $f"; done | sort -n | tail -1 | cut -d' ' -f2)
+  cp $best $out/${k}.csv
+done
 WARM=20 bash tools/pmc.sh $tag/sq tools/gridbench.py 8 128 fast 3 > /dev/null 2>&1; cp gpurun_out/$tag/sq/summary.txt $out/sq_counters.txt
 if [ -f tron_amd/lib/libtronhip_aprof.so ]; then
   cp tron_amd/lib/libtronhip.so /tmp/orig.so; cp tron_amd/lib/libtronhip_aprof.so tron_amd/lib/libtronhip.so

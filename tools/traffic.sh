@@ -4,7 +4,7 @@
 # Writes gpurun_out/traffic/traffic_<key>.json stamped with the kernel-source hash and the launch size; copy it to profiles/.
 # <key> must be bench.py's workload_key() of the arguments (bench.py prints the one it looks for in roofline.traffic_source).
 export TRON_TUNING=1   # the library reads TRON_* switches only under TRON_TUNING=1
-R=$GRAFT_REPO_ROOT; key=$1; shift; out=$R/gpurun_out/traffic/$key; mkdir -p $out; cd /tmp; export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT; key=$1; shift; out=$R/gpurun_out/traffic/$key; mkdir -p $out; cd /tmp; export TMPDIR=/tmp TRON_BENCH_NO_BURN_IN=1   # (no burn-in child under the profiler)
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace -d $out/$c --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-slices 0 --no-irt --no-check "$@" > $out/$c.log 2> $out/$c.err
 done

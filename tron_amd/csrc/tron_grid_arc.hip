@@ -798,6 +798,9 @@ grid_arc_kernel(const GridParams p)
             } while (true);
             APROF_MARK(6);                                      // gather
         }
+        // an empty run (a rim tile no spoke of this window crosses) has no batch to hide the request behind: without it the next
+        // slice of this workgroup would use this slice's (empty) table and window and drop its samples
+        if (more && ns <= 0) fetch_table(z + 1, hdr_next);
 
         {
             unsigned char *zbase = reinterpret_cast<unsigned char *>(p.udata + (size_t)z * p.out_z + (size_t)c0 * p.out_c);

@@ -33,6 +33,8 @@
 // 55 instead of 68 for 32 slices.
 #include <algorithm>
 
+#include <mutex>
+
 #include "tron_device.h"
 #include "tron_host.h"
 
@@ -389,11 +391,15 @@ template <int LPV, bool ONE, bool HALF>
 static hipError_t launch_centre_lpv(const GridParams &p, hipStream_t s)
 {
     // as many workgroups as the chip holds at once (they stay and draw items), fewer when the launch has fewer items
-    static int wgs_per_xcd[16] = {};                                                      // per device
+    // (filled under a lock: the workers of tron_recon_radial2d_multi launch from their own threads)
+    constexpr int kMaxDev = 64;
+    static int wgs_per_xcd[kMaxDev] = {};                                                 // per device
+    static std::mutex wgs_lock;
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    dev &= 15;
+    if (dev < 0 || dev >= kMaxDev) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> guard(wgs_lock);
     if (wgs_per_xcd[dev] == 0) {
         int occ = 0, cus = 0;
         if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, grid_centre_kernel<LPV, ONE, HALF>, 64 * kCenWaves, 0)) != hipSuccess) return e;

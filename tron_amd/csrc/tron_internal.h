@@ -175,6 +175,7 @@ hipError_t launch_precompensate(float2 *nudata, int nchan, int nro, int npe, flo
 hipError_t launch_degrid(const DegridParams &p, int kb_mode, hipStream_t s);
 size_t grid_lds_bytes(int cpb, int cw);
 hipError_t warm_kernels();       // force-load the code object of tron_kernels.hip
+hipError_t launch_clock_probe(unsigned long long *d_out4, hipStream_t s);   // shader cycles, 100 MHz ticks of a short spin (tron_plan_shader_clock)
 hipError_t warm_grid_binned();   // ... and of tron_grid_binned.hip
 hipError_t warm_fft512();        // ... and of tron_fft512.hip
 hipError_t warm_degrid_tile();   // ... and of tron_degrid_tile.hip

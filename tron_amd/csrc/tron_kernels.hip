@@ -482,6 +482,29 @@ hipError_t launch_degrid(const DegridParams &p, int kb_mode, hipStream_t s)
 // Each TU therefore exposes a no-op launch that tron_plan_create() runs and waits for once.
 __global__ void warm_kernels_tu() {}
 
+// Shader clock of the moment: every wave spins on dependent FMAs between two readings of the shader-clock counter (s_memtime) and
+// of the constant 100 MHz counter (s_memrealtime); out[0] += shader cycles, out[1] += 100 MHz ticks (tron_plan_shader_clock).
+__global__ void __launch_bounds__(256) clock_probe_kernel(unsigned long long *out, int spins)
+{
+    const unsigned long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+    float a = (float)threadIdx.x * 1e-3f, b = 1.0000001f;
+    for (int i = 0; i < spins; ++i) a = fmaf(a, b, 1e-7f);
+    const unsigned long long c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&out[0], c1 - c0);
+        atomicAdd(&out[1], r1 - r0);
+    }
+    if (a == 123.456f) out[2] = 1ull;                           // keeps the loop
+}
+
+hipError_t launch_clock_probe(unsigned long long *d_out, hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(d_out, 0, 4 * sizeof(unsigned long long), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1024), dim3(256), 0, s, d_out, 6000);     // ~25 k cycles per wave: 10-15 us
+    return hipGetLastError();
+}
+
 hipError_t warm_kernels()
 {
     hipLaunchKernelGGL(warm_kernels_tu, dim3(1), dim3(64), 0, nullptr);

@@ -150,8 +150,9 @@ int main(int argc, char *argv[])
             fprintf(stderr, "tron: cannot stat %s\n", infile);
             return 1;
         }
+        // (a pipe or a device has no size to check: the reader finds a short stream when it ends)
         const uint64_t need = (6 + 5) * sizeof(uint64_t) + dims.in_elems * (cfg.input_half ? 4 : 8);
-        if ((uint64_t)si.st_size < need) {
+        if (S_ISREG(si.st_mode) && (uint64_t)si.st_size < need) {
             fprintf(stderr, "tron: %s is %llu bytes long, its header needs %llu\n", infile, (unsigned long long)si.st_size, (unsigned long long)need);
             return 1;
         }

@@ -14,6 +14,7 @@
 #include "tron_plan_impl.h"
 
 #include <time.h>
+#include <unistd.h>
 
 namespace tron {
 
@@ -58,6 +59,15 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
 {
     if (!out || !cfg || !dims) return fail(TRON_ERR_INVALID, "tron_plan_create: null argument");
     *out = nullptr;
+    // Test hook (TRON_TUNING=1 only): TRON_INJECT_COLD_FAULT=<path> makes the FIRST plan creation on a box fail -- the process that
+    // finds <path> missing creates it and fails; every later one runs normally.  That is the shape of the cold-start faults of
+    // DESIGN.md 4.5 (first GPU process on a fresh box), and tests/test_gpu_cold_start.py uses it to prove that such a fault is seen.
+    if (const char *mark = tuning_env("TRON_INJECT_COLD_FAULT")) {
+        if (access(mark, F_OK) != 0) {
+            if (FILE *f = fopen(mark, "w")) fclose(f);
+            return fail(TRON_ERR_HIP, "injected cold-start fault (TRON_INJECT_COLD_FAULT=%s)", mark);
+        }
+    }
     const tron_dims &d = *dims;
     if (share_z0 < 0 || share_nz < 0 || share_z0 + share_nz > std::max(d.nz, 1))
         return fail(TRON_ERR_INVALID, "slice share [%d,%d) outside [0,%d)", share_z0, share_z0 + share_nz, d.nz);
@@ -396,7 +406,9 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
                     hipFree(p->d_cen_order); hipFree(p->d_cen_cs);
                     p->d_cen_order = nullptr; p->d_cen_cs = nullptr;
                     p->arc = false;
-                    if (cfg->verbose) printf("tronhip: arc tables overflowed (flag %u): binned gridding kernel\n", flag);
+                    // never silent: this is a 2x slower kernel the caller did not ask for (the shapes that go to the binned kernel by design are
+                    // listed in README.md; tron_plan_grid_kernel_name tells which one a plan runs)
+                    fprintf(stderr, "tronhip: arc tables overflowed (flag %u): falling back to the binned gridding kernel\n", flag);
                 }
             }
             if (p->arc) {
@@ -609,6 +621,21 @@ extern "C" const char *tron_plan_grid_kernel_name(const tron_plan *p)
 extern "C" const char *tron_plan_degrid_kernel_name(const tron_plan *p)
 {
     return p ? p->last_degrid_kernel : "";
+}
+
+extern "C" int tron_plan_shader_clock(tron_plan *p, double *mhz)
+{
+    if (!p || !mhz) return fail(TRON_ERR_INVALID, "tron_plan_shader_clock: null argument");
+    HIP_TRY(hipSetDevice(p->cfg.device));
+    unsigned long long *d = nullptr, h[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d), sizeof(h)));
+    hipError_t e = launch_clock_probe(d, p->stream);             // behind whatever the plan has queued: the clock that work ran at
+    if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+    if (e == hipSuccess) e = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+    hipFree(d);
+    if (e != hipSuccess) return fail(TRON_ERR_HIP, "clock probe failed: %s", hipGetErrorString(e));
+    *mhz = h[1] ? 100.0 * (double)h[0] / (double)h[1] : 0.0;
+    return TRON_OK;
 }
 
 extern "C" int tron_plan_sync(tron_plan *p)

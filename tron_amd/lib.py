@@ -55,7 +55,7 @@ EXPORTS = [
     "tron_config_default", "tron_derive_dims", "tron_plan_create", "tron_plan_destroy",
     "tron_recon_radial2d", "tron_recon_radial2d_range", "tron_recon_radial2d_block", "tron_recon_radial2d_multi", "tron_nufft_adj_radial2d", "tron_cgnr_radial2d", "tron_nufft_radial2d",
     "tron_precompensate", "tron_gridradial2d", "tron_degridradial2d", "tron_plan_sync",
-    "tron_plan_timing", "tron_plan_timing_get", "tron_plan_timing_reset", "tron_plan_two_lanes", "tron_plan_grid_kernel_name", "tron_plan_degrid_kernel_name", "tron_plan_create_times",
+    "tron_plan_timing", "tron_plan_timing_get", "tron_plan_timing_reset", "tron_plan_two_lanes", "tron_plan_grid_kernel_name", "tron_plan_degrid_kernel_name", "tron_plan_create_times", "tron_plan_shader_clock",
     "tron_host_trig_table", "tron_host_band_table", "tron_host_deapod_table", "tron_host_numa_cpulist",
     "tron_device_count", "tron_device_malloc", "tron_device_free", "tron_memcpy_h2d", "tron_memcpy_d2h",
     "tron_last_error", "tron_version",
@@ -102,6 +102,7 @@ def load():
     sig("tron_plan_sync", i, [p])
     sig("tron_plan_two_lanes", i, [p, i, ctypes.POINTER(i)])
     sig("tron_plan_create_times", i, [p, ctypes.POINTER(ctypes.c_double)])
+    sig("tron_plan_shader_clock", i, [p, ctypes.POINTER(ctypes.c_double)])
     sig("tron_plan_grid_kernel_name", ctypes.c_char_p, [p])
     sig("tron_plan_degrid_kernel_name", ctypes.c_char_p, [p])
     sig("tron_host_numa_cpulist", i, [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(i), i])
@@ -292,6 +293,12 @@ class Plan:
         t = (ctypes.c_double * 5)()
         check(load().tron_plan_create_times(self._h, t))
         return dict(total=t[0], runtime=t[1], tables=t[2], run_tables=t[3], work_buffers=t[4])
+
+    def shader_clock_mhz(self) -> float:
+        """Shader clock (MHz) right behind what the plan has queued (s_memtime / s_memrealtime of a short spin kernel); synchronises."""
+        mhz = ctypes.c_double(0.0)
+        check(load().tron_plan_shader_clock(self._h, ctypes.byref(mhz)))
+        return mhz.value
 
     def two_lanes(self, enable=True) -> bool:
         """Serialise (False) or restore (True) the gridding || FFT overlap; returns whether the plan has a second lane."""
