@@ -210,7 +210,7 @@ def launch_ranks(args):
     return 0
 
 
-GRID_STAGE_KERNELS = ("grid_arc_kernel", "grid_centre_kernel", "grid_binned_kernel", "grid_tile_kernel", "grid_reduce_parts_kernel")
+GRID_STAGE_KERNELS = ("grid_arc_kernel", "grid_scatter_kernel", "grid_centre_kernel", "grid_binned_kernel", "grid_tile_kernel", "grid_reduce_parts_kernel")
 
 
 def workload_key(args):

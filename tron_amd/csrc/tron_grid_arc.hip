@@ -367,11 +367,15 @@ arc_prep_kernel(const ArcPrepParams p)
         } else {
             L.base = base;
         }
-        *hdr = make_int4(L.base < 0 ? 0 : ns, K, base, total);
+        if (!p.flat) *hdr = make_int4(L.base < 0 ? 0 : ns, K, base, total);
+        L.umax = 0;                                          // (reused below: the longest window of the tile's blocks, p.flat)
     }
     __syncthreads();
     const int base = L.base;
-    if (base < 0) return;
+    if (base < 0) {
+        if (p.flat && tid == 0) *hdr = make_int4(0, 0, 0, 0);
+        return;
+    }
     uint4 *ent = p.ent + (size_t)w * p.cap + base;
     for (int i = tid; i < ns; i += kArcThreads) {
         const float2 cs = L.s_cs[i];
@@ -409,6 +413,19 @@ arc_prep_kernel(const ArcPrepParams p)
             jhi = lo - 1;
         }
         p.win[((size_t)w * p.ntiles + tile) * kArcThreads + tid] = (uint32_t)jlo | ((uint32_t)(jhi + 1) << 16);
+        if (p.flat) {
+            // grid_scatter_kernel (tron_grid_scatter.hip): ONE batch per run (the record offsets then number the run's samples) and, in
+            // the header's second word, the most spokes whose line can pass one of the tile's blocks -- the bound behind its fixed-point scale
+            int mw = max(jhi - jlo + 1, 0);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mw = max(mw, __shfl_xor(mw, o));
+            if (lane == 0) atomicMax(&L.umax, mw);
+            __syncthreads();
+            if (tid == 0) {
+                if (K != 1) atomicOr(p.errflag, 1024u);
+                *hdr = make_int4(ns, L.umax, base, total);
+            }
+        }
     }
 }
 

@@ -1,0 +1,425 @@
+// Gridding kernel of the TRON_KB_FAST path for ONE or TWO channels: every lane takes a SAMPLE and adds it to the 4x4 grid points
+// of its Kaiser-Bessel footprint in a tile of 64-bit fixed-point sums in LDS (integer LDS atomics).
+//
+// Why a second formulation.  grid_arc_kernel (thread = 2x2 grid points, the samples come to it) spends ~34 VALU instructions per
+// (sample, block) visit of which only 4-8 depend on the coils, visits every sample from ~6 blocks, and runs its radius loop at 0.57
+// of its lanes: at one coil it is VALU- and LDS-issue-bound at 0.12 of the HBM roofline (DESIGN.md 4.1c, round-5 phase clock).  The
+// coil-independent work cannot be amortised over larger per-thread blocks (the band test of src/tron.cu:498-502 costs two
+// instructions per POINT and visit, so 4x4 points per thread save nothing).  Turned round -- lane = sample -- every sample is
+// handled once: positions and the eight window values once, then 16 point updates.  The updates are LDS atomics; float atomics run
+// at 3 clocks per LANE on this chip (profiles/round1_lds_atomic_rates.txt), 64-bit INTEGER ones hide completely under the arithmetic
+// (tools/probe/scatter.hip: 154 clocks per 64 samples and CU with ds_add_u64, 172 for the arithmetic alone), so the tile holds
+// (re << 32) + im as two 32-bit fixed-point numbers per point and channel, scaled per (tile, slice) by a power of two:
+//   scale   S = 2^e, the largest with  max|d| * dcf_max * M * 4 K(0)^2 * S < 2^30, M = the most spokes whose line can pass any of the
+//           tile's 2x2 blocks (the arc kernel's window rule; arc_prep_kernel leaves it in the run header) and 4 K(0)^2 a bound of the
+//           window products one spoke can add to one point: no sum can leave 32 bits.  What is lost is 2^-25..2^-23 of the
+//           tile's largest sample per added term -- the level of fp32 rounding for data whose magnitude does not vary by orders
+//           of magnitude INSIDE one 32x32 tile (measured: parity_rel_l2_vs_oracle on the bench line; tests/test_gpu_scatter.py).
+//   order   integer sums do not depend on the order of the additions: bit-identical results run to run by construction.
+// Same (sample, point) pairs as the reference's gridradial2d (src/tron.cu:465-536): |kx - X| < W and |ky - Y| < W strictly (the
+// arc kernel's pair table: exact support, build_kb_pair_lut), band Rlo <= |r| <= Rhi from the host's band table (:498-502,
+// :512, :521), density compensation :412-414, scale :532, (kx, ky) = r (cos, sin) as two fp32 products (:514-515).
+//
+// Work per (tile, slice), one workgroup of four waves (tables: arc_prep_kernel with ONE batch per run, so that the record offsets
+// number the tile's samples 0 .. total-1):
+//   table    the tile's run of crossing spokes (<= 512 entries, asked for one slice ahead) -> LDS; tile of sums zeroed;
+//   maximum  wave = spoke segment, lane = radius: max |re|, |im| of the tile's samples -> S (the samples then come from L1 / L2 again);
+//   scatter  wave = 64 consecutive records of its quarter of the run: the lane's spoke by a walk over the <= ~3 segments that start
+//            inside the 64 records (wave-uniform, v_readlane), sample -> (kx, ky) -> first column / row of the footprint -> two
+//            pair-table positions per axis -> 4 + 4 window values; d * dcf * S * wx[j] once per column, then per point: * wy[i], two
+//            conversions, one ds_add_u64 under the band test (one LDS read of the point's band, two SDWA compares);
+//   store    thread = 2x2 points: (float)sum * 2^-e * scale, once, coil-planar, FFT-native order (as the arc kernel).
+// The samples |r| < inner_r0 are the centre kernel's (tron_grid_centre.hip), behind this one on the same stream.
+#include <stdlib.h>
+
+#include "tron_device.h"
+#include "tron_grid_store.h"
+
+namespace tron {
+
+constexpr int kScatTile = 32;
+constexpr int kScatThreads = 256;
+constexpr int kScatHalo = 4;                        // 2 W for W <= 2: first column of a footprint >= x0 - 2 W
+constexpr int kScatPitch = kScatTile + 2 * kScatHalo;   // 40
+constexpr int kScatMaxSpokes = 512;                 // = kArcMaxSpokes (arc_prep_kernel)
+
+template <int NC>
+struct ScatCfg {
+    static constexpr int WAVES = NC >= 2 ? 3 : 4;   // workgroups per CU (LDS: 29 / 39 units of 1280 bytes)
+};
+
+template <int NC>
+struct ScatLds {
+    float2 lut[3 * kArcLutEntries];                              // Kaiser-Bessel pair table (build_kb_pair_lut)
+    uint4 run[kScatMaxSpokes];                                   // first sample | down << 31, ulo | len << 10 | offset << 17, cos, sin
+    uint32_t band[kScatPitch * kScatPitch];                      // Rlo | Rhi << 16 of the tile's points and its halo (empty outside the grid)
+    unsigned long long acc[NC][kScatPitch * kScatPitch];         // (re << 32) + im, fixed point
+    unsigned dmax_bits;
+    unsigned pad[3];
+};
+
+typedef const __attribute__((address_space(3))) v2f *slds_f2p;
+
+__device__ __forceinline__ int cvt_rpi(float x)      // floor(x + 0.5): one instruction (v_cvt_i32_f32 truncates, rndne + cvt are two)
+{
+    int r;
+    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
+template <int NC, bool HALF, bool RS>
+__global__ void __launch_bounds__(kScatThreads, ScatCfg<NC>::WAVES)
+grid_scatter_kernel(const GridParams p)
+{
+    static_assert(NC == 1 || NC == 2, "one or two channels per pass");
+    static_assert((sizeof(ScatLds<NC>) + 1279) / 1280 * ScatCfg<NC>::WAVES <= 128, "ScatCfg::WAVES workgroups do not fit a CU's 128 LDS units of 1280 bytes");
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    ScatLds<NC> &L = *reinterpret_cast<ScatLds<NC> *>(lds_raw);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int zper = p.arc_zper > 0 ? p.arc_zper : 1;
+    const int ngroups = (p.nslices + zper - 1) / zper;
+    const int zg = blockIdx.x % ngroups;
+    const int tile = p.tile_order[blockIdx.x / ngroups] & 0xffff;
+    if (tile >= p.ntiles) {
+        if (tid == 0) atomicOr(p.errflag, 128u);
+        return;
+    }
+    const int c0 = p.coil0 + blockIdx.y * NC;
+    const int ncb = min(NC, p.nchan - c0);
+    const int n = p.nxos, h = n / 2, rmax = n / 2 - 1;
+    const int x0 = (tile % p.tiles_per_row) * kScatTile - h;      // tile origin, centred coordinates
+    const int y0 = (tile / p.tiles_per_row) * kScatTile - h;
+    if (p.skip_outside) {
+        // nearest point of the tile to the k-space centre; beyond rmax + W every band is empty (src/tron.cu:498-502,512)
+        const int ax = max(max(x0, -(x0 + kScatTile - 1)), 0), ay = max(max(y0, -(y0 + kScatTile - 1)), 0);
+        const float lim = (float)rmax + p.W + 1.0f;
+        if ((float)(ax * ax + ay * ay) > lim * lim) return;
+    }
+
+    // ---- once per workgroup: window table, band of the tile's points and their halo ----
+    for (int i = tid; i < 3 * kArcLutEntries; i += kScatThreads) L.lut[i] = p.kb_lut[i];
+    for (int i = tid; i < kScatPitch * kScatPitch; i += kScatThreads) {
+        const int X = x0 - kScatHalo + i % kScatPitch, Y = y0 - kScatHalo + i / kScatPitch;
+        uint32_t b = 1u;                                          // Rlo 1 > Rhi 0: nothing passes
+        if (X >= -h && X < h && Y >= -h && Y < h) b = p.band[(size_t)(Y + h) * n + (X + h)];
+        L.band[i] = b;
+    }
+    const slds_f2p lutq = (slds_f2p)(__attribute__((address_space(3))) const void *)L.lut + p.lut_bias;    // entry of table position 0
+    const float W = p.W, lscale = p.lut_scale, two_s = 2.0f * p.lut_scale;
+    const float dcf_a = p.apply_dcf ? p.dcf_a : 0.0f, dcf_b = p.apply_dcf ? p.dcf_b : 1.0f;
+    const float dcf_max = fmaf(fabsf(dcf_a), (float)rmax, fabsf(dcf_b));
+    const float rs_nro = (float)p.nro, rs_inv = 1.0f / (float)p.nxos;
+    const unsigned nchan_b = (unsigned)p.nchan * (HALF ? 4u : 8u);       // bytes per sample (all channels)
+    const float fx0 = (float)(x0 - kScatHalo), fy0 = (float)(y0 - kScatHalo);
+
+    // this thread's 2x2 points of the tile (the store's layout, as in grid_arc_kernel)
+    const int mx = 2 * (lane & 15), my = 8 * wave + 2 * (lane >> 4);
+    unsigned out_off[2];
+#pragma unroll
+    for (int qy = 0; qy < 2; ++qy) {
+        const int X0 = x0 + mx, Y = y0 + my + qy;
+        const int row = p.out_shift ? (Y < 0 ? Y + n : Y) : Y + h;      // both fftshifts of src/tron.cu:631 folded in
+        const int col = p.out_shift ? (X0 < 0 ? X0 + n : X0) : X0 + h;
+        out_off[qy] = (unsigned)(row * n + col) * 8u;
+    }
+
+    // the run table of a slice (<= 512 entries, two per thread) is asked for one slice ahead and waits in registers
+    uint4 pf_ent[2] = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)};
+    int4 hdr_next = make_int4(0, 1, 0, 0);
+    auto fetch_table = [&](const int z, const int4 hh) {
+        const size_t win = (size_t)z * p.arc_slice_stride;
+        const uint4 *ent = p.arc_ent + win * p.arc_cap + hh.z;
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            if (tid + k * kScatThreads < hh.x) pf_ent[k] = ent[tid + k * kScatThreads];
+    };
+    if (zg * zper < p.nslices) {
+        hdr_next = p.arc_hdr[(size_t)(zg * zper) * p.arc_slice_stride * p.ntiles + tile];
+        fetch_table(zg * zper, hdr_next);
+    }
+
+    for (int iz = 0; iz < zper; ++iz) {
+        const int z = zg * zper + iz;
+        if (z >= p.nslices) break;
+        const int4 hdr = hdr_next;
+        const int ns = hdr.x, mwin = hdr.y, total = hdr.w;
+        const bool more = iz + 1 < zper && z + 1 < p.nslices;
+        if (more) hdr_next = p.arc_hdr[(size_t)(z + 1) * p.arc_slice_stride * p.ntiles + tile];
+        const unsigned char *in = reinterpret_cast<const unsigned char *>(p.nudata) + ((size_t)z * (size_t)p.in_slice_stride + c0) * (HALF ? 4 : 8);
+
+        __syncthreads();                                        // the last slice's store has read the sums
+        // ---- run table -> LDS, sums zeroed ----
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = tid + k * kScatThreads;
+            if (i < ns) L.run[i] = pf_ent[k];
+        }
+        {
+            uint4 *const a4 = reinterpret_cast<uint4 *>(&L.acc[0][0]);
+            constexpr int N4 = NC * kScatPitch * kScatPitch / 2;
+            for (int i = tid; i < N4; i += kScatThreads) a4[i] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        if (tid == 0) L.dmax_bits = 0u;
+        __syncthreads();
+        if (more) fetch_table(z + 1, hdr_next);                 // on its way while this slice is gridded
+
+        // lane's sample of member entry e at offset k inside the segment -> byte offset of its first channel
+        auto sample_off = [&](const uint4 e, const int k) -> unsigned {
+            const unsigned first = e.x & 0x7fffffffu;
+            unsigned s;
+            if constexpr (RS) {                                  // `first` is the spoke's centre sample: radius u reads sample (u nro) / nxos (src/tron.cu:517)
+                const unsigned so = (unsigned)(int)arc_sample_of((float)((int)(e.y & 1023u) + k), rs_nro, rs_inv);
+                s = (e.x >> 31) ? first - so : first + so;
+            } else {
+                s = (e.x >> 31) ? first - (unsigned)k : first + (unsigned)k;
+            }
+            return s * nchan_b;
+        };
+        auto load_d = [&](const unsigned off, v2f (&d)[NC]) {
+            if constexpr (HALF) {
+                if constexpr (NC == 1) {
+                    const __half2 hv = *reinterpret_cast<const __half2 *>(in + off);
+                    const float2 f = __half22float2(hv);
+                    d[0] = (v2f){f.x, f.y};
+                } else {
+                    const uint2 raw = *reinterpret_cast<const uint2 *>(in + off);
+                    __half2 h0, h1;
+                    __builtin_memcpy(&h0, &raw.x, 4);
+                    __builtin_memcpy(&h1, &raw.y, 4);
+                    const float2 f0 = __half22float2(h0), f1 = __half22float2(h1);
+                    d[0] = (v2f){f0.x, f0.y};
+                    d[1] = (v2f){f1.x, f1.y};
+                }
+            } else if constexpr (NC == 1) {
+                const float2 f = *reinterpret_cast<const float2 *>(in + off);
+                d[0] = (v2f){f.x, f.y};
+            } else {
+                const float4 f = *reinterpret_cast<const float4 *>(in + off);
+                d[0] = (v2f){f.x, f.y};
+                d[1] = (v2f){f.z, f.w};
+            }
+        };
+
+        // ---- largest |re|, |im| of the tile's samples: wave = segment, lane = radius ----
+        {
+            float mxv = 0.f;
+            for (int m = wave; m < ns; m += 4) {
+                const uint4 e = L.run[m];
+                const int len = (int)((e.y >> 10) & 127u);
+                if (lane < len) {
+                    v2f d[NC];
+                    load_d(sample_off(e, lane), d);
+#pragma unroll
+                    for (int c = 0; c < NC; ++c)
+                        if (c < ncb) mxv = fmaxf(mxv, fmaxf(fabsf(d[c].x), fabsf(d[c].y)));
+                }
+            }
+            if (!(mxv < 3.0e38f)) mxv = 3.0e38f;                // inf / NaN in the data: the sums saturate to garbage either way; keep S finite
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mxv = fmaxf(mxv, __shfl_xor(mxv, o));
+            if (lane == 0) atomicMax(&L.dmax_bits, __float_as_uint(mxv));
+        }
+        __syncthreads();
+        // S = 2^e: max|d| dcf_max mwin wsum 2^e < 2^30
+        int e2 = 0;
+        {
+            const float bound = __uint_as_float(L.dmax_bits) * dcf_max * (float)max(mwin, 1) * p.scat_wsum;
+            if (bound > 0.f) {
+                const int ex = (int)((__float_as_uint(bound) >> 23) & 255u) - 127;      // bound < 2^(ex + 1)
+                e2 = min(max(29 - ex, -120), 120);
+            }
+        }
+        const float S = __uint_as_float((unsigned)(e2 + 127) << 23), invS = __uint_as_float((unsigned)(127 - e2) << 23);
+
+        // ---- scatter: this wave's quarter of the run's records, 64 at a time ----
+        if (total > 0) {
+            const int quota = ((total + 255) >> 8) << 6;
+            const int pbeg = wave * quota, pend = min(total, pbeg + quota);
+            if (pbeg < pend) {
+                // the member that holds record pbeg
+                int m_cur = 0;
+                {
+                    int found = -1;
+                    for (int i = lane; i < ns; i += 64) {
+                        const unsigned sb = L.run[i].y;
+                        const int off = (int)(sb >> 17), len = (int)((sb >> 10) & 127u);
+                        if (len > 0 && off <= pbeg && pbeg < off + len) found = i;
+                    }
+                    const unsigned long long bm = __ballot(found >= 0);
+                    m_cur = bm ? __builtin_amdgcn_readlane(found, (int)__builtin_ctzll(bm)) : 0;
+                }
+                for (int pbase = pbeg; pbase < pend; pbase += 64) {
+                    const int pos = pbase + lane;
+                    // the lane's member: walk over the segments that start inside these 64 records
+                    int mem = m_cur;
+                    {
+                        int cbase = m_cur;
+                        for (;;) {
+                            const int ci = cbase + 1 + lane;
+                            const unsigned sbc = ci < ns ? L.run[ci].y : 0xfffe0000u;       // (offset 32767: beyond every record)
+                            bool done = false;
+                            for (int j = 0; j < 64; ++j) {
+                                const unsigned sbj = (unsigned)__builtin_amdgcn_readlane((int)sbc, j);
+                                const int offj = (int)(sbj >> 17);
+                                if (offj >= pbase + 64) { done = true; break; }
+                                if (pos >= offj) mem = cbase + 1 + j;
+                            }
+                            if (done || cbase + 65 >= ns) break;
+                            cbase += 64;
+                        }
+                    }
+                    m_cur = __builtin_amdgcn_readlane(mem, 63);
+                    const uint4 e = L.run[mem];
+                    const int off = (int)(e.y >> 17), len = (int)((e.y >> 10) & 127u), ulo = (int)(e.y & 1023u);
+                    const int k = pos - off;
+                    if (pos < pend && k >= 0 && k < len) {
+                        const int u = ulo + k;
+                        const float uf = (float)u;
+                        v2f d[NC];
+                        load_d(sample_off(e, k), d);
+                        const float cs_c = __uint_as_float(e.z), cs_s = __uint_as_float(e.w);
+                        const float kx = uf * cs_c, ky = uf * cs_s;                        // src/tron.cu:514-515
+                        // first column / row X with |k - X| < W: floor(k - W) + 1; footprint = that and the next three
+                        const float ixf = floorf(kx - W) + 1.0f, iyf = floorf(ky - W) + 1.0f;
+                        // table positions of the distance from the first column (exact: the scale is a power of two), and of the third
+                        const v2f t0 = (v2f){kx - ixf, ky - iyf} * (v2f){lscale, lscale};
+                        const v2f t2 = t0 - (v2f){two_s, two_s};
+                        const v2f tt0 = {__builtin_truncf(t0.x), __builtin_truncf(t0.y)}, tt2 = {__builtin_truncf(t2.x), __builtin_truncf(t2.y)};
+                        const v2f f0 = t0 - tt0, f2 = t2 - tt2;
+                        const slds_f2p lx0 = lutq + (int)tt0.x, ly0 = lutq + (int)tt0.y, lx2 = lutq + (int)tt2.x, ly2 = lutq + (int)tt2.y;
+                        auto pair = [&](const slds_f2p q, const float f) -> v2f {
+                            const v2f a0 = q[0], a1 = q[kArcLutEntries], a2 = q[2 * kArcLutEntries];
+                            const v2f fv = {f, f};
+                            return __builtin_elementwise_fma(fv, __builtin_elementwise_fma(fv, a2, a1), a0);
+                        };
+                        const v2f wxa = pair(lx0, f0.x), wxb = pair(lx2, f2.x), wya = pair(ly0, f0.y), wyb = pair(ly2, f2.y);
+                        const float wx[4] = {wxa.x, wxa.y, wxb.x, wxb.y}, wy[4] = {wya.x, wya.y, wyb.x, wyb.y};
+                        // density compensation (src/tron.cu:412: |ro - nro/2| = u, or u's sample) and the fixed-point scale, once per sample
+                        const float sdc = fmaf(dcf_a, RS ? arc_sample_of(uf, rs_nro, rs_inv) : uf, dcf_b) * S;
+                        v2f a[4][NC];
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) {
+                            const v2f ds = d[c] * (v2f){sdc, sdc};
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) a[j][c] = ds * (v2f){wx[j], wx[j]};
+                        }
+                        int bx = (int)(ixf - fx0), by = (int)(iyf - fy0);
+                        bx = min(max(bx, 0), kScatPitch - 4);                              // (never binds: the segments are clipped to tile + W)
+                        by = min(max(by, 0), kScatPitch - 4);
+                        const int base = by * kScatPitch + bx;
+                        const uint32_t *const bnd = &L.band[base];
+                        const unsigned uu = (unsigned)u;
+                        uint32_t bb[16];                                                   // all sixteen bands first: a read behind an atomic waits for it
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) bb[4 * i + j] = bnd[i * kScatPitch + j];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const uint32_t b = bb[4 * i + j];
+                                if (uu >= (b & 0xffffu) && uu <= (b >> 16)) {              // src/tron.cu:512, 521
+#pragma unroll
+                                    for (int c = 0; c < NC; ++c)
+                                        if (c < ncb) {
+                                            const v2f v = a[j][c] * (v2f){wy[i], wy[i]};   // src/tron.cu:516, 519
+                                            const int re = cvt_rpi(v.x), im = cvt_rpi(v.y);
+                                            const long long add = ((long long)re << 32) + (long long)im;
+                                            __hip_atomic_fetch_add(&L.acc[c][base + i * kScatPitch + j], (unsigned long long)add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                        }
+                                }
+                            }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- store: thread = 2x2 points ----
+        {
+            const float os = invS * p.scale;                    // src/tron.cu:532-534
+            unsigned char *zbase = reinterpret_cast<unsigned char *>(p.udata + (size_t)z * p.out_z + (size_t)c0 * p.out_c);
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                if (c < ncb) {
+#pragma unroll
+                    for (int qy = 0; qy < 2; ++qy) {
+                        const unsigned long long *const s2 = &L.acc[c][(my + qy + kScatHalo) * kScatPitch + mx + kScatHalo];
+                        float f[4];
+#pragma unroll
+                        for (int qx = 0; qx < 2; ++qx) {
+                            const long long t = (long long)s2[qx];
+                            const int im = (int)(unsigned)(t & 0xffffffffll);
+                            const int re = (int)((t - (long long)im) >> 32);
+                            f[2 * qx] = (float)re * os;
+                            f[2 * qx + 1] = (float)im * os;
+                        }
+                        float4 v = make_float4(f[0], f[1], f[2], f[3]);
+                        float4 *const o = reinterpret_cast<float4 *>(zbase + (size_t)c * p.out_c * 8 + out_off[qy]);
+                        if (p.arc_accumulate) {                             // a later pass over more than kArcMaxNpe spokes per window
+                            const float4 old = *o;
+                            v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
+                        }
+                        *o = v;
+                    }
+                }
+        }
+    }
+}
+
+template <int NC, bool HALF, bool RS>
+static hipError_t launch_scatter_rs(const GridParams &p, int first_plain, hipStream_t s)
+{
+    const int tpr = (p.nxos + kScatTile - 1) / kScatTile;
+    GridParams q = p;
+    q.tiles_per_row = tpr;
+    q.ntiles = tpr * tpr;
+    q.tile_order = p.tile_order + first_plain;
+    q.arc_zper = p.arc_zper > 0 ? p.arc_zper : 1;
+    const int ngroups = (p.nslices + q.arc_zper - 1) / q.arc_zper;
+    const int chunks = (p.nchan - p.coil0 + NC - 1) / NC;
+    dim3 grid((unsigned)((size_t)q.ntiles * ngroups), (unsigned)chunks);
+    const size_t lds = sizeof(ScatLds<NC>);
+    hipLaunchKernelGGL((grid_scatter_kernel<NC, HALF, RS>), grid, dim3(kScatThreads), lds, s, q);
+    return hipGetLastError();
+}
+
+template <int NC>
+static hipError_t launch_scatter_nc(const GridParams &p, int half_in, int first_plain, hipStream_t s)
+{
+    const bool rs = p.nro != p.nxos;
+    if (half_in) return rs ? launch_scatter_rs<NC, true, true>(p, first_plain, s) : launch_scatter_rs<NC, true, false>(p, first_plain, s);
+    return rs ? launch_scatter_rs<NC, false, true>(p, first_plain, s) : launch_scatter_rs<NC, false, false>(p, first_plain, s);
+}
+
+// The plans the arc kernel takes (grid_arc_supported) with one or two channels and a window of at most four points per axis.
+bool grid_scatter_supported(int nchan, int nxos, int nro, int npe, float W, int half_in)
+{
+    (void)half_in;                                              // fp32 and complex-half k-space alike: the samples are read by plain loads
+    return (nchan == 1 || nchan == 2) && W <= 2.0f && grid_arc_supported(nchan, nxos, nro, npe, W, 0);
+}
+
+// p.tile_order[first_plain ...] must list the 32x32 tiles; run tables from arc_prep_kernel with ONE batch per run (ArcPrepParams::nrec >= 32767).
+hipError_t launch_grid_scatter(const GridParams &p, int half_in, int first_plain, hipStream_t s)
+{
+    const int nc = p.nchan - p.coil0;
+    if (p.out_p != 1 || p.inner_r0 <= 0 || !p.arc_hdr || !p.arc_ent || !p.kb_lut || p.lut_entries > kArcLutEntries || p.npe > kArcMaxNpe || !(p.scat_wsum > 0.f)
+        || !grid_scatter_supported(nc, p.nxos, p.nro, p.npe, p.W, half_in) || (reinterpret_cast<uintptr_t>(p.nudata) & (half_in ? 3 : 7)) != 0
+        || (nc == 2 && (reinterpret_cast<uintptr_t>(p.nudata) & (half_in ? 7 : 15)) != 0))
+        return hipErrorInvalidValue;
+    return nc == 2 ? launch_scatter_nc<2>(p, half_in, first_plain, s) : launch_scatter_nc<1>(p, half_in, first_plain, s);
+}
+
+__global__ void warm_grid_scatter_tu() {}
+
+hipError_t warm_grid_scatter()   // see warm_kernels() in tron_kernels.hip
+{
+    hipLaunchKernelGGL(warm_grid_scatter_tu, dim3(1), dim3(64), 0, nullptr);
+    return hipGetLastError();
+}
+
+}  // namespace tron

@@ -35,6 +35,7 @@ void build_split_tile_order(int nxos, int tile, int npe, float W, int target, in
 bool build_centre_relief_order(int nxos, int tile, int npe, float W, int max_parts, int &inner_r0, std::vector<int> &order, std::vector<int> &slots,
                                int target_records = 1400);
 float kb_beta(float kernwidth);
+double kb_peak(float kernwidth);      // the window's value at 0
 // arc gridding kernel: Kaiser-Bessel table over the signed distance from a 2x2 block's first column, two windows per entry
 // (tron_hostmath.cpp); kb_pair_lut_scale = pieces per grid unit for a table of `cap` entries (0: this width has none),
 // build_kb_pair_lut fills coef[3][cap][2] and returns the entries used

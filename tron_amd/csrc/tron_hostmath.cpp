@@ -264,6 +264,11 @@ int kb_pair_lut_scale(float kernwidth, int cap)
     return 0;
 }
 
+double kb_peak(float kernwidth)      // the un-normalised window at 0: 0.5 I0(beta) / W (src/tron.cu:338-349)
+{
+    return 0.5 / (double)kernwidth * bessel_i0_series(kb_beta(kernwidth));
+}
+
 int build_kb_pair_lut(float kernwidth, int cap, float *coef, float *scale, int *bias, double *err)
 {
     const int s = kb_pair_lut_scale(kernwidth, cap);

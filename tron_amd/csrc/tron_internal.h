@@ -85,6 +85,7 @@ struct GridParams {
     int lut_entries, lut_bias;
     float lut_scale;
     int arc_zper;                      // consecutive slices one workgroup grids in turn (the table stays in LDS)
+    float scat_wsum;                   // scatter kernel: bound of the window products one spoke adds to one grid point, 4 K(0)^2 (its fixed-point scale)
     // centre kernel (tron_grid_centre.hip): the angle-sorted spoke lists of the arc kernel's plan, kept
     const unsigned short *cen_order;   // [window][npe] window-relative spoke index, ascending line angle (mod pi)
     const uint32_t *cen_win;           // [window][cen_ngroups] the block's run of that list: first entry | entries << 16 (circular)
@@ -166,8 +167,13 @@ struct ArcPrepParams {
     unsigned int *errflag;
     int nxos, nro, npe, ntiles, inner_r0, nrec, cap;
     float W;
+    int flat;                          // tables for grid_scatter_kernel: one batch per run (nrec >= 32767), hdr.y = the longest block window of the tile
 };
 hipError_t launch_arc_prep(const ArcPrepParams &p, int nwindows, hipStream_t s);
+// one or two channels, W <= 2 (tron_grid_scatter.hip): lane = sample, 64-bit fixed-point sums in LDS; same tables (ArcPrepParams::flat), same call as launch_grid_arc
+bool grid_scatter_supported(int nchan, int nxos, int nro, int npe, float W, int half_in);
+hipError_t launch_grid_scatter(const GridParams &p, int half_in, int first_plain, hipStream_t s);
+hipError_t warm_grid_scatter();
 hipError_t warm_grid_arc();
 hipError_t launch_post(const PostParams &p, hipStream_t s);
 hipError_t launch_pre(const PreParams &p, hipStream_t s);

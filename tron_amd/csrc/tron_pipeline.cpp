@@ -300,7 +300,9 @@ int adjoint_run_raw(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, 
                         ga.arc_win = p->d_arc_win + tab * nt32 * 256;
                         ga.npe = std::min(d.npe1work, (q + 1) * p->arc_pass_npe) - q * p->arc_pass_npe;
                         ga.arc_accumulate = q > 0;
-                        HIP_TRY(launch_grid_arc(ga, p->cfg.input_half, relief_parts, st));
+                        ga.scat_wsum = p->scat_wsum;
+                        if (p->scatter) HIP_TRY(launch_grid_scatter(ga, p->cfg.input_half, relief_parts, st));
+                        else HIP_TRY(launch_grid_arc(ga, p->cfg.input_half, relief_parts, st));
                     }
                     if (p->centre_kernel) {
                         const size_t woff = win0 * (size_t)d.npe1work;

@@ -114,6 +114,7 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
     HIP_TRY(warm_grid_binned());
     HIP_TRY(warm_grid_arc());
     HIP_TRY(warm_grid_centre());
+    HIP_TRY(warm_grid_scatter());
     HIP_TRY(warm_fft512());
     HIP_TRY(warm_degrid_tile());
     HIP_TRY(warm_degrid_stream());
@@ -224,7 +225,13 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
             t_arc1 = t_arc0;
             // arc kernel: everything but the inner tile, when the trajectory and the sample layout allow it
             p->arc = p->relief_entries > 0 && grid_arc_supported(p->nchan, d.nxos, d.nro, d.npe1work, cfg->kernwidth, cfg->input_half);
-            if (const char *gk = tuning_env("TRON_GRID_KERNEL")) p->arc = p->arc && strcmp(gk, "binned") != 0;
+            // one or two channels: lane = sample, fixed-point sums in LDS (tron_grid_scatter.hip) on the arc kernel's tables
+            p->scatter = p->relief_entries > 0 && grid_scatter_supported(p->nchan, d.nxos, d.nro, d.npe1work, cfg->kernwidth, cfg->input_half);
+            if (const char *gk = tuning_env("TRON_GRID_KERNEL")) {
+                p->scatter = p->scatter && strcmp(gk, "binned") != 0 && strcmp(gk, "arc") != 0;
+                p->arc = p->arc && strcmp(gk, "binned") != 0;
+            }
+            if (p->scatter) p->arc = true;
             if (p->arc) {
                 // plan-time pass: every window's spokes sorted by line angle (host), clipped against every tile and dealt
                 // into batches (arc_prep_kernel); the sorted lists are scratch
@@ -332,7 +339,7 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
                 float *d_scs = nullptr;
                 // a spoke crosses at most 2 * nxos / 32 + 3 tiles (+ their halos): 56 run entries per spoke bound every window
                 p->arc_cap = sub * (2 * (d.nxos / kBinnedTile) + 24);
-                p->arc_nrec = grid_arc_nrec(p->nchan, cfg->input_half);
+                p->arc_nrec = p->scatter ? 32767 : grid_arc_nrec(p->nchan, cfg->input_half);      // (scatter kernel: one batch per run)
                 rc = upload(&d_order, order.data(), order.size() * sizeof(unsigned short));
                 if (!rc) rc = upload(&d_scs, scs.data(), scs.size() * sizeof(float));
                 p->d_cen_order = d_order;                       // the sorted lists stay: centre kernel
@@ -389,7 +396,7 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
                     ap.hdr = p->d_arc_hdr + (size_t)q * nwin * nt32; ap.ent = p->d_arc_ent + (size_t)q * nwin * p->arc_cap;
                     ap.win = p->d_arc_win + (size_t)q * nwin * nt32 * 256; ap.band = p->d_band; ap.alloc = d_alloc; ap.errflag = p->d_errflag;
                     ap.nxos = d.nxos; ap.nro = d.nro; ap.npe = nq; ap.ntiles = nt32; ap.inner_r0 = p->relief_r0; ap.nrec = p->arc_nrec;
-                    ap.cap = p->arc_cap; ap.W = cfg->kernwidth;
+                    ap.cap = p->arc_cap; ap.W = cfg->kernwidth; ap.flat = p->scatter ? 1 : 0;
                     he = launch_arc_prep(ap, (int)nwin, p->stream);
                     if (he == hipSuccess) he = hipStreamSynchronize(p->stream);
                     drop();
@@ -406,6 +413,7 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
                     hipFree(p->d_cen_order); hipFree(p->d_cen_cs);
                     p->d_cen_order = nullptr; p->d_cen_cs = nullptr;
                     p->arc = false;
+                    p->scatter = false;
                     // never silent: this is a 2x slower kernel the caller did not ask for (the shapes that go to the binned kernel by design are
                     // listed in README.md; tron_plan_grid_kernel_name tells which one a plan runs)
                     fprintf(stderr, "tronhip: arc tables overflowed (flag %u): falling back to the binned gridding kernel\n", flag);
@@ -416,6 +424,7 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
                 p->lut_entries = build_kb_pair_lut(cfg->kernwidth, kArcLutEntries, lut.data(), &p->lut_scale, &p->lut_bias, &p->lut_err);
                 if (p->lut_entries <= 0) return bail(fail(TRON_ERR_UNSUPPORTED, "no Kaiser-Bessel pair table for width %g", (double)cfg->kernwidth));
                 if ((rc = upload(&p->d_kb_lut, lut.data(), lut.size() * sizeof(float)))) return bail(rc);
+                p->scat_wsum = (float)(4.0 * kb_peak(cfg->kernwidth) * kb_peak(cfg->kernwidth));
                 p->arc_zper = 0;                                    // 0: by launch size (tron_pipeline.cpp)
                 if (const char *e = tuning_env("TRON_CENTRE_KERNEL")) p->centre_kernel = strcmp(e, "binned") != 0;
                 // the inner tile's workgroups are few and slow (every spoke passes the k-space centre): on a stream of their own,
@@ -613,6 +622,7 @@ extern "C" int tron_plan_destroy(tron_plan *p)
 extern "C" const char *tron_plan_grid_kernel_name(const tron_plan *p)
 {
     if (!p || !p->cfg.adjoint) return "";
+    if (p->scatter) return p->centre_kernel ? "grid_scatter_kernel (+ grid_centre_kernel for |r| < inner_r0)" : "grid_scatter_kernel (+ grid_binned_kernel on the inner tile, grid_reduce_parts_kernel)";
     if (p->arc) return p->centre_kernel ? "grid_arc_kernel (+ grid_centre_kernel for |r| < inner_r0)" : "grid_arc_kernel (+ grid_binned_kernel on the inner tile, grid_reduce_parts_kernel)";
     if (p->binned) return p->relief_entries > 0 ? "grid_binned_kernel (+ grid_reduce_parts_kernel)" : "grid_binned_kernel";
     return "grid_tile_kernel";

@@ -89,6 +89,8 @@ struct tron_plan {
     size_t partial_slices = 0;
     // arc gridding kernel (tron_grid_arc.hip): per (window, tile) run tables built at plan creation, Kaiser-Bessel table
     bool arc = false;
+    bool scatter = false;                 // ... gridded by grid_scatter_kernel (one or two channels, tron_grid_scatter.hip): same tables, one batch per run
+    float scat_wsum = 0;
     int4 *d_arc_hdr = nullptr;
     uint4 *d_arc_ent = nullptr;
     uint32_t *d_arc_win = nullptr;
