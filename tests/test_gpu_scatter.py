@@ -116,10 +116,45 @@ def test_scatter_kernel_dynamic_range(oracle, nc):
     assert rel_l2(got, want) <= 1e-5
     other = _child(data, dict(TRON_GRID_KERNEL="arc"), **fl)
     assert rel_l2(got, other) <= 2e-6
-    # the same data scaled by 2^40 and by 2^-40: the scale is a power of two, so the bits of the result only shift
-    for k in (40, -40):
+    # the same data scaled by 2^12 and by 2^-12: the scale is a power of two, so the bits of the result only shift
+    # (no further: two coils are combined by a root of a sum of squares, whose smallest terms would leave fp32's range)
+    for k in (12, -12):
         s, _ = lib.recon(np.asfortranarray(data * np.float32(2.0 ** k)), adjoint=True, **fl)
         assert np.array_equal(s * np.float32(2.0 ** -k), got)
+
+
+@pytest.mark.parametrize("nc", [1, 2])
+def test_scatter_kernel_rescales_its_sums_when_a_later_round_brings_larger_samples(oracle, nc):
+    """A tile of more than 2 048 records is gridded in rounds of the angle-sorted spoke list, the fixed-point scale following the
+    largest sample seen so far: spokes whose amplitude grows with their line angle by 2^0 .. 2^24 make every later round of the
+    inner tiles shrink the scale and divide the sums gathered so far (grid_scatter_kernel, `ksh`)."""
+    nro, npe = 256, 300                                            # 300 / (pi r) samples per unit area: > 2 048 per tile + halo inside r ~ 60
+    data = synth.kspace(nc, nro, npe, seed=9800 + nc)
+    PHI = np.float32(1.9416089796736116)
+    ang = np.mod((PHI * np.arange(npe, dtype=np.float32)).astype(np.float64), np.pi)       # line angle of spoke pe (src/tron.cu:509, mod pi)
+    amp = np.exp2(np.floor(ang / np.pi * 25.0)).astype(np.float32)                         # 2^0 .. 2^24 with the line angle
+    data = np.asfortranarray((data * amp[None, None, None, :, None]).astype(np.complex64))
+    fl = dict(golden_angle=1, data_undersamp=(npe + 0.5) / nro, prof_slide=npe)
+    assert "grid_scatter_kernel" in _kernel_name(data.shape, **fl)
+    got, _ = lib.recon(data, adjoint=True, **fl)
+    again, _ = lib.recon(data, adjoint=True, **fl)
+    assert np.array_equal(got, again)
+    want, _ = oracle.recon(data, adjoint=1, golden=1, data_undersamp=(npe + 0.5) / nro, prof_slide=npe)
+    assert rel_l2(got, want) <= 1e-5
+
+
+def test_scatter_kernel_first_row_of_a_footprint_when_k_minus_W_rounds(oracle):
+    """Spoke 155 of the golden-angle series has (cos, sin) = (0.8, -0.6) in fp32 (a 3-4-5 triangle): its sample at r = 105 lies at
+    ky = -63.0000038, and row -65 is inside its footprint by the reference's test (|ky - Y| = 1.9999962 < 2, src/tron.cu:341,
+    516) although fl(ky - W) = -65 exactly.  A first build of the kernel took floor(k - W) + 1 for the first row and lost that
+    row's weight: 4e-4 of this sample, 4e-6 of a whole 180-spoke slice."""
+    nro, npe = 256, 180
+    fl = dict(golden_angle=1, data_undersamp=(npe + 0.5) / nro, prof_slide=npe)
+    data = np.zeros((1, 1, nro, npe, 1), dtype=np.complex64, order="F")
+    data[0, 0, 128 + 105, 155, 0] = 1.0 - 0.5j
+    got, _ = lib.recon(data, adjoint=True, **fl)
+    want, _ = oracle.recon(data, adjoint=1, golden=1, data_undersamp=(npe + 0.5) / nro, prof_slide=npe)
+    assert rel_l2(got, want) <= 2e-6
 
 
 def test_shapes_the_scatter_kernel_leaves_to_the_arc_kernel():

@@ -46,6 +46,7 @@ constexpr int kScatMaxSpokes = 512;                 // = kArcMaxSpokes (arc_prep
 template <int NC>
 struct ScatCfg {
     static constexpr int WAVES = NC >= 2 ? 3 : 4;   // workgroups per CU (LDS: 29 / 39 units of 1280 bytes)
+    static constexpr int R = 8;                     // iterations (of 64 records per wave) whose samples wait in registers: one round up to 2 048 records per tile
 };
 
 template <int NC>
@@ -54,17 +55,37 @@ struct ScatLds {
     uint4 run[kScatMaxSpokes];                                   // first sample | down << 31, ulo | len << 10 | offset << 17, cos, sin
     uint32_t band[kScatPitch * kScatPitch];                      // Rlo | Rhi << 16 of the tile's points and its halo (empty outside the grid)
     unsigned long long acc[NC][kScatPitch * kScatPitch];         // (re << 32) + im, fixed point
-    unsigned dmax_bits;
-    unsigned pad[3];
+    unsigned dmax_bits[2];                                        // largest |d| dcf of the rounds so far, by round parity
+    unsigned pad[2];
 };
 
 typedef const __attribute__((address_space(3))) v2f *slds_f2p;
 
+// Phase clock of tools/scatprof.py (-DTRON_SCAT_PROFILE builds only): shader-clock cycles per wave and phase, summed over all waves
+// of all launches since the last read, plus loop counters; production builds carry none of it.
+#ifdef TRON_SCAT_PROFILE
+constexpr int kScatProfSlots = 16, kScatProfCopies = 4096;
+__device__ unsigned long long g_scat_prof[kScatProfCopies * kScatProfSlots];
+#define SPROF_DECL unsigned prof_acc[kScatProfSlots] = {}; unsigned long long prof_t = __builtin_readcyclecounter(); const unsigned long long prof_c0 = prof_t, prof_r0 = __builtin_amdgcn_s_memrealtime()
+#define SPROF_MARK(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); prof_acc[i] += (unsigned)(t_ - prof_t); prof_t = t_; } while (0)
+#define SPROF_COUNT(i, v) do { prof_acc[i] += (unsigned)(v); } while (0)
+#define SPROF_FLUSH do { prof_acc[10] = (unsigned)(__builtin_readcyclecounter() - prof_c0); prof_acc[11] = (unsigned)(__builtin_amdgcn_s_memrealtime() - prof_r0); if (lane == 0) { for (int i_ = 0; i_ < kScatProfSlots; ++i_) if (prof_acc[i_]) atomicAdd(&g_scat_prof[((blockIdx.x * 4 + wave) % kScatProfCopies) * kScatProfSlots + i_], (unsigned long long)prof_acc[i_]); } } while (0)
+#else
+#define SPROF_DECL
+#define SPROF_MARK(i)
+#define SPROF_COUNT(i, v)
+#define SPROF_FLUSH
+#endif
+
 __device__ __forceinline__ int cvt_rpi(float x)      // floor(x + 0.5): one instruction (v_cvt_i32_f32 truncates, rndne + cvt are two)
 {
+#ifdef TRON_SCAT_RN
+    return __float2int_rn(x);
+#else
     int r;
     asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x));
     return r;
+#endif
 }
 
 template <int NC, bool HALF, bool RS>
@@ -76,6 +97,7 @@ grid_scatter_kernel(const GridParams p)
     extern __shared__ __align__(16) unsigned char lds_raw[];
     ScatLds<NC> &L = *reinterpret_cast<ScatLds<NC> *>(lds_raw);
 
+    using C = ScatCfg<NC>;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -110,8 +132,7 @@ grid_scatter_kernel(const GridParams p)
     const slds_f2p lutq = (slds_f2p)(__attribute__((address_space(3))) const void *)L.lut + p.lut_bias;    // entry of table position 0
     const float W = p.W, lscale = p.lut_scale, two_s = 2.0f * p.lut_scale;
     const float dcf_a = p.apply_dcf ? p.dcf_a : 0.0f, dcf_b = p.apply_dcf ? p.dcf_b : 1.0f;
-    const float dcf_max = fmaf(fabsf(dcf_a), (float)rmax, fabsf(dcf_b));
-    const float rs_nro = (float)p.nro, rs_inv = 1.0f / (float)p.nxos;
+        const float rs_nro = (float)p.nro, rs_inv = 1.0f / (float)p.nxos;
     const unsigned nchan_b = (unsigned)p.nchan * (HALF ? 4u : 8u);       // bytes per sample (all channels)
     const float fx0 = (float)(x0 - kScatHalo), fy0 = (float)(y0 - kScatHalo);
 
@@ -126,6 +147,7 @@ grid_scatter_kernel(const GridParams p)
         out_off[qy] = (unsigned)(row * n + col) * 8u;
     }
 
+    SPROF_DECL;
     // the run table of a slice (<= 512 entries, two per thread) is asked for one slice ahead and waits in registers
     uint4 pf_ent[2] = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)};
     int4 hdr_next = make_int4(0, 1, 0, 0);
@@ -150,7 +172,9 @@ grid_scatter_kernel(const GridParams p)
         if (more) hdr_next = p.arc_hdr[(size_t)(z + 1) * p.arc_slice_stride * p.ntiles + tile];
         const unsigned char *in = reinterpret_cast<const unsigned char *>(p.nudata) + ((size_t)z * (size_t)p.in_slice_stride + c0) * (HALF ? 4 : 8);
 
+        SPROF_MARK(0);                                          // set-up (first slice: window table, bands)
         __syncthreads();                                        // the last slice's store has read the sums
+        SPROF_MARK(1);
         // ---- run table -> LDS, sums zeroed ----
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
@@ -162,8 +186,10 @@ grid_scatter_kernel(const GridParams p)
             constexpr int N4 = NC * kScatPitch * kScatPitch / 2;
             for (int i = tid; i < N4; i += kScatThreads) a4[i] = make_uint4(0u, 0u, 0u, 0u);
         }
-        if (tid == 0) L.dmax_bits = 0u;
+        if (tid < 2) L.dmax_bits[tid] = 0u;
+        SPROF_MARK(2);                                          // run table, zeroing
         __syncthreads();
+        SPROF_MARK(3);
         if (more) fetch_table(z + 1, hdr_next);                 // on its way while this slice is gridded
 
         // lane's sample of member entry e at offset k inside the segment -> byte offset of its first channel
@@ -203,55 +229,41 @@ grid_scatter_kernel(const GridParams p)
             }
         };
 
-        // ---- largest |re|, |im| of the tile's samples: wave = segment, lane = radius ----
-        {
-            float mxv = 0.f;
-            for (int m = wave; m < ns; m += 4) {
-                const uint4 e = L.run[m];
-                const int len = (int)((e.y >> 10) & 127u);
-                if (lane < len) {
-                    v2f d[NC];
-                    load_d(sample_off(e, lane), d);
-#pragma unroll
-                    for (int c = 0; c < NC; ++c)
-                        if (c < ncb) mxv = fmaxf(mxv, fmaxf(fabsf(d[c].x), fabsf(d[c].y)));
-                }
+        // This wave's quarter of the run's records, 64 per iteration, R iterations per ROUND: a round first finds every lane's
+        // (spoke, radius) and asks for its sample -- all R loads of a wave in flight together, one memory latency per round -- then
+        // agrees on the largest density-compensated |re|, |im| so far (-> the fixed-point scale; the sums are rescaled if it grew
+        // by a power of two), then scatters from registers.  Most tiles are one round.
+        constexpr int R = C::R;
+        const int quota = ((total + 255) >> 8) << 6;
+        const int iters = quota >> 6;                           // per wave, the same for all four
+        const int pbeg = wave * quota, pend = min(total, pbeg + quota);
+        int m_cur = 0;
+        if (pbeg < pend) {                                      // the member that holds record pbeg
+            int found = -1;
+            for (int i = lane; i < ns; i += 64) {
+                const unsigned sb = L.run[i].y;
+                const int off = (int)(sb >> 17), len = (int)((sb >> 10) & 127u);
+                if (len > 0 && off <= pbeg && pbeg < off + len) found = i;
             }
-            if (!(mxv < 3.0e38f)) mxv = 3.0e38f;                // inf / NaN in the data: the sums saturate to garbage either way; keep S finite
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) mxv = fmaxf(mxv, __shfl_xor(mxv, o));
-            if (lane == 0) atomicMax(&L.dmax_bits, __float_as_uint(mxv));
+            const unsigned long long bm = __ballot(found >= 0);
+            m_cur = bm ? __builtin_amdgcn_readlane(found, (int)__builtin_ctzll(bm)) : 0;
         }
-        __syncthreads();
-        // S = 2^e: max|d| dcf_max mwin wsum 2^e < 2^30
+        float run_max = 0.f;                                    // largest weighted sample of the rounds so far (workgroup-uniform)
         int e2 = 0;
-        {
-            const float bound = __uint_as_float(L.dmax_bits) * dcf_max * (float)max(mwin, 1) * p.scat_wsum;
-            if (bound > 0.f) {
-                const int ex = (int)((__float_as_uint(bound) >> 23) & 255u) - 127;      // bound < 2^(ex + 1)
-                e2 = min(max(29 - ex, -120), 120);
-            }
-        }
-        const float S = __uint_as_float((unsigned)(e2 + 127) << 23), invS = __uint_as_float((unsigned)(127 - e2) << 23);
-
-        // ---- scatter: this wave's quarter of the run's records, 64 at a time ----
-        if (total > 0) {
-            const int quota = ((total + 255) >> 8) << 6;
-            const int pbeg = wave * quota, pend = min(total, pbeg + quota);
-            if (pbeg < pend) {
-                // the member that holds record pbeg
-                int m_cur = 0;
-                {
-                    int found = -1;
-                    for (int i = lane; i < ns; i += 64) {
-                        const unsigned sb = L.run[i].y;
-                        const int off = (int)(sb >> 17), len = (int)((sb >> 10) & 127u);
-                        if (len > 0 && off <= pbeg && pbeg < off + len) found = i;
-                    }
-                    const unsigned long long bm = __ballot(found >= 0);
-                    m_cur = bm ? __builtin_amdgcn_readlane(found, (int)__builtin_ctzll(bm)) : 0;
-                }
-                for (int pbase = pbeg; pbase < pend; pbase += 64) {
+        bool have_scale = false;
+        float S = 1.0f, invS = 1.0f;
+        for (int r0 = 0; r0 < iters; r0 += R) {
+            // ---- front: (spoke, radius) of every lane, samples requested ----
+            v2f dreg[R][NC];
+            unsigned meta[R];                                   // member | offset in the segment << 16 | valid << 31
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                meta[q] = 0u;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) dreg[q][c] = (v2f){0.f, 0.f};
+                const int pbase = pbeg + (r0 + q) * 64;
+                if (r0 + q < iters && pbase < pend) {
+                    SPROF_COUNT(12, 1);
                     const int pos = pbase + lane;
                     // the lane's member: walk over the segments that start inside these 64 records
                     int mem = m_cur;
@@ -273,71 +285,147 @@ grid_scatter_kernel(const GridParams p)
                     }
                     m_cur = __builtin_amdgcn_readlane(mem, 63);
                     const uint4 e = L.run[mem];
-                    const int off = (int)(e.y >> 17), len = (int)((e.y >> 10) & 127u), ulo = (int)(e.y & 1023u);
+                    const int off = (int)(e.y >> 17), len = (int)((e.y >> 10) & 127u);
                     const int k = pos - off;
                     if (pos < pend && k >= 0 && k < len) {
-                        const int u = ulo + k;
-                        const float uf = (float)u;
-                        v2f d[NC];
-                        load_d(sample_off(e, k), d);
-                        const float cs_c = __uint_as_float(e.z), cs_s = __uint_as_float(e.w);
-                        const float kx = uf * cs_c, ky = uf * cs_s;                        // src/tron.cu:514-515
-                        // first column / row X with |k - X| < W: floor(k - W) + 1; footprint = that and the next three
-                        const float ixf = floorf(kx - W) + 1.0f, iyf = floorf(ky - W) + 1.0f;
-                        // table positions of the distance from the first column (exact: the scale is a power of two), and of the third
-                        const v2f t0 = (v2f){kx - ixf, ky - iyf} * (v2f){lscale, lscale};
-                        const v2f t2 = t0 - (v2f){two_s, two_s};
-                        const v2f tt0 = {__builtin_truncf(t0.x), __builtin_truncf(t0.y)}, tt2 = {__builtin_truncf(t2.x), __builtin_truncf(t2.y)};
-                        const v2f f0 = t0 - tt0, f2 = t2 - tt2;
-                        const slds_f2p lx0 = lutq + (int)tt0.x, ly0 = lutq + (int)tt0.y, lx2 = lutq + (int)tt2.x, ly2 = lutq + (int)tt2.y;
-                        auto pair = [&](const slds_f2p q, const float f) -> v2f {
-                            const v2f a0 = q[0], a1 = q[kArcLutEntries], a2 = q[2 * kArcLutEntries];
-                            const v2f fv = {f, f};
-                            return __builtin_elementwise_fma(fv, __builtin_elementwise_fma(fv, a2, a1), a0);
-                        };
-                        const v2f wxa = pair(lx0, f0.x), wxb = pair(lx2, f2.x), wya = pair(ly0, f0.y), wyb = pair(ly2, f2.y);
-                        const float wx[4] = {wxa.x, wxa.y, wxb.x, wxb.y}, wy[4] = {wya.x, wya.y, wyb.x, wyb.y};
-                        // density compensation (src/tron.cu:412: |ro - nro/2| = u, or u's sample) and the fixed-point scale, once per sample
-                        const float sdc = fmaf(dcf_a, RS ? arc_sample_of(uf, rs_nro, rs_inv) : uf, dcf_b) * S;
-                        v2f a[4][NC];
-#pragma unroll
-                        for (int c = 0; c < NC; ++c) {
-                            const v2f ds = d[c] * (v2f){sdc, sdc};
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) a[j][c] = ds * (v2f){wx[j], wx[j]};
-                        }
-                        int bx = (int)(ixf - fx0), by = (int)(iyf - fy0);
-                        bx = min(max(bx, 0), kScatPitch - 4);                              // (never binds: the segments are clipped to tile + W)
-                        by = min(max(by, 0), kScatPitch - 4);
-                        const int base = by * kScatPitch + bx;
-                        const uint32_t *const bnd = &L.band[base];
-                        const unsigned uu = (unsigned)u;
-                        uint32_t bb[16];                                                   // all sixteen bands first: a read behind an atomic waits for it
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) bb[4 * i + j] = bnd[i * kScatPitch + j];
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                const uint32_t b = bb[4 * i + j];
-                                if (uu >= (b & 0xffffu) && uu <= (b >> 16)) {              // src/tron.cu:512, 521
-#pragma unroll
-                                    for (int c = 0; c < NC; ++c)
-                                        if (c < ncb) {
-                                            const v2f v = a[j][c] * (v2f){wy[i], wy[i]};   // src/tron.cu:516, 519
-                                            const int re = cvt_rpi(v.x), im = cvt_rpi(v.y);
-                                            const long long add = ((long long)re << 32) + (long long)im;
-                                            __hip_atomic_fetch_add(&L.acc[c][base + i * kScatPitch + j], (unsigned long long)add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                        }
-                                }
-                            }
+                        meta[q] = (unsigned)mem | ((unsigned)k << 16) | 0x80000000u;
+                        load_d(sample_off(e, k), dreg[q]);
                     }
                 }
             }
+            // ---- largest density-compensated |re|, |im| ----
+            float mxv = 0.f;
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                if (meta[q] >> 31) {
+                    const unsigned sb = L.run[meta[q] & 0xffffu].y;
+                    const float uf = (float)((int)(sb & 1023u) + (int)((meta[q] >> 16) & 127u));
+                    const float sdc = fabsf(fmaf(dcf_a, RS ? arc_sample_of(uf, rs_nro, rs_inv) : uf, dcf_b));
+#pragma unroll
+                    for (int c = 0; c < NC; ++c)
+                        if (c < ncb) mxv = fmaxf(mxv, fmaxf(fabsf(dreg[q][c].x), fabsf(dreg[q][c].y)) * sdc);
+                }
+            }
+            if (!(mxv < 3.0e38f)) mxv = 3.0e38f;                // inf / NaN in the data: garbage either way; keep the scale finite
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mxv = fmaxf(mxv, __shfl_xor(mxv, o));
+            const int slot = (r0 / R) & 1;                      // (two slots, never cleared inside a slice: a fast wave's next round cannot disturb this one)
+            if (lane == 0) atomicMax(&L.dmax_bits[slot], __float_as_uint(fmaxf(mxv, run_max)));
+            SPROF_MARK(4);                                      // front: walk, loads, maximum
+            __syncthreads();
+            SPROF_MARK(5);
+            const float new_max = __uint_as_float(L.dmax_bits[slot]);
+            // S = 2^e: every sum of the tile stays inside 32 bits: max (|d| dcf) * (spokes that can reach one point) * (4 K(0)^2 per spoke) * S < 2^31
+            if (new_max > run_max || !have_scale) {
+                int e_new = 0;
+#ifdef TRON_SCAT_TIGHT                                         // (experiment: how much of the error is the scale's head-room)
+                const float bound = new_max * 2.0f * p.scat_wsum;
+#else
+                const float bound = new_max * (float)max(mwin, 1) * p.scat_wsum;
+#endif
+                if (bound > 0.f) {
+                    const int ex = (int)((__float_as_uint(bound) >> 23) & 255u) - 127;      // bound < 2^(ex + 1)
+                    e_new = min(max(30 - ex, -120), 120);
+                }
+                if (have_scale && run_max > 0.f && e_new < e2) {
+                    // the scale shrinks by 2^k: what has been added so far is divided by it (rounded), all threads, then everyone goes on
+                    const int ksh = min(e2 - e_new, 31);
+                    const long long half_ulp = 1ll << (ksh - 1);
+                    unsigned long long *const flat = &L.acc[0][0];
+                    for (int i = tid; i < NC * kScatPitch * kScatPitch; i += kScatThreads) {
+                        const long long t = (long long)flat[i];
+                        const int im = (int)(unsigned)(t & 0xffffffffll);
+                        const int re = (int)((t - (long long)im) >> 32);
+                        const long long im2 = ((long long)im + half_ulp) >> ksh, re2 = ((long long)re + half_ulp) >> ksh;
+                        flat[i] = (unsigned long long)((re2 << 32) + im2);
+                    }
+                    __syncthreads();
+                }
+                if (new_max > 0.f || !have_scale) e2 = e_new;
+                have_scale = true;
+                run_max = new_max;
+                S = __uint_as_float((unsigned)(e2 + 127) << 23);
+                invS = __uint_as_float((unsigned)(127 - e2) << 23);
+            }
+            // ---- back: scatter from registers ----
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                if (r0 + q >= iters) break;
+                if (meta[q] >> 31) {
+                    const uint4 e = L.run[meta[q] & 0xffffu];
+                    const int u = (int)(e.y & 1023u) + (int)((meta[q] >> 16) & 127u);
+                    const float uf = (float)u;
+                    const float cs_c = __uint_as_float(e.z), cs_s = __uint_as_float(e.w);
+                    const float kx = uf * cs_c, ky = uf * cs_s;                            // src/tron.cu:514-515
+                    // first column / row X with |k - X| < W: floor(k - W) + 1; footprint = that and the next three
+                    // (k - W is rounded at the magnitude of k: where that swallows a distance just below W -- k = -63.0000038, W = 2: k - W
+                    // rounds to -65 -- the column below is still inside by the reference's own test, fabsf(k - X) < W, whose difference is exact)
+                    float ixf = floorf(kx - W) + 1.0f, iyf = floorf(ky - W) + 1.0f;
+                    if (kx - (ixf - 1.0f) < W) ixf -= 1.0f;
+                    if (ky - (iyf - 1.0f) < W) iyf -= 1.0f;
+                    // table positions of the distance from the first column (exact: the scale is a power of two), and of the third
+                    const v2f t0 = (v2f){kx - ixf, ky - iyf} * (v2f){lscale, lscale};
+                    const v2f t2 = t0 - (v2f){two_s, two_s};
+                    const v2f tt0 = {__builtin_truncf(t0.x), __builtin_truncf(t0.y)}, tt2 = {__builtin_truncf(t2.x), __builtin_truncf(t2.y)};
+                    const v2f f0 = t0 - tt0, f2 = t2 - tt2;
+                    const slds_f2p lx0 = lutq + (int)tt0.x, ly0 = lutq + (int)tt0.y, lx2 = lutq + (int)tt2.x, ly2 = lutq + (int)tt2.y;
+                    auto pair = [&](const slds_f2p qq, const float f) -> v2f {
+                        const v2f a0 = qq[0], a1 = qq[kArcLutEntries], a2 = qq[2 * kArcLutEntries];
+                        const v2f fv = {f, f};
+                        return __builtin_elementwise_fma(fv, __builtin_elementwise_fma(fv, a2, a1), a0);
+                    };
+                    const v2f wxa = pair(lx0, f0.x), wxb = pair(lx2, f2.x), wya = pair(ly0, f0.y), wyb = pair(ly2, f2.y);
+                    const float wx[4] = {wxa.x, wxa.y, wxb.x, wxb.y}, wy[4] = {wya.x, wya.y, wyb.x, wyb.y};
+                    int bx = (int)(ixf - fx0), by = (int)(iyf - fy0);
+                    bx = min(max(bx, 0), kScatPitch - 4);                                  // (never binds: the segments are clipped to tile + W)
+                    by = min(max(by, 0), kScatPitch - 4);
+                    const int base = by * kScatPitch + bx;
+                    const uint32_t *const bnd = &L.band[base];
+                    const unsigned uu = (unsigned)u;
+                    uint32_t bb[16];                                                       // all sixteen bands first: a read behind an atomic waits for it
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) bb[4 * i + j] = bnd[i * kScatPitch + j];
+                    // density compensation (src/tron.cu:412: |ro - nro/2| = u, or u's sample) and the fixed-point scale, once per sample
+                    const float sdc = fmaf(dcf_a, RS ? arc_sample_of(uf, rs_nro, rs_inv) : uf, dcf_b) * S;
+                    v2f a[4][NC];
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        const v2f ds = dreg[q][c] * (v2f){sdc, sdc};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) a[j][c] = ds * (v2f){wx[j], wx[j]};
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const uint32_t b = bb[4 * i + j];
+                            // src/tron.cu:512, 521: outside the point's band the weight is zero (the addition of 0 costs less than a branch)
+                            const float wyb2 = (uu >= (b & 0xffffu) && uu <= (b >> 16)) ? wy[i] : 0.0f;
+#pragma unroll
+                            for (int c = 0; c < NC; ++c)
+                                if (c < ncb) {
+                                    const v2f v = a[j][c] * (v2f){wyb2, wyb2};             // src/tron.cu:516, 519
+                                    const int re = cvt_rpi(v.x), im = cvt_rpi(v.y);
+                                    // (re << 32) + im as a signed 64-bit number: low word im, high word re - (im < 0)
+                                    const unsigned lo = (unsigned)im, hi = (unsigned)re + (unsigned)(im >> 31);
+#ifdef TRON_SCAT_U32                                          // (experiment: two 32-bit atomics, high word = re, low word = im, no carry between them)
+                                    unsigned *const w32 = reinterpret_cast<unsigned *>(&L.acc[c][base + i * kScatPitch + j]);
+                                    __hip_atomic_fetch_add(w32, (unsigned)im, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    __hip_atomic_fetch_add(w32 + 1, (unsigned)re, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    (void)hi; (void)lo;
+#else
+                                    __hip_atomic_fetch_add(&L.acc[c][base + i * kScatPitch + j], ((unsigned long long)hi << 32) | lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+                                }
+                        }
+                }
+            }
+            SPROF_MARK(6);                                      // scatter
         }
         __syncthreads();
+        SPROF_MARK(7);
 
         // ---- store: thread = 2x2 points ----
         {
@@ -354,7 +442,11 @@ grid_scatter_kernel(const GridParams p)
                         for (int qx = 0; qx < 2; ++qx) {
                             const long long t = (long long)s2[qx];
                             const int im = (int)(unsigned)(t & 0xffffffffll);
+#ifdef TRON_SCAT_U32
+                            const int re = (int)(unsigned)((unsigned long long)t >> 32);
+#else
                             const int re = (int)((t - (long long)im) >> 32);
+#endif
                             f[2 * qx] = (float)re * os;
                             f[2 * qx + 1] = (float)im * os;
                         }
@@ -368,8 +460,24 @@ grid_scatter_kernel(const GridParams p)
                     }
                 }
         }
+        SPROF_MARK(8);                                          // store
     }
+    SPROF_FLUSH;
 }
+
+#ifdef TRON_SCAT_PROFILE
+extern "C" __attribute__((visibility("default"))) int tron_debug_scat_profile(unsigned long long *out, int n)   // reads and clears the phase clock
+{
+    static unsigned long long h[kScatProfCopies * kScatProfSlots];
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(h, HIP_SYMBOL(g_scat_prof), sizeof(h)) != hipSuccess) return 1;
+    for (int i = 0; i < n && i < kScatProfSlots; ++i) {
+        out[i] = 0;
+        for (int c = 0; c < kScatProfCopies; ++c) out[i] += h[c * kScatProfSlots + i];
+    }
+    for (size_t i = 0; i < sizeof(h) / sizeof(h[0]); ++i) h[i] = 0;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_scat_prof), h, sizeof(h)) != hipSuccess;
+}
+#endif
 
 template <int NC, bool HALF, bool RS>
 static hipError_t launch_scatter_rs(const GridParams &p, int first_plain, hipStream_t s)
