@@ -20,6 +20,19 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+# One-channel plans take grid_scatter_kernel since round 5 (tests/test_gpu_scatter.py); this module keeps testing the arc kernel's
+# one-coil instantiation, which TRON_GRID_KERNEL=arc (read at plan creation) still selects.
+@pytest.fixture(autouse=True, scope="module")
+def _arc_kernel_for_one_channel_too():
+    old = os.environ.get("TRON_GRID_KERNEL")
+    os.environ["TRON_GRID_KERNEL"] = "arc"
+    yield
+    if old is None:
+        os.environ.pop("TRON_GRID_KERNEL", None)
+    else:
+        os.environ["TRON_GRID_KERNEL"] = old
+
+
 def _kernel_name(shape, **flags):
     cfg = lib.default_config(adjoint=1, **flags)
     dims = lib.derive_dims(cfg, shape)

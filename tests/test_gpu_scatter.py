@@ -18,6 +18,20 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+# Plans take this kernel for one channel (fp32 or complex-half k-space) and for two channels of complex-half; two fp32 channels stay with
+# the arc kernel (faster there) unless TRON_GRID_KERNEL=scatter asks for it: set for this whole module (the switch is read at plan
+# creation), so that the two-channel instantiation is tested all the same.
+@pytest.fixture(autouse=True, scope="module")
+def _scatter_for_two_channels_too():
+    old = os.environ.get("TRON_GRID_KERNEL")
+    os.environ["TRON_GRID_KERNEL"] = "scatter"
+    yield
+    if old is None:
+        os.environ.pop("TRON_GRID_KERNEL", None)
+    else:
+        os.environ["TRON_GRID_KERNEL"] = old
+
+
 def _kernel_name(shape, **flags):
     cfg = lib.default_config(adjoint=1, **flags)
     dims = lib.derive_dims(cfg, shape)
@@ -47,8 +61,6 @@ CASES = [
     (1, 128, 64, 5, dict(golden_angle=1, skip_angles=7)),            # smallest grid (4 x 4 tiles)
     (2, 256, 100, 2, dict(golden_angle=0)),                         # linear angles: samples at exactly |x| = W on the axis spokes
     (1, 256, 120, 2, dict(golden_angle=0)),
-    (2, 256, 120, 2, dict(golden_angle=1, kernwidth=1.5)),          # W = 1.5: three columns per footprint, the fourth has weight 0
-    (1, 256, 120, 2, dict(golden_angle=0, kernwidth=1.25)),         # W = 1.25, linear angles
     (2, 512, 402, 2, dict(golden_angle=1)),                         # the metric's shape
     (1, 1024, 60, 1, dict(golden_angle=1)),                         # 1024^2 grid, few spokes
     (2, 256, 100, 2, dict(golden_angle=1, gridos=1.5)),             # nro != nxos: radius r reads sample (r nro) / nxos (src/tron.cu:517)
@@ -158,6 +170,14 @@ def test_scatter_kernel_first_row_of_a_footprint_when_k_minus_W_rounds(oracle):
 
 
 def test_shapes_the_scatter_kernel_leaves_to_the_arc_kernel():
+    os.environ.pop("TRON_GRID_KERNEL", None)              # the plan's own choice
+    try:
+        assert "grid_scatter_kernel" in _kernel_name((1, 1, 256, 100, 1), golden_angle=1, data_undersamp=0.39)
+        assert "grid_arc_kernel" in _kernel_name((2, 1, 256, 100, 1), golden_angle=1, data_undersamp=0.39)                  # two fp32 channels
+        assert "grid_scatter_kernel" in _kernel_name((2, 1, 256, 100, 1), golden_angle=1, data_undersamp=0.39, input_half=1)
+    finally:
+        os.environ["TRON_GRID_KERNEL"] = "scatter"
     assert "grid_arc_kernel" in _kernel_name((4, 1, 256, 100, 1), golden_angle=1, data_undersamp=0.39)
     assert "grid_arc_kernel" in _kernel_name((2, 1, 256, 100, 1), golden_angle=1, data_undersamp=0.39, kernwidth=2.5)     # six points per axis
+    assert "grid_arc_kernel" in _kernel_name((2, 1, 256, 100, 1), golden_angle=1, data_undersamp=0.39, kernwidth=1.5)     # the inner points are not always inside their band
     assert "grid_scatter_kernel" in _kernel_name((2, 1, 256, 100, 1), golden_angle=1, data_undersamp=0.39)

@@ -11,7 +11,7 @@ from tron_amd import lib
 nc = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 nz = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 NRO, NPE = 512, int(os.environ.get("NPE", "402"))
-NAMES = ["set-up (first slice: window table, bands)", "barrier", "run table, zeroing", "barrier", "maximum", "barrier", "scatter", "barrier", "store"]
+NAMES = ["set-up (first slice: window table)", "barrier", "first member of the quarter", "walk", "wait for the samples, maximum", "barrier", "scatter", "barrier", "store, zeroing, next table", "entries, loads issued"]
 cfg = lib.default_config(adjoint=1, golden_angle=1, data_undersamp=(NPE + 0.5) / NRO, prof_slide=NPE, kb_mode=lib.KB_FAST)
 dims = lib.derive_dims(cfg, (nc, 1, NRO, NPE * nz, 1))
 rng = np.random.default_rng(1)
@@ -30,7 +30,7 @@ with lib.Plan(cfg, dims) as plan:
     assert fn(buf, 16) == 0
     plan.adjoint_device(d_out.ptr, d_in.ptr, 0, nz, 1); plan.sync()
     assert fn(buf, 16) == 0
-tot = float(sum(buf[:9]))
+tot = float(sum(buf[:10]))
 print(f"nc={nc} nz={nz}: {tot:.3e} wave-cycles in total ({tot / nz:.3e} per slice)")
 for name, v in zip(NAMES, buf):
     print(f"  {name:44s} {100.0 * v / tot:6.2f} %")

@@ -45,18 +45,28 @@ constexpr int kScatMaxSpokes = 512;                 // = kArcMaxSpokes (arc_prep
 
 template <int NC>
 struct ScatCfg {
-    static constexpr int WAVES = NC >= 2 ? 3 : 4;   // workgroups per CU (LDS: 29 / 39 units of 1280 bytes)
-    static constexpr int R = 8;                     // iterations (of 64 records per wave) whose samples wait in registers: one round up to 2 048 records per tile
+#ifndef TRON_SCAT_WAVES1
+#define TRON_SCAT_WAVES1 5
+#define TRON_SCAT_R1 6
+#endif
+    static constexpr int WAVES = NC >= 2 ? 4 : TRON_SCAT_WAVES1;   // workgroups per CU (LDS: 19 / 29 units of 1280 bytes; registers: 96 / 128)
+    // iterations (of 64 records per wave) whose samples wait in registers: one round up to 1 536 / 2 048 records per tile
+    static constexpr int R = NC >= 2 ? 8 : TRON_SCAT_R1;
 };
+
+constexpr int kScatLutS = 64;                       // pieces per grid unit of the pair table this kernel copies (kb_pair_lut_scale: 64 for every width it takes)
 
 template <int NC>
 struct ScatLds {
-    float2 lut[3 * kArcLutEntries];                              // Kaiser-Bessel pair table (build_kb_pair_lut)
+    // The two stretches of the Kaiser-Bessel pair table (build_kb_pair_lut) a sample can reach, planes c0 | c1 | c2: its first column
+    // lies W-1 <= d < W from it (positions (W-1) s .. W s), the third d - 2 (positions (W-3) s .. (W-2) s): 2 x 65 entries of 400.
+    float2 lutA[3][kScatLutS + 2];
+    float2 lutB[3][kScatLutS + 2];
     uint4 run[kScatMaxSpokes];                                   // first sample | down << 31, ulo | len << 10 | offset << 17, cos, sin
-    uint32_t band[kScatPitch * kScatPitch];                      // Rlo | Rhi << 16 of the tile's points and its halo (empty outside the grid)
     unsigned long long acc[NC][kScatPitch * kScatPitch];         // (re << 32) + im, fixed point
     unsigned dmax_bits[2];                                        // largest |d| dcf of the rounds so far, by round parity
     unsigned pad[2];
+    unsigned junk[4][64];                                         // where the L2 prefetch of the next slice's samples lands (never read)
 };
 
 typedef const __attribute__((address_space(3))) v2f *slds_f2p;
@@ -121,15 +131,16 @@ grid_scatter_kernel(const GridParams p)
         if ((float)(ax * ax + ay * ay) > lim * lim) return;
     }
 
-    // ---- once per workgroup: window table, band of the tile's points and their halo ----
-    for (int i = tid; i < 3 * kArcLutEntries; i += kScatThreads) L.lut[i] = p.kb_lut[i];
-    for (int i = tid; i < kScatPitch * kScatPitch; i += kScatThreads) {
-        const int X = x0 - kScatHalo + i % kScatPitch, Y = y0 - kScatHalo + i / kScatPitch;
-        uint32_t b = 1u;                                          // Rlo 1 > Rhi 0: nothing passes
-        if (X >= -h && X < h && Y >= -h && Y < h) b = p.band[(size_t)(Y + h) * n + (X + h)];
-        L.band[i] = b;
+    // ---- once per workgroup: the two stretches of the window table ----
+    const int ws = (int)(p.W * p.lut_scale + 0.5f);                   // W s, an integer (kb_pair_lut_scale)
+    const int iA0 = ws - kScatLutS, iB0 = ws - 3 * kScatLutS;         // first entries: positions (W - 1) s and (W - 3) s
+    for (int i = tid; i < 3 * (kScatLutS + 1); i += kScatThreads) {
+        const int pl = i / (kScatLutS + 1), k = i - pl * (kScatLutS + 1);
+        L.lutA[pl][k] = p.kb_lut[pl * kArcLutEntries + p.lut_bias + iA0 + k];
+        L.lutB[pl][k] = p.kb_lut[pl * kArcLutEntries + p.lut_bias + iB0 + k];
     }
-    const slds_f2p lutq = (slds_f2p)(__attribute__((address_space(3))) const void *)L.lut + p.lut_bias;    // entry of table position 0
+    const slds_f2p lutA = (slds_f2p)(__attribute__((address_space(3))) const void *)&L.lutA[0][0] - iA0;    // entry of table position 0 (virtual)
+    const slds_f2p lutB = (slds_f2p)(__attribute__((address_space(3))) const void *)&L.lutB[0][0] - iB0;
     const float W = p.W, lscale = p.lut_scale, two_s = 2.0f * p.lut_scale;
     const float dcf_a = p.apply_dcf ? p.dcf_a : 0.0f, dcf_b = p.apply_dcf ? p.dcf_b : 1.0f;
         const float rs_nro = (float)p.nro, rs_inv = 1.0f / (float)p.nxos;
@@ -158,9 +169,33 @@ grid_scatter_kernel(const GridParams p)
         for (int k = 0; k < 2; ++k)
             if (tid + k * kScatThreads < hh.x) pf_ent[k] = ent[tid + k * kScatThreads];
     };
+    // the tile of sums is all zeros when a slice begins: its halo ring (everything but the 32 x 32 points) is dealt to the threads
+    // here and cleared again by each slice's store, which also clears the points it has just read
+    auto halo_index = [&](const int k) -> int {                 // k-th element of the ring, 0 <= k < 40^2 - 32^2
+        constexpr int top = kScatHalo * kScatPitch;             // 4 full rows above, 4 below, 2 x 4 columns beside the 32 rows
+        if (k < top) return k;
+        if (k < 2 * top) return (kScatPitch - kScatHalo) * kScatPitch + (k - top);
+        const int m = k - 2 * top, row = m >> 3, c8 = m & 7;
+        return (kScatHalo + row) * kScatPitch + (c8 < kScatHalo ? c8 : kScatTile + c8);
+    };
+    constexpr int kRing = kScatPitch * kScatPitch - kScatTile * kScatTile;
+    auto table_to_lds = [&](const int ns_) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = tid + k * kScatThreads;
+            if (i < ns_) L.run[i] = pf_ent[k];
+        }
+    };
     if (zg * zper < p.nslices) {
         hdr_next = p.arc_hdr[(size_t)(zg * zper) * p.arc_slice_stride * p.ntiles + tile];
         fetch_table(zg * zper, hdr_next);
+        table_to_lds(hdr_next.x);
+    }
+    {
+        uint4 *const a4 = reinterpret_cast<uint4 *>(&L.acc[0][0]);
+        constexpr int N4 = NC * kScatPitch * kScatPitch / 2;
+        for (int i = tid; i < N4; i += kScatThreads) a4[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (tid < 2) L.dmax_bits[tid] = 0u;
     }
 
     for (int iz = 0; iz < zper; ++iz) {
@@ -172,37 +207,22 @@ grid_scatter_kernel(const GridParams p)
         if (more) hdr_next = p.arc_hdr[(size_t)(z + 1) * p.arc_slice_stride * p.ntiles + tile];
         const unsigned char *in = reinterpret_cast<const unsigned char *>(p.nudata) + ((size_t)z * (size_t)p.in_slice_stride + c0) * (HALF ? 4 : 8);
 
-        SPROF_MARK(0);                                          // set-up (first slice: window table, bands)
-        __syncthreads();                                        // the last slice's store has read the sums
+        SPROF_MARK(0);                                          // set-up (first slice: window table), table -> LDS
+        __syncthreads();                                        // this slice's run table is in LDS, the sums are zero
         SPROF_MARK(1);
-        // ---- run table -> LDS, sums zeroed ----
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int i = tid + k * kScatThreads;
-            if (i < ns) L.run[i] = pf_ent[k];
-        }
-        {
-            uint4 *const a4 = reinterpret_cast<uint4 *>(&L.acc[0][0]);
-            constexpr int N4 = NC * kScatPitch * kScatPitch / 2;
-            for (int i = tid; i < N4; i += kScatThreads) a4[i] = make_uint4(0u, 0u, 0u, 0u);
-        }
-        if (tid < 2) L.dmax_bits[tid] = 0u;
-        SPROF_MARK(2);                                          // run table, zeroing
-        __syncthreads();
-        SPROF_MARK(3);
         if (more) fetch_table(z + 1, hdr_next);                 // on its way while this slice is gridded
 
         // lane's sample of member entry e at offset k inside the segment -> byte offset of its first channel
         auto sample_off = [&](const uint4 e, const int k) -> unsigned {
             const unsigned first = e.x & 0x7fffffffu;
-            unsigned s;
+            unsigned so;
             if constexpr (RS) {                                  // `first` is the spoke's centre sample: radius u reads sample (u nro) / nxos (src/tron.cu:517)
-                const unsigned so = (unsigned)(int)arc_sample_of((float)((int)(e.y & 1023u) + k), rs_nro, rs_inv);
-                s = (e.x >> 31) ? first - so : first + so;
+                const unsigned t = (unsigned)(int)arc_sample_of((float)((int)(e.y & 1023u) + k), rs_nro, rs_inv);
+                so = (e.x >> 31) ? first - t : first + t;
             } else {
-                s = (e.x >> 31) ? first - (unsigned)k : first + (unsigned)k;
+                so = (e.x >> 31) ? first - (unsigned)k : first + (unsigned)k;
             }
-            return s * nchan_b;
+            return so * nchan_b;
         };
         auto load_d = [&](const unsigned off, v2f (&d)[NC]) {
             if constexpr (HALF) {
@@ -248,6 +268,7 @@ grid_scatter_kernel(const GridParams p)
             const unsigned long long bm = __ballot(found >= 0);
             m_cur = bm ? __builtin_amdgcn_readlane(found, (int)__builtin_ctzll(bm)) : 0;
         }
+        SPROF_MARK(2);                                          // first member of the wave's quarter
         float run_max = 0.f;                                    // largest weighted sample of the rounds so far (workgroup-uniform)
         int e2 = 0;
         bool have_scale = false;
@@ -255,51 +276,85 @@ grid_scatter_kernel(const GridParams p)
         for (int r0 = 0; r0 < iters; r0 += R) {
             // ---- front: (spoke, radius) of every lane, samples requested ----
             v2f dreg[R][NC];
-            unsigned meta[R];                                   // member | offset in the segment << 16 | valid << 31
+            unsigned meta[R];                                   // member | radius << 9 | valid << 31
+            {
+                // The lane's member.  Candidates: the run entries behind the wave's current member, one per lane (read again when the wave has
+                // moved 32 members on).  A candidate whose segment starts inside the lane's 64 records marks its start in a 64-word
+                // scratch row (ds_max: an empty segment shares its successor's start, the later one wins), every lane reads its own word and a
+                // running maximum over the lanes (DPP) gives the last start at or before it -- no loop over the segments.
+                int cbase = m_cur;
+                unsigned offc = 32767u;                         // (beyond every record)
+                { const int ci = cbase + 1 + lane; if (ci < ns) offc = L.run[ci].y >> 17; }
+                unsigned *const row = &L.junk[wave][0];
 #pragma unroll
-            for (int q = 0; q < R; ++q) {
-                meta[q] = 0u;
-#pragma unroll
-                for (int c = 0; c < NC; ++c) dreg[q][c] = (v2f){0.f, 0.f};
-                const int pbase = pbeg + (r0 + q) * 64;
-                if (r0 + q < iters && pbase < pend) {
-                    SPROF_COUNT(12, 1);
-                    const int pos = pbase + lane;
-                    // the lane's member: walk over the segments that start inside these 64 records
-                    int mem = m_cur;
-                    {
-                        int cbase = m_cur;
-                        for (;;) {
+                for (int q = 0; q < R; ++q) {
+                    meta[q] = 0u;
+                    const int pbase = pbeg + (r0 + q) * 64;
+                    if (r0 + q < iters && pbase < pend) {
+                        SPROF_COUNT(12, 1);
+                        const int pos = pbase + lane;
+                        if (m_cur - cbase >= 32) {
+                            cbase = m_cur;
                             const int ci = cbase + 1 + lane;
-                            const unsigned sbc = ci < ns ? L.run[ci].y : 0xfffe0000u;       // (offset 32767: beyond every record)
-                            bool done = false;
-                            for (int j = 0; j < 64; ++j) {
-                                const unsigned sbj = (unsigned)__builtin_amdgcn_readlane((int)sbc, j);
-                                const int offj = (int)(sbj >> 17);
-                                if (offj >= pbase + 64) { done = true; break; }
-                                if (pos >= offj) mem = cbase + 1 + j;
-                            }
-                            if (done || cbase + 65 >= ns) break;
-                            cbase += 64;
+                            offc = ci < ns ? L.run[ci].y >> 17 : 32767u;
                         }
+                        int mem = m_cur;
+                        int cb = cbase;
+                        unsigned oc = offc;
+                        for (;;) {
+                            // (lanes talk through LDS here without a workgroup barrier: the LDS executes a wave's instructions in order; the atomics
+                            // and the wave barriers keep the compiler from forwarding the cleared word to the read)
+                            __hip_atomic_store(&row[lane], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                            __builtin_amdgcn_wave_barrier();
+                            const unsigned rel = oc - (unsigned)pbase;
+                            if (rel < 64u) __hip_atomic_fetch_max(&row[rel], (unsigned)lane + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                            __builtin_amdgcn_wave_barrier();
+                            int v = (int)__hip_atomic_load(&row[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                            // inclusive running maximum over the lanes
+                            v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false));      // row_shr:1
+                            v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false));      // row_shr:2
+                            v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false));      // row_shr:4
+                            v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false));      // row_shr:8
+                            v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false));      // row_bcast:15 into rows 1 and 3
+                            v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false));      // row_bcast:31 into rows 2 and 3
+                            if (v > 0) mem = cb + v;
+                            const unsigned last = (unsigned)__builtin_amdgcn_readlane((int)oc, 63);
+                            if (last >= (unsigned)(pbase + 64) || cb + 65 >= ns) break;
+                            cb += 64;                           // (more than 64 segments start inside 64 records: the next candidates)
+                            const int ci = cb + 1 + lane;
+                            oc = ci < ns ? L.run[ci].y >> 17 : 32767u;
+                        }
+                        m_cur = __builtin_amdgcn_readlane(mem, 63);
+                        meta[q] = (unsigned)mem | ((unsigned)pos << 9);      // (the record's position for now)
                     }
-                    m_cur = __builtin_amdgcn_readlane(mem, 63);
-                    const uint4 e = L.run[mem];
-                    const int off = (int)(e.y >> 17), len = (int)((e.y >> 10) & 127u);
-                    const int k = pos - off;
-                    if (pos < pend && k >= 0 && k < len) {
-                        meta[q] = (unsigned)mem | ((unsigned)k << 16) | 0x80000000u;
-                        load_d(sample_off(e, k), dreg[q]);
+                }
+                SPROF_MARK(3);                                  // walk
+                // the members' entries (independent LDS reads), then the samples (independent loads)
+#pragma unroll
+                for (int q = 0; q < R; ++q) {
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) dreg[q][c] = (v2f){0.f, 0.f};
+                    const int pbase = pbeg + (r0 + q) * 64;
+                    if (r0 + q < iters && pbase < pend) {
+                        const int mem = (int)(meta[q] & 511u), pos = (int)(meta[q] >> 9);
+                        const uint4 e = L.run[mem];
+                        const int off = (int)(e.y >> 17), len = (int)((e.y >> 10) & 127u);
+                        const int k = pos - off;
+                        meta[q] = 0u;
+                        if (pos < pend && k >= 0 && k < len) {
+                            meta[q] = (unsigned)mem | ((unsigned)((int)(e.y & 1023u) + k) << 9) | 0x80000000u;
+                            load_d(sample_off(e, k), dreg[q]);
+                        }
                     }
                 }
             }
+            SPROF_MARK(9);                                      // entries, loads issued
             // ---- largest density-compensated |re|, |im| ----
             float mxv = 0.f;
 #pragma unroll
             for (int q = 0; q < R; ++q) {
                 if (meta[q] >> 31) {
-                    const unsigned sb = L.run[meta[q] & 0xffffu].y;
-                    const float uf = (float)((int)(sb & 1023u) + (int)((meta[q] >> 16) & 127u));
+                    const float uf = (float)((meta[q] >> 9) & 1023u);
                     const float sdc = fabsf(fmaf(dcf_a, RS ? arc_sample_of(uf, rs_nro, rs_inv) : uf, dcf_b));
 #pragma unroll
                     for (int c = 0; c < NC; ++c)
@@ -318,11 +373,7 @@ grid_scatter_kernel(const GridParams p)
             // S = 2^e: every sum of the tile stays inside 32 bits: max (|d| dcf) * (spokes that can reach one point) * (4 K(0)^2 per spoke) * S < 2^31
             if (new_max > run_max || !have_scale) {
                 int e_new = 0;
-#ifdef TRON_SCAT_TIGHT                                         // (experiment: how much of the error is the scale's head-room)
-                const float bound = new_max * 2.0f * p.scat_wsum;
-#else
                 const float bound = new_max * (float)max(mwin, 1) * p.scat_wsum;
-#endif
                 if (bound > 0.f) {
                     const int ex = (int)((__float_as_uint(bound) >> 23) & 255u) - 127;      // bound < 2^(ex + 1)
                     e_new = min(max(30 - ex, -120), 120);
@@ -347,19 +398,41 @@ grid_scatter_kernel(const GridParams p)
                 S = __uint_as_float((unsigned)(e2 + 127) << 23);
                 invS = __uint_as_float((unsigned)(127 - e2) << 23);
             }
+            // ---- the NEXT slice's samples on their way into L2 (its run table has arrived in registers: every thread holds two entries and
+            // touches the 128-byte lines of their segments); that slice's front then waits for L2, not for HBM ----
+#ifdef TRON_SCAT_PREFETCH
+            if (more && r0 == 0) {
+                const unsigned char *const in_next = in + (size_t)p.in_slice_stride * (HALF ? 4 : 8);
+                const unsigned junk = lds_addr(&L.junk[wave][0]);
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const uint4 e = pf_ent[k];
+                    const int len = (int)((e.y >> 10) & 127u);
+                    if (tid + k * kScatThreads < hdr_next.x && len > 0) {
+                        const unsigned o0 = sample_off(e, 0), o1 = sample_off(e, len - 1);
+                        const unsigned hi = max(o0, o1) + (unsigned)(NC * (HALF ? 4 : 8)) - 1u;
+                        unsigned a = min(o0, o1) & ~127u;
+#pragma unroll
+                        for (int i = 0; i < (NC == 1 ? 5 : 8); ++i) {
+                            if (a <= hi) lds_dma4_s(in_next, a, junk);        // (LDS-DMA: no destination register to keep alive; the four bytes land in a scratch row)
+                            a += 128u;
+                        }
+                    }
+                }
+            }
+#endif
             // ---- back: scatter from registers ----
 #pragma unroll
             for (int q = 0; q < R; ++q) {
                 if (r0 + q >= iters) break;
                 if (meta[q] >> 31) {
-                    const uint4 e = L.run[meta[q] & 0xffffu];
-                    const int u = (int)(e.y & 1023u) + (int)((meta[q] >> 16) & 127u);
-                    const float uf = (float)u;
-                    const float cs_c = __uint_as_float(e.z), cs_s = __uint_as_float(e.w);
+                    const float2 ecs = *reinterpret_cast<const float2 *>(&L.run[meta[q] & 511u].z);
+                    const float uf = (float)((meta[q] >> 9) & 1023u);
+                    const float cs_c = ecs.x, cs_s = ecs.y;
                     const float kx = uf * cs_c, ky = uf * cs_s;                            // src/tron.cu:514-515
-                    // first column / row X with |k - X| < W: floor(k - W) + 1; footprint = that and the next three
-                    // (k - W is rounded at the magnitude of k: where that swallows a distance just below W -- k = -63.0000038, W = 2: k - W
-                    // rounds to -65 -- the column below is still inside by the reference's own test, fabsf(k - X) < W, whose difference is exact)
+                    // First column / row X with |k - X| < W: floor(k - W) + 1, the footprint = that and the next three.  (k - W is rounded
+                    // at the magnitude of k: where that swallows a distance just below W -- k = -63.0000038, W = 2: k - W rounds to -65 --
+                    // the column below is still inside by the reference's own test, fabsf(k - X) < W, whose difference is exact.)
                     float ixf = floorf(kx - W) + 1.0f, iyf = floorf(ky - W) + 1.0f;
                     if (kx - (ixf - 1.0f) < W) ixf -= 1.0f;
                     if (ky - (iyf - 1.0f) < W) iyf -= 1.0f;
@@ -368,9 +441,9 @@ grid_scatter_kernel(const GridParams p)
                     const v2f t2 = t0 - (v2f){two_s, two_s};
                     const v2f tt0 = {__builtin_truncf(t0.x), __builtin_truncf(t0.y)}, tt2 = {__builtin_truncf(t2.x), __builtin_truncf(t2.y)};
                     const v2f f0 = t0 - tt0, f2 = t2 - tt2;
-                    const slds_f2p lx0 = lutq + (int)tt0.x, ly0 = lutq + (int)tt0.y, lx2 = lutq + (int)tt2.x, ly2 = lutq + (int)tt2.y;
+                    const slds_f2p lx0 = lutA + (int)tt0.x, ly0 = lutA + (int)tt0.y, lx2 = lutB + (int)tt2.x, ly2 = lutB + (int)tt2.y;
                     auto pair = [&](const slds_f2p qq, const float f) -> v2f {
-                        const v2f a0 = qq[0], a1 = qq[kArcLutEntries], a2 = qq[2 * kArcLutEntries];
+                        const v2f a0 = qq[0], a1 = qq[kScatLutS + 2], a2 = qq[2 * (kScatLutS + 2)];
                         const v2f fv = {f, f};
                         return __builtin_elementwise_fma(fv, __builtin_elementwise_fma(fv, a2, a1), a0);
                     };
@@ -380,13 +453,22 @@ grid_scatter_kernel(const GridParams p)
                     bx = min(max(bx, 0), kScatPitch - 4);                                  // (never binds: the segments are clipped to tile + W)
                     by = min(max(by, 0), kScatPitch - 4);
                     const int base = by * kScatPitch + bx;
-                    const uint32_t *const bnd = &L.band[base];
-                    const unsigned uu = (unsigned)u;
-                    uint32_t bb[16];                                                       // all sixteen bands first: a read behind an atomic waits for it
+                    // The band of src/tron.cu:498-502, 512, 521 -- ceil(R - W) <= u <= floor(R + W), R = hypotf(X, Y) -- as
+                    // (u - W)^2 <= X^2 + Y^2 <= (u + W)^2: the same set for integer u (checked against the host's band table point by point before
+                    // a plan takes this kernel, scatter_band_is_analytic), all three exact in fp32.  The four points next to the sample lie
+                    // within sqrt(2) < W = 2 of it and pass always.
+                    // As ONE comparison: |X^2 + Y^2 - C| <= D with C = (A + B) / 2, D = (B - A) / 2, A = (u - W)^2 (0 below W), B = (u + W)^2 --
+                    // integers or multiples of 1/2 below 2^23: every term and difference exact.
+                    const float um = fmaxf(uf - W, 0.0f), up = uf + W;
+                    const float bandA = um * um, bandB = up * up;
+                    const float bandC = 0.5f * (bandA + bandB), bandD = 0.5f * (bandB - bandA);
+                    float xc[4], y2[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) bb[4 * i + j] = bnd[i * kScatPitch + j];
+                    for (int j = 0; j < 4; ++j) {
+                        const float xj = ixf + (float)j, yj = iyf + (float)j;
+                        xc[j] = xj * xj - bandC;
+                        y2[j] = yj * yj;
+                    }
                     // density compensation (src/tron.cu:412: |ro - nro/2| = u, or u's sample) and the fixed-point scale, once per sample
                     const float sdc = fmaf(dcf_a, RS ? arc_sample_of(uf, rs_nro, rs_inv) : uf, dcf_b) * S;
                     v2f a[4][NC];
@@ -400,9 +482,10 @@ grid_scatter_kernel(const GridParams p)
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            const uint32_t b = bb[4 * i + j];
-                            // src/tron.cu:512, 521: outside the point's band the weight is zero (the addition of 0 costs less than a branch)
-                            const float wyb2 = (uu >= (b & 0xffffu) && uu <= (b >> 16)) ? wy[i] : 0.0f;
+                            float wyb2 = wy[i];
+                            if (!((i == 1 || i == 2) && (j == 1 || j == 2))) {
+                                wyb2 = fabsf(xc[j] + y2[i]) <= bandD ? wy[i] : 0.0f;      // outside the point's band: weight zero (adding 0 costs less than a branch)
+                            }
 #pragma unroll
                             for (int c = 0; c < NC; ++c)
                                 if (c < ncb) {
@@ -410,43 +493,33 @@ grid_scatter_kernel(const GridParams p)
                                     const int re = cvt_rpi(v.x), im = cvt_rpi(v.y);
                                     // (re << 32) + im as a signed 64-bit number: low word im, high word re - (im < 0)
                                     const unsigned lo = (unsigned)im, hi = (unsigned)re + (unsigned)(im >> 31);
-#ifdef TRON_SCAT_U32                                          // (experiment: two 32-bit atomics, high word = re, low word = im, no carry between them)
-                                    unsigned *const w32 = reinterpret_cast<unsigned *>(&L.acc[c][base + i * kScatPitch + j]);
-                                    __hip_atomic_fetch_add(w32, (unsigned)im, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                    __hip_atomic_fetch_add(w32 + 1, (unsigned)re, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                    (void)hi; (void)lo;
-#else
                                     __hip_atomic_fetch_add(&L.acc[c][base + i * kScatPitch + j], ((unsigned long long)hi << 32) | lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
                                 }
                         }
                 }
             }
             SPROF_MARK(6);                                      // scatter
         }
-        __syncthreads();
+        __syncthreads();                                        // every sample of the slice has been added
         SPROF_MARK(7);
 
-        // ---- store: thread = 2x2 points ----
+        // ---- store: thread = 2x2 points; the points read and the thread's share of the halo ring are zeroed for the next slice ----
         {
             const float os = invS * p.scale;                    // src/tron.cu:532-534
             unsigned char *zbase = reinterpret_cast<unsigned char *>(p.udata + (size_t)z * p.out_z + (size_t)c0 * p.out_c);
 #pragma unroll
-            for (int c = 0; c < NC; ++c)
+            for (int c = 0; c < NC; ++c) {
                 if (c < ncb) {
 #pragma unroll
                     for (int qy = 0; qy < 2; ++qy) {
-                        const unsigned long long *const s2 = &L.acc[c][(my + qy + kScatHalo) * kScatPitch + mx + kScatHalo];
+                        unsigned long long *const s2 = &L.acc[c][(my + qy + kScatHalo) * kScatPitch + mx + kScatHalo];
                         float f[4];
 #pragma unroll
                         for (int qx = 0; qx < 2; ++qx) {
                             const long long t = (long long)s2[qx];
+                            s2[qx] = 0ull;
                             const int im = (int)(unsigned)(t & 0xffffffffll);
-#ifdef TRON_SCAT_U32
-                            const int re = (int)(unsigned)((unsigned long long)t >> 32);
-#else
                             const int re = (int)((t - (long long)im) >> 32);
-#endif
                             f[2 * qx] = (float)re * os;
                             f[2 * qx + 1] = (float)im * os;
                         }
@@ -459,8 +532,12 @@ grid_scatter_kernel(const GridParams p)
                         *o = v;
                     }
                 }
+                for (int k = tid; k < kRing; k += kScatThreads) L.acc[c][halo_index(k)] = 0ull;
+            }
+            if (tid < 2) L.dmax_bits[tid] = 0u;
+            if (more) table_to_lds(hdr_next.x);                 // (every wave is past the scatter: the old table is done with)
         }
-        SPROF_MARK(8);                                          // store
+        SPROF_MARK(8);                                          // store, next slice's table
     }
     SPROF_FLUSH;
 }
@@ -504,18 +581,23 @@ static hipError_t launch_scatter_nc(const GridParams &p, int half_in, int first_
     return rs ? launch_scatter_rs<NC, false, true>(p, first_plain, s) : launch_scatter_rs<NC, false, false>(p, first_plain, s);
 }
 
-// The plans the arc kernel takes (grid_arc_supported) with one or two channels and a window of at most four points per axis.
+// The plans the arc kernel takes (grid_arc_supported) with one or two channels and a window of four points per axis; the caller has
+// checked scatter_band_is_analytic for the plan's grid and width.
 bool grid_scatter_supported(int nchan, int nxos, int nro, int npe, float W, int half_in)
 {
     (void)half_in;                                              // fp32 and complex-half k-space alike: the samples are read by plain loads
-    return (nchan == 1 || nchan == 2) && W <= 2.0f && grid_arc_supported(nchan, nxos, nro, npe, W, 0);
+    // W = 2 (the reference's default, src/tron.cu:69): four columns per footprint, of which the inner two lie within 1 of the sample, so that the
+    // four inner points (within sqrt(2) < W) are always inside their band; the band test's squares are exact; the pair table has 64 pieces
+    // per unit.  Other widths keep the arc kernel.
+    return (nchan == 1 || nchan == 2) && W == 2.0f && kb_pair_lut_scale(W, kArcLutEntries) == kScatLutS
+           && grid_arc_supported(nchan, nxos, nro, npe, W, 0);
 }
 
 // p.tile_order[first_plain ...] must list the 32x32 tiles; run tables from arc_prep_kernel with ONE batch per run (ArcPrepParams::nrec >= 32767).
 hipError_t launch_grid_scatter(const GridParams &p, int half_in, int first_plain, hipStream_t s)
 {
     const int nc = p.nchan - p.coil0;
-    if (p.out_p != 1 || p.inner_r0 <= 0 || !p.arc_hdr || !p.arc_ent || !p.kb_lut || p.lut_entries > kArcLutEntries || p.npe > kArcMaxNpe || !(p.scat_wsum > 0.f)
+    if (p.out_p != 1 || p.inner_r0 <= 0 || !p.arc_hdr || !p.arc_ent || !p.kb_lut || p.lut_entries > kArcLutEntries || p.npe > kArcMaxNpe || !(p.scat_wsum > 0.f) || (int)p.lut_scale != kScatLutS
         || !grid_scatter_supported(nc, p.nxos, p.nro, p.npe, p.W, half_in) || (reinterpret_cast<uintptr_t>(p.nudata) & (half_in ? 3 : 7)) != 0
         || (nc == 2 && (reinterpret_cast<uintptr_t>(p.nudata) & (half_in ? 7 : 15)) != 0))
         return hipErrorInvalidValue;

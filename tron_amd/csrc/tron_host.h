@@ -23,6 +23,7 @@ size_t trig_table_size(const tron_config &cfg, const tron_dims &d);
 void build_trig_table(const tron_config &cfg, const tron_dims &d, float *cos_sin, size_t n);
 void build_trig_table_window(int npe, int skip, int golden, float *cos_sin);
 void build_band_table(int nxos, float kernwidth, uint32_t *band);
+bool scatter_band_is_analytic(int nxos, float kernwidth, const uint32_t *band);   // (u - W)^2 <= X^2 + Y^2 <= (u + W)^2 reproduces the table (tron_grid_scatter.hip)
 void build_deapod_table(int n, float kernwidth, float sigma, float *inv_weight);
 void build_deapod_table_rect(int rows, int cols, float kernwidth, float sigma, float *inv_weight);
 void build_tile_order(int nxos, int tile, std::vector<int> &order);

@@ -102,6 +102,30 @@ void build_band_table(int nxos, float kernwidth, uint32_t *band)
         }
 }
 
+// grid_scatter_kernel tests the band as (u - W)^2 <= X^2 + Y^2 <= (u + W)^2 (u - W clamped at 0) instead of reading this table.  For integer u
+// that is the same set as Rlo <= u <= Rhi in exact arithmetic; the table is built in fp32 (hypotf, R +- W rounded), so the two are
+// compared here for every point and every radius next to its band's ends, in the kernel's own fp32 expressions (all exact: 4 W is an
+// integer, the squares stay below 2^24).  False: the plan keeps the arc kernel.
+bool scatter_band_is_analytic(int nxos, float kernwidth, const uint32_t *band)
+{
+    const int h = nxos / 2, rmax = nxos / 2 - 1;
+    const float W = kernwidth;
+    if (nxos > 2048 || 4.0f * W != floorf(4.0f * W)) return false;
+    for (int yy = 0; yy < nxos; ++yy)
+        for (int xx = 0; xx < nxos; ++xx) {
+            const uint32_t b = band[(size_t)yy * nxos + xx];
+            const int lo = (int)(b & 0xffffu), hi = (int)(b >> 16);
+            const float X = (float)(xx - h), Y = (float)(yy - h);
+            const float n2 = X * X + Y * Y;
+            for (int u = std::max(lo - 2, 0); u <= std::min(hi + 2, rmax); ++u) {
+                const float um = fmaxf((float)u - W, 0.0f), up = (float)u + W;
+                const bool analytic = n2 >= um * um && n2 <= up * up;
+                if (analytic != (u >= lo && u <= hi)) return false;
+            }
+        }
+    return true;
+}
+
 // src/tron.cu:323-335 (BEATTY_BETA is not defined by the reference Makefile)
 float kb_beta(float kernwidth)
 {

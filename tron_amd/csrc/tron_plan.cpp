@@ -226,8 +226,14 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
             // arc kernel: everything but the inner tile, when the trajectory and the sample layout allow it
             p->arc = p->relief_entries > 0 && grid_arc_supported(p->nchan, d.nxos, d.nro, d.npe1work, cfg->kernwidth, cfg->input_half);
             // one or two channels: lane = sample, fixed-point sums in LDS (tron_grid_scatter.hip) on the arc kernel's tables
-            p->scatter = p->relief_entries > 0 && grid_scatter_supported(p->nchan, d.nxos, d.nro, d.npe1work, cfg->kernwidth, cfg->input_half);
-            if (const char *gk = tuning_env("TRON_GRID_KERNEL")) {
+            p->scatter = p->relief_entries > 0 && grid_scatter_supported(p->nchan, d.nxos, d.nro, d.npe1work, cfg->kernwidth, cfg->input_half)
+                         && scatter_band_is_analytic(d.nxos, cfg->kernwidth, band.data());
+            // Two channels of fp32 k-space stay with the arc kernel: there the scatter's two 64-bit LDS atomics per point are what bounds it
+            // (round 5: 149 k slices/s against 157 k); complex-half k-space with two channels has no arc kernel (16-byte copies = four
+            // channels) and takes it.  TRON_GRID_KERNEL=scatter (tuning) forces it wherever it is supported.
+            const char *gk = tuning_env("TRON_GRID_KERNEL");
+            if (p->nchan == 2 && !cfg->input_half && !(gk && strcmp(gk, "scatter") == 0)) p->scatter = false;
+            if (gk) {
                 p->scatter = p->scatter && strcmp(gk, "binned") != 0 && strcmp(gk, "arc") != 0;
                 p->arc = p->arc && strcmp(gk, "binned") != 0;
             }
