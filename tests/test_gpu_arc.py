@@ -108,7 +108,10 @@ def test_arc_kernel_vs_oracle_and_binned(oracle, nc, nro, npe, nz, flags):
 def test_arc_kernel_half_input_and_determinism(oracle):
     """complex-half k-space, 4 and 8 coils (the halves are converted in LDS, in place); identical bits run to run.  The third case
     has nro != nxos (src/tron.cu:517), the fourth more than 1 024 spokes per window."""
-    for nc, npe, extra in ((4, 140, {}), (8, 140, {}), (4, 140, dict(gridos=3.0)), (4, 1040, {})):     # the last one: two passes over the spokes
+    # 6 and 10 coils (round 5): 24- and 40-byte records, the last 16-byte piece of a record read 8 bytes early (coils 2..5 / 6..9);
+    # 6 coils is the whole-body shape (src/RUNME3_tron_grid_all.sh:10)
+    for nc, npe, extra in ((4, 140, {}), (8, 140, {}), (4, 140, dict(gridos=3.0)), (4, 1040, {}),     # (4, 1040): two passes over the spokes
+                           (6, 140, {}), (10, 140, {}), (6, 140, dict(gridos=3.0)), (14, 100, {})):
         data = synth.kspace(nc, 256, npe * 2, seed=9100 + nc)
         h = np.stack([data.real, data.imag]).astype(np.float16)
         fl = dict(golden_angle=1, data_undersamp=(npe + 0.5) / 256, prof_slide=npe, **extra)

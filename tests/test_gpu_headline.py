@@ -208,3 +208,27 @@ def test_config3_whole_body_at_full_size_through_the_cli(oracle, tmp_path):
     for z in (0, 478, 955):
         want, _ = oracle.recon(data, adjoint=1, zfirst=z, zcount=1, golden=1, data_undersamp=0.4, prof_slide=21)
         assert rel_l2(got[..., z], want[..., z]) <= 1e-5
+
+
+@pytest.mark.timeout(600)
+def test_whole_body_shape_with_complex_half_input_through_the_cli(oracle, tmp_path):
+    """The whole-body shape (6 coils, 204-spoke windows sliding by 21, `tron -u 0.4 -d 21 -a -G`, src/RUNME3_tron_grid_all.sh:10)
+    with the k-space file stored as complex-half (eltype 4, elbyte 4): 24-byte records on the arc kernel (round 5; the binned
+    kernel until then).  86 windows of a [6, 1, 512, 2000, 1] stream; first, middle and last slice against the oracle run on
+    the half-rounded input."""
+    from tron_amd import ra
+    nc, nro, npe1 = 6, 512, 2000
+    data = synth.kspace(nc, nro, npe1, seed=synth.SEED_BASE + 31)
+    h = np.stack([data.real, data.imag]).astype(np.float16)
+    inp, outp = str(tmp_path / "wbh_in.ra"), str(tmp_path / "wbh_out.ra")
+    ra.write(inp, h, complex_half=True)
+    r = subprocess.run([os.path.join(ROOT, "tron_amd", "bin", "tron"), "-v", "-u", "0.4", "-d", "21", "-a", "-G", inp, outp],
+                       capture_output=True, text=True, timeout=500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "grid_arc_kernel" in r.stdout, r.stdout[-1500:]
+    got = ra.read(outp)
+    assert got.shape == (1, 1, 256, 256, 86)
+    rounded = np.asfortranarray((h[0].astype(np.float32) + 1j * h[1].astype(np.float32)).astype(np.complex64))
+    for z in (0, 43, 85):
+        want, _ = oracle.recon(rounded, adjoint=1, zfirst=z, zcount=1, golden=1, data_undersamp=0.4, prof_slide=21)
+        assert rel_l2(got[..., z], want[..., z]) <= 1e-5

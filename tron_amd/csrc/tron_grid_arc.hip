@@ -105,8 +105,9 @@ struct ArcLds {
 
 int grid_arc_nrec(int nchan, int half_in)  // records per batch for a plan of nchan channels (must match launch_grid_arc's choice of CPB)
 {
-    if (half_in) return nchan >= 5 ? ArcCfg<8>::NREC : ArcCfg<4>::NREC;
+    if (half_in && nchan < 5) return ArcCfg<4>::NREC;
     if (nchan >= 5) {
+        if (half_in) return nchan == 6 ? ArcCfg<6>::NREC : ArcCfg<8>::NREC;
         const int pad8 = (nchan + 7) / 8 * 8, pad6 = (nchan + 5) / 6 * 6;
         return pad6 < pad8 ? ArcCfg<6>::NREC : ArcCfg<8>::NREC;
     }
@@ -456,7 +457,7 @@ grid_arc_kernel(const GridParams p)
 {
     using C = ArcCfg<CPB>;
     static_assert(CPB == 1 || CPB % 2 == 0, "the samples are copied as 16-byte coil pairs (or one coil as two 4-byte planes)");
-    static_assert(!HALF || CPB % 4 == 0, "complex-half samples are copied four coils at a time");
+    static_assert(!HALF || CPB >= 4, "complex-half samples are copied four coils at a time (the last piece of 6 coils holds coils 2..5)");
     static_assert(arc_lds_fits<CPB>(), "ArcCfg::WAVES workgroups of ArcLds do not fit a CU's 128 LDS units of 1280 bytes");
     extern __shared__ __align__(16) unsigned char lds_raw[];
     ArcLds<CPB> &L = *reinterpret_cast<ArcLds<CPB> *>(lds_raw);
@@ -521,6 +522,8 @@ grid_arc_kernel(const GridParams p)
     const lds_f2p lutq = (lds_f2p)(__attribute__((address_space(3))) const void *)L.lut + p.lut_bias;      // entry of table position 0
     const unsigned dbase = lds_addr(L.d);
     constexpr unsigned kBufBytes = (unsigned)(C::NREC * CPB * 8);
+    // complex-half: pieces of four coils (16 bytes) wait in the last coil-pair planes of a record's fp32 slots until they are converted in place
+    constexpr int kHalfPieces = (CPB + 3) / 4, kHalfPlane0 = CPB / 2 - kHalfPieces;
     constexpr unsigned kRecStep = CPB == 1 ? 4u : 16u;              // bytes between consecutive records of one plane
     const float dcf_a = p.apply_dcf ? p.dcf_a : 0.0f, dcf_b = p.apply_dcf ? p.dcf_b : 1.0f;
     const float rs_nro = (float)p.nro, rs_inv = 1.0f / (float)p.nxos;
@@ -622,8 +625,11 @@ grid_arc_kernel(const GridParams p)
                             lds_dma4_s(in + 4, voff, dst + (unsigned)(C::NREC * 4));
                         } else if constexpr (HALF) {
 #pragma unroll
-                            for (int hq = 0; hq < CPB / 4; ++hq)                           // four coils per piece, parked in coil-pair planes CPB/4 ...
-                                if (4 * hq < ncb) lds_dma16_s(in + 16 * hq, voff, dst + (unsigned)((CPB / 4 + hq) * C::NREC * 16));
+                            for (int hq = 0; hq < kHalfPieces; ++hq)                       // four coils per piece, parked in the LAST coil-pair planes
+                                // (a piece with only two coils left -- channel counts 6, 10, ...: 24-byte records -- is read 8 bytes early, coils
+                                // 4 hq - 2 .. 4 hq + 1: inside the record, where a piece read straight would run 8 bytes past the last sample of the
+                                // buffer; the LDS-DMA path takes 4-byte-aligned sources, tools/probe/dma_align.hip)
+                                if (4 * hq < ncb) lds_dma16_s(in + 16 * hq - (4 * hq + 4 > ncb ? 8 : 0), voff, dst + (unsigned)((kHalfPlane0 + hq) * C::NREC * 16));
                         } else {
 #pragma unroll
                             for (int c = 0; c < CPB / 2; ++c)
@@ -696,15 +702,17 @@ grid_arc_kernel(const GridParams p)
                 // complex-half -> fp32 in place, record by record (slots beyond the batch's records hold stale bits: never read)
                 const unsigned cbuf = dbase + (unsigned)(b & (C::NBUF - 1)) * kBufBytes;
                 for (int rec = tid; rec < C::NREC; rec += kArcThreads) {
-                    v4u hv[CPB / 4];
+                    v4u hv[kHalfPieces];
 #pragma unroll
-                    for (int hq = 0; hq < CPB / 4; ++hq)
-                        hv[hq] = *(const __attribute__((address_space(3))) v4u *)(size_t)(cbuf + (unsigned)((CPB / 4 + hq) * C::NREC * 16 + rec * 16));
+                    for (int hq = 0; hq < kHalfPieces; ++hq)
+                        hv[hq] = *(const __attribute__((address_space(3))) v4u *)(size_t)(cbuf + (unsigned)((kHalfPlane0 + hq) * C::NREC * 16 + rec * 16));
 #pragma unroll
-                    for (int hq = 0; hq < CPB / 4; ++hq) {
-                        const unsigned w[4] = {hv[hq].x, hv[hq].y, hv[hq].z, hv[hq].w};
+                    for (int hq = 0; hq < kHalfPieces; ++hq) {
+                        const bool early = 4 * hq < ncb && 4 * hq + 4 > ncb;                   // (the piece was read 8 bytes early: its coils are words 2, 3)
+                        const unsigned w[4] = {early ? hv[hq].z : hv[hq].x, early ? hv[hq].w : hv[hq].y, hv[hq].z, hv[hq].w};
 #pragma unroll
                         for (int k = 0; k < 2; ++k) {
+                            if (2 * hq + k >= CPB / 2) continue;                               // (six coils: the second piece fills one plane)
                             __half2 h0, h1;
                             __builtin_memcpy(&h0, &w[2 * k], 4);
                             __builtin_memcpy(&h1, &w[2 * k + 1], 4);
@@ -887,10 +895,11 @@ static hipError_t launch_arc_cpb(const GridParams &p, int first_plain, hipStream
     return p.nro != p.nxos ? launch_arc_rs<CPB, HALF, true>(p, first_plain, s) : launch_arc_rs<CPB, HALF, false>(p, first_plain, s);
 }
 
-// fp32 k-space: one coil or an even coil count (16-byte coil pairs); complex-half: a multiple of four coils (16 bytes)
+// fp32 k-space: one coil or an even coil count (16-byte coil pairs); complex-half: an even coil count >= 4 (16-byte pieces of four
+// coils; the last piece of a count that is no multiple of four is read 8 bytes early)
 bool grid_arc_supported(int nchan, int nxos, int nro, int npe, float W, int half_in)
 {
-    const bool coils = half_in ? (nchan >= 4 && (nchan & 3) == 0) : (nchan == 1 || (nchan & 1) == 0);
+    const bool coils = half_in ? (nchan >= 4 && (nchan & 1) == 0) : (nchan == 1 || (nchan & 1) == 0);
     // widths without a Kaiser-Bessel pair table (W <= 1, W 2^k no integer; build_kb_pair_lut) stay on the binned kernel
     // nro != nxos (any -o but 2): the truncating resample of src/tron.cu:517, where its float form is exact (it is for every size tried)
     return nchan >= 1 && coils && (nro == nxos || (nro >= 2 && arc_resample_exact(nxos, nro))) && nxos <= 2048 && npe <= kArcMaxPasses * kArcMaxNpe && W <= 3.0f && kb_pair_lut_scale(W, kArcLutEntries) > 0
@@ -905,11 +914,13 @@ hipError_t launch_grid_arc(const GridParams &p, int half_in, int first_plain, hi
         || p.npe > kArcMaxNpe || !grid_arc_supported(p.nchan, p.nxos, p.nro, p.npe, p.W, half_in) || (reinterpret_cast<uintptr_t>(p.nudata) & 15) != 0)
         return hipErrorInvalidValue;
     const int nc = p.nchan - p.coil0;
-    if (half_in) return nc >= 5 ? launch_arc_cpb<8, true>(p, first_plain, s) : launch_arc_cpb<4, true>(p, first_plain, s);
     if (nc >= 5) {
         const int pad8 = (nc + 7) / 8 * 8, pad6 = (nc + 5) / 6 * 6;
+        // (complex-half chunks start on a multiple of four coils: 6-coil chunks only for exactly 6 coils)
+        if (half_in) return nc == 6 ? launch_arc_cpb<6, true>(p, first_plain, s) : launch_arc_cpb<8, true>(p, first_plain, s);
         return pad6 < pad8 ? launch_arc_cpb<6, false>(p, first_plain, s) : launch_arc_cpb<8, false>(p, first_plain, s);
     }
+    if (half_in) return launch_arc_cpb<4, true>(p, first_plain, s);
     if (nc >= 3) return launch_arc_cpb<4, false>(p, first_plain, s);
     if (nc >= 2) return launch_arc_cpb<2, false>(p, first_plain, s);
     return launch_arc_cpb<1, false>(p, first_plain, s);
