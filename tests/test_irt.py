@@ -101,3 +101,41 @@ def test_cpp_irt_comparator_matches_the_numpy_restatement():
     assert np.linalg.norm(got - want) / np.linalg.norm(want) < 1e-12
     r = irt_cpp.bench_golden(32, 64, 20, 2, 3, 2)          # the timed loop runs and produces finite images
     assert r["wall_s"] > 0 and np.isfinite(r["checksum"]) and r["checksum"] > 0
+
+
+def test_config1_at_its_literal_size_writes_the_reference_scripts_file(tmp_path):
+    """BASELINE.json configs[0] literally (src/RUNME2_others_degrid_phantom.m:23-69): 256^2 Shepp-Logan -> IRT forward on 512 x 512
+    linear-radial samples -> the [1, 1, 512, 512, 1] complex64 RawArray (tools/config1.py; ~4 s on one core)."""
+    import json
+    import subprocess
+    import sys
+    from tron_amd import ra
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "config1.py"), str(tmp_path)], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", "")))
+    assert r.returncode == 0, r.stderr[-1500:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    data = ra.read(str(tmp_path / "sl_data_irt.ra"))
+    assert data.shape == (1, 1, 512, 512, 1) and data.dtype == np.complex64 and np.isfinite(data).all()
+    assert os.path.getsize(tmp_path / "sl_data_irt.ra") == 88 + 512 * 512 * 8
+    assert os.path.getsize(tmp_path / "sl.ra") == 524376                      # the size the reference's LFS pointer declares for data/shepplogan.ra
+    # the k-space centre of every spoke (ro = 256) is the phantom's sum
+    phantom = ra.read(str(tmp_path / "sl.ra"))
+    assert np.allclose(data[0, 0, 256, :, 0], phantom.sum(), rtol=2e-3)
+    if "data_nmse" in line:                                                   # a GPU was there: RUNME2:96's figure for the HIP forward path
+        assert line["data_nmse"] < 0.1 and line["max_abs_magnitude_difference"] < 5e-3, line      # measured on MI355X: 0.0547 (1.1e-4 of max|irt| per sample, rms) and 1.2e-3
+
+
+@pytest.mark.gpu
+def test_config1_data_nmse_of_the_hip_forward_path(tmp_path):
+    """RUNME2:89-96 at N = 256 on the GPU box: Data NMSE = norm(irt - tron) / max|irt| and the largest ||tron| - |irt|| (the
+    script plots it on a +-4e-4 scale of max|irt| = 1 after normalisation)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "config1.py"), str(tmp_path)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert "data_nmse" in line, line
+    assert line["data_nmse"] < 0.1 and line["max_abs_magnitude_difference"] < 5e-3, line      # measured on MI355X: 0.0547 (1.1e-4 of max|irt| per sample, rms) and 1.2e-3

@@ -1,4 +1,7 @@
 export TRON_TUNING=1
-timeout 1500 python -m pytest tests/test_gpu_arc.py tests/test_gpu_headline.py -x -q -m gpu -k "half or shapes_the_arc" 2>&1 | tail -8
-NI="--cpu-slices 0 --no-irt --sustain 0"
-for a in "--half --coils 6" "--coils 6" "--half --coils 8" ; do echo -n "$a: "; python bench.py $NI $a 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print(d['value'], d['parity_rel_l2_vs_oracle'], d['roofline']['kernel'], d['roofline']['frac'])"; done
+cp tron_amd/lib/libtronhip.so /tmp/orig.so
+for r in 1 2; do
+for v in /tmp/orig.so tron_amd/lib/libtronhip_s41.so tron_amd/lib/libtronhip_s42.so tron_amd/lib/libtronhip_s44.so tron_amd/lib/libtronhip_r5.so tron_amd/lib/libtronhip_r4.so; do cp $v tron_amd/lib/libtronhip.so; echo -n "$(basename $v) "; WARM=20 python tools/gridbench.py 1 128 fast 5 2>&1 | tail -1; done
+done
+cp /tmp/orig.so tron_amd/lib/libtronhip.so
+python -m pytest tests/test_irt.py -x -q -m gpu 2>&1 | tail -3

@@ -40,7 +40,11 @@ namespace tron {
 constexpr int kScatTile = 32;
 constexpr int kScatThreads = 256;
 constexpr int kScatHalo = 4;                        // 2 W for W <= 2: first column of a footprint >= x0 - 2 W
-constexpr int kScatPitch = kScatTile + 2 * kScatHalo;   // 40
+constexpr int kScatPitch = kScatTile + 2 * kScatHalo;   // 40 points per row and rows per tile
+#ifndef TRON_SCAT_STRIDE
+#define TRON_SCAT_STRIDE 42       // (40, 41, 42, 44 within 1.5 % of each other; 42 the best by a hair)
+#endif
+constexpr int kScatStride = TRON_SCAT_STRIDE;           // 8-byte words between the rows of the tile of sums in LDS
 constexpr int kScatMaxSpokes = 512;                 // = kArcMaxSpokes (arc_prep_kernel)
 
 template <int NC>
@@ -63,7 +67,7 @@ struct ScatLds {
     float2 lutA[3][kScatLutS + 2];
     float2 lutB[3][kScatLutS + 2];
     uint4 run[kScatMaxSpokes];                                   // first sample | down << 31, ulo | len << 10 | offset << 17, cos, sin
-    unsigned long long acc[NC][kScatPitch * kScatPitch];         // (re << 32) + im, fixed point
+    unsigned long long acc[NC][kScatPitch * kScatStride];         // (re << 32) + im, fixed point
     unsigned dmax_bits[2];                                        // largest |d| dcf of the rounds so far, by round parity
     unsigned pad[2];
     unsigned junk[4][64];                                         // where the L2 prefetch of the next slice's samples lands (never read)
@@ -173,10 +177,12 @@ grid_scatter_kernel(const GridParams p)
     // here and cleared again by each slice's store, which also clears the points it has just read
     auto halo_index = [&](const int k) -> int {                 // k-th element of the ring, 0 <= k < 40^2 - 32^2
         constexpr int top = kScatHalo * kScatPitch;             // 4 full rows above, 4 below, 2 x 4 columns beside the 32 rows
-        if (k < top) return k;
-        if (k < 2 * top) return (kScatPitch - kScatHalo) * kScatPitch + (k - top);
+        if (k < 2 * top) {
+            const int kk = k < top ? k : k - top, row = kk / kScatPitch, col = kk - row * kScatPitch;
+            return (k < top ? row : kScatPitch - kScatHalo + row) * kScatStride + col;
+        }
         const int m = k - 2 * top, row = m >> 3, c8 = m & 7;
-        return (kScatHalo + row) * kScatPitch + (c8 < kScatHalo ? c8 : kScatTile + c8);
+        return (kScatHalo + row) * kScatStride + (c8 < kScatHalo ? c8 : kScatTile + c8);
     };
     constexpr int kRing = kScatPitch * kScatPitch - kScatTile * kScatTile;
     auto table_to_lds = [&](const int ns_) {
@@ -193,7 +199,7 @@ grid_scatter_kernel(const GridParams p)
     }
     {
         uint4 *const a4 = reinterpret_cast<uint4 *>(&L.acc[0][0]);
-        constexpr int N4 = NC * kScatPitch * kScatPitch / 2;
+        constexpr int N4 = NC * kScatPitch * kScatStride / 2;
         for (int i = tid; i < N4; i += kScatThreads) a4[i] = make_uint4(0u, 0u, 0u, 0u);
         if (tid < 2) L.dmax_bits[tid] = 0u;
     }
@@ -383,7 +389,7 @@ grid_scatter_kernel(const GridParams p)
                     const int ksh = min(e2 - e_new, 31);
                     const long long half_ulp = 1ll << (ksh - 1);
                     unsigned long long *const flat = &L.acc[0][0];
-                    for (int i = tid; i < NC * kScatPitch * kScatPitch; i += kScatThreads) {
+                    for (int i = tid; i < NC * kScatPitch * kScatStride; i += kScatThreads) {
                         const long long t = (long long)flat[i];
                         const int im = (int)(unsigned)(t & 0xffffffffll);
                         const int re = (int)((t - (long long)im) >> 32);
@@ -452,7 +458,7 @@ grid_scatter_kernel(const GridParams p)
                     int bx = (int)(ixf - fx0), by = (int)(iyf - fy0);
                     bx = min(max(bx, 0), kScatPitch - 4);                                  // (never binds: the segments are clipped to tile + W)
                     by = min(max(by, 0), kScatPitch - 4);
-                    const int base = by * kScatPitch + bx;
+                    const int base = by * kScatStride + bx;
                     // The band of src/tron.cu:498-502, 512, 521 -- ceil(R - W) <= u <= floor(R + W), R = hypotf(X, Y) -- as
                     // (u - W)^2 <= X^2 + Y^2 <= (u + W)^2: the same set for integer u (checked against the host's band table point by point before
                     // a plan takes this kernel, scatter_band_is_analytic), all three exact in fp32.  The four points next to the sample lie
@@ -493,7 +499,7 @@ grid_scatter_kernel(const GridParams p)
                                     const int re = cvt_rpi(v.x), im = cvt_rpi(v.y);
                                     // (re << 32) + im as a signed 64-bit number: low word im, high word re - (im < 0)
                                     const unsigned lo = (unsigned)im, hi = (unsigned)re + (unsigned)(im >> 31);
-                                    __hip_atomic_fetch_add(&L.acc[c][base + i * kScatPitch + j], ((unsigned long long)hi << 32) | lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    __hip_atomic_fetch_add(&L.acc[c][base + i * kScatStride + j], ((unsigned long long)hi << 32) | lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                                 }
                         }
                 }
@@ -512,7 +518,7 @@ grid_scatter_kernel(const GridParams p)
                 if (c < ncb) {
 #pragma unroll
                     for (int qy = 0; qy < 2; ++qy) {
-                        unsigned long long *const s2 = &L.acc[c][(my + qy + kScatHalo) * kScatPitch + mx + kScatHalo];
+                        unsigned long long *const s2 = &L.acc[c][(my + qy + kScatHalo) * kScatStride + mx + kScatHalo];
                         float f[4];
 #pragma unroll
                         for (int qx = 0; qx < 2; ++qx) {
