@@ -18,6 +18,7 @@ t nc4_npe402_nz256 --coils 4
 t nc2_npe402_nz256 --coils 2
 t nc1_npe402_nz256 --coils 1
 t nc8_npe402_nz256_half --half
+t nc6_npe402_nz256_half --half --coils 6
 t nc8_npe804_nz256 --spokes 804
 t nc8_npe804_nz32 --spokes 804 --slices 32
 t nc8_npe402_nz32 --slices 32
@@ -31,6 +32,8 @@ b nc4 $NI --coils 4
 b nc2 $NI --coils 2
 b nc1 $NI --coils 1
 b half $NI --half
+b half_nc6 $NI --half --coils 6
+b half_nc1 $NI --half --coils 1
 b 804spokes $NI --spokes 804
 b cfg4_share $NI --spokes 804 --slices 32
 b 32slices $NI --slices 32
@@ -50,9 +53,15 @@ for k in stats stats_one_lane stats_forward; do
   cp $best $out/${k}.csv
 done
 WARM=20 bash tools/pmc.sh $tag/sq tools/gridbench.py 8 128 fast 3 > /dev/null 2>&1; cp gpurun_out/$tag/sq/summary.txt $out/sq_counters.txt
+WARM=20 bash tools/pmc.sh $tag/sq1 tools/gridbench.py 1 128 fast 3 > /dev/null 2>&1; cp gpurun_out/$tag/sq1/summary.txt $out/sq_counters_nc1.txt
+WARM=5 bash tools/pmc.sh $tag/sqf tools/fwdbench.py 8 64 fast > /dev/null 2>&1; cp gpurun_out/$tag/sqf/summary.txt $out/forward_sq_counters.txt
 if [ -f tron_amd/lib/libtronhip_aprof.so ]; then
   cp tron_amd/lib/libtronhip.so /tmp/orig.so; cp tron_amd/lib/libtronhip_aprof.so tron_amd/lib/libtronhip.so
   WARM=20 python tools/arcprof.py 8 128 > $out/phase_clock.log 2>&1; cp /tmp/orig.so tron_amd/lib/libtronhip.so
+fi
+if [ -f tron_amd/lib/libtronhip_sprof.so ]; then
+  cp tron_amd/lib/libtronhip.so /tmp/orig.so; cp tron_amd/lib/libtronhip_sprof.so tron_amd/lib/libtronhip.so
+  python tools/scatprof.py 1 128 > $out/scatter_phase_clock.log 2>&1; cp /tmp/orig.so tron_amd/lib/libtronhip.so
 fi
 if [ -f tron_amd/lib/libtronhip_cprof.so ]; then
   cp tron_amd/lib/libtronhip.so /tmp/orig.so; cp tron_amd/lib/libtronhip_cprof.so tron_amd/lib/libtronhip.so
@@ -66,4 +75,5 @@ timeout 120 tools/probe/cumask_main > $out/cu_mask_probe.txt 2>&1
 TRON_GRID_KERNEL=binned python tools/gridbench.py 8 128 fast 5 2>&1 | tail -1 >> $out/gridbench.log
 TRON_DUAL_STREAM=0 bash tools/ktrace.sh $tag tools/gridbench.py 8 128 fast 3 > $out/ktrace_one_lane.log 2>&1
 WARM=20 python tools/gridbench.py 8 128 fast 20 2>&1 | tail -1 > $out/gridbench_warm.log
-rm -rf $out/stats $out/stats_one_lane $out/stats_forward $out/sq
+python tools/config1.py /tmp/c1 > $out/config1.json 2> $out/config1.err
+rm -rf $out/stats $out/stats_one_lane $out/stats_forward $out/sq $out/sq1 $out/sqf gpurun_out/$tag/sq gpurun_out/$tag/sq1 gpurun_out/$tag/sqf
