@@ -24,13 +24,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # one-coil instantiation, which TRON_GRID_KERNEL=arc (read at plan creation) still selects.
 @pytest.fixture(autouse=True, scope="module")
 def _arc_kernel_for_one_channel_too():
-    old = os.environ.get("TRON_GRID_KERNEL")
+    # (TRON_SLICES_PER_PASS=0: linear-angle plans with few channels otherwise grid several slices per pass of the BINNED kernel)
+    old = {k: os.environ.get(k) for k in ("TRON_GRID_KERNEL", "TRON_SLICES_PER_PASS")}
     os.environ["TRON_GRID_KERNEL"] = "arc"
+    os.environ["TRON_SLICES_PER_PASS"] = "0"
     yield
-    if old is None:
-        os.environ.pop("TRON_GRID_KERNEL", None)
-    else:
-        os.environ["TRON_GRID_KERNEL"] = old
+    for k, v in old.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
 
 
 def _kernel_name(shape, **flags):

@@ -23,13 +23,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # creation), so that the two-channel instantiation is tested all the same.
 @pytest.fixture(autouse=True, scope="module")
 def _scatter_for_two_channels_too():
-    old = os.environ.get("TRON_GRID_KERNEL")
+    # (TRON_SLICES_PER_PASS=0: linear-angle plans with few channels otherwise grid several slices per pass of the BINNED kernel)
+    old = {k: os.environ.get(k) for k in ("TRON_GRID_KERNEL", "TRON_SLICES_PER_PASS")}
     os.environ["TRON_GRID_KERNEL"] = "scatter"
+    os.environ["TRON_SLICES_PER_PASS"] = "0"
     yield
-    if old is None:
-        os.environ.pop("TRON_GRID_KERNEL", None)
-    else:
-        os.environ["TRON_GRID_KERNEL"] = old
+    for k, v in old.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
 
 
 def _kernel_name(shape, **flags):

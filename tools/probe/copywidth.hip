@@ -49,6 +49,7 @@ int main()
     };
     for (int blocks : {2048, 8192}) {
         printf("grid-stride, %d blocks\n", blocks);
+        time("  float (4 B per lane)", [&] { copy_k<float><<<blocks, 256>>>((float *)b, (const float *)a, bytes / 4); });
         time("  float2 (8 B per lane)", [&] { copy_k<float2><<<blocks, 256>>>((float2 *)b, (const float2 *)a, bytes / 8); });
         time("  float4 (16 B per lane)", [&] { copy_k<float4><<<blocks, 256>>>((float4 *)b, (const float4 *)a, bytes / 16); });
     }

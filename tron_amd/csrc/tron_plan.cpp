@@ -628,6 +628,8 @@ extern "C" int tron_plan_destroy(tron_plan *p)
 extern "C" const char *tron_plan_grid_kernel_name(const tron_plan *p)
 {
     if (!p || !p->cfg.adjoint) return "";
+    // linear angles with few channels: several slices share one pass of the binned kernel (slice groups, tron_pipeline.cpp), whatever tables the plan holds
+    if (p->binned && !p->cfg.golden_angle && p->nchan <= 4 && p->slices_per_pass && p->d.nz > 1) return "grid_binned_kernel (linear-angle slice groups)";
     if (p->scatter) return p->centre_kernel ? "grid_scatter_kernel (+ grid_centre_kernel for |r| < inner_r0)" : "grid_scatter_kernel (+ grid_binned_kernel on the inner tile, grid_reduce_parts_kernel)";
     if (p->arc) return p->centre_kernel ? "grid_arc_kernel (+ grid_centre_kernel for |r| < inner_r0)" : "grid_arc_kernel (+ grid_binned_kernel on the inner tile, grid_reduce_parts_kernel)";
     if (p->binned) return p->relief_entries > 0 ? "grid_binned_kernel (+ grid_reduce_parts_kernel)" : "grid_binned_kernel";
