@@ -333,3 +333,30 @@ def test_recon_multi_rejects_a_complex64_array_flagged_as_half():
     import numpy as np
     with pytest.raises(ValueError):
         lib.recon_multi(np.zeros((2, 1, 16, 8, 1), np.complex64), adjoint=True, input_half=1)
+
+
+@pytest.mark.parametrize("nxos", [128, 256, 512, 1024])
+def test_band_table_equals_the_scatter_kernels_analytic_test(nxos):
+    """grid_scatter_kernel (tron_grid_scatter.hip) tests a point's band, Rlo <= u <= Rhi with R = hypotf(X, Y) in fp32
+    (src/tron.cu:498-502), as |X^2 + Y^2 - C| <= D with C = ((u - W)^2 + (u + W)^2) / 2, D = ((u + W)^2 - (u - W)^2) / 2 and u - W
+    clamped at 0 -- in fp32, every term exact for W = 2.  The library checks that against its own band table before a plan takes
+    the kernel (scatter_band_is_analytic); here the same comparison in numpy float32, for every point and every radius."""
+    from tron_amd import lib
+    import ctypes
+    L = lib.load()
+    band = np.zeros(nxos * nxos, dtype=np.uint32)
+    L.tron_host_band_table.argtypes = [ctypes.c_int, ctypes.c_float, ctypes.c_void_p]
+    assert L.tron_host_band_table(nxos, ctypes.c_float(2.0), band.ctypes.data_as(ctypes.c_void_p)) == 0
+    lo = (band & 0xffff).astype(np.int32).reshape(nxos, nxos)
+    hi = (band >> 16).astype(np.int32).reshape(nxos, nxos)
+    h = nxos // 2
+    X = (np.arange(nxos, dtype=np.float32) - np.float32(h))
+    n2 = (X * X)[None, :] + (X * X)[:, None]                     # exact in fp32: integers below 2^24
+    W = np.float32(2.0)
+    for u in range(0, h):                                        # u <= nxos / 2 - 1, as every sample the kernel sees
+        uf = np.float32(u)
+        um, up = np.maximum(uf - W, np.float32(0)), uf + W
+        A, B = um * um, up * up
+        C, D = np.float32(0.5) * (A + B), np.float32(0.5) * (B - A)
+        analytic = np.abs(n2 - C) <= D
+        assert np.array_equal(analytic, (lo <= u) & (u <= hi)), u
