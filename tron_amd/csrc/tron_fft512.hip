@@ -236,7 +236,112 @@ __device__ __forceinline__ int crop_index(int k) { return k < kFKeep / 2 ? k + k
 // line buffers live in the part of the transposition tile the exchange regions leave unused until the end.  The
 // twiddles come from LDS so that no compiler-tracked global load (whose wait would drain the DMA, the counters being
 // in-order) sits between the copy's issue and its use.
-#ifndef TRON_FFT_ROWS_NO_DMA
+#if !defined(TRON_FFT_ROWS_NO_DMA) && defined(TRON_FFT_ROWS_TWO_LINES)
+// Round 5 experiment, NOT the default (measured slower, see the end of this comment): TWO lines on their way per wave, as in pass 2 since round 4.  The pass is bound by memory latency -- with one line in
+// flight a wave waits ~3.6 us for a line it transforms in ~1.8 -- so every wave copies lines j + 1 and j + 2 while it transforms line j.
+// The LDS for the second set of line buffers comes from the twiddle table (a lane's fourteen twiddles wait in registers, which also
+// takes 14 LDS reads out of every line) and from three workgroups per CU instead of four (50 KiB each).  A line's copy is up to four
+// LDS-DMA instructions, fewer where the row's 128-point pieces lie outside the sampled disc: the count is wave-uniform (a ballot per
+// piece) and the wait in front of line j names the pieces of line j + 1 that may still fly.
+// Measured (same box, interleaved, 8 coils x 128 slices): FFT stage 0.725-0.741 us per coil-slice against 0.680-0.717 with one line in flight
+// and four workgroups per CU; bench.py 68.1 k against 69.1 k slices/s.  With four lines per wave the deeper prefetch does not make up for the
+// fourth workgroup; it would take workgroups that walk the coils of their row block (more lines per wave) to pay.
+__device__ __forceinline__ void wait_vmcnt_le(const int n)      // n wave-uniform, 0..4
+{
+    switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    }
+}
+
+__global__ void __launch_bounds__(256, 3) fft512_rows_kernel(const Fft512Params p)
+{
+    constexpr int kElems = 4 * kXch + 8 * kF > kFKeep * (kLinesPerWg + 1) ? 4 * kXch + 8 * kF : kFKeep * (kLinesPerWg + 1);
+    __shared__ float2 s_t[kElems];                         // exchange regions | two line buffers per wave, then [kept col][line], +1 pad
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t img = blockIdx.y;
+    const int row0 = blockIdx.x * kLinesPerWg;
+    const float2 *src = p.in + img * (size_t)kF * kF;
+    float2 *xch = s_t + wave * kXch;
+    const unsigned lbuf = lds_addr(s_t + 4 * kXch + wave * 2 * kF);          // this wave's two line buffers: a line as it lies in memory
+    // the gridded spokes fill a disc of radius nxos/2 - 1 + W (src/tron.cu:498-502): 21 % of the square is zero and is
+    // neither copied nor read from the buffer
+    auto row_lim = [&](const int row) {
+        const int Y = row < kF / 2 ? row : row - kF;
+        return p.rzero2 > 0 ? p.rzero2 - Y * Y : 0x7fffffff;
+    };
+    auto inside = [&](const int col, const int lim) {
+        const int X = col < kF / 2 ? col : col - kF;
+        return X * X <= lim;
+    };
+    auto copy_line = [&](const int lr, const int b) -> int {   // up to 4 x (64 lanes x 16 bytes = two points per lane); returns the instructions issued
+        const int lim = row_lim(row0 + lr);
+        const float2 *line = src + (size_t)(row0 + lr) * kF;
+        int issued = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int col = k * 128 + 2 * lane;
+            const bool want = inside(col, lim) || inside(col + 1, lim);
+            if (__ballot(want) != 0ull) {
+                ++issued;
+                if (want) lds_dma16(line + col, lbuf + (unsigned)((b * kF + k * 128) * (int)sizeof(float2)));
+            }
+        }
+        return issued;
+    };
+    v2f twa[8], twb[8];
+    fft512_lane_twiddles(p.tw, lane, twa, twb);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the twiddles are in: from here on only the copies count
+    int fly[4];                                             // DMA instructions of line j (wave-uniform)
+    fly[0] = copy_line(wave * 4, 0);
+    fly[1] = copy_line(wave * 4 + 1, 1);
+    fly[2] = fly[3] = 0;
+    float2 keep[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int lr = wave * 4 + j;
+        const int lim = row_lim(row0 + lr);
+        float2 v[8];
+        wait_vmcnt_le(j < 3 ? fly[j + 1] : 0);              // line j has landed (the pieces of line j + 1 may still fly)
+        const unsigned buf = lbuf + (unsigned)((j & 1) * kF * (int)sizeof(float2));
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float2 t = lds_ld64(buf + (unsigned)((q * 64 + lane) * (int)sizeof(float2)));
+            v[q] = inside(q * 64 + lane, lim) ? t : make_float2(0.f, 0.f);
+        }
+        if (j < 2) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the buffer has been read: line j + 2 may overwrite it
+            fly[j + 2] = copy_line(lr + 2, j & 1);
+        }
+        fft512_inv_tw(v, xch, [&](const int k) { return twa[k]; }, [&](const int k) { return twb[k]; }, lane);
+        // keep k = lane + 64*j2 for j2 in {0,1,6,7}
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) keep[j][jj] = v[jj < 2 ? jj : jj + 4];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int j2 = jj < 2 ? jj : jj + 4;
+            s_t[crop_index(lane + 64 * j2) * (kLinesPerWg + 1) + wave * 4 + j] = keep[j][jj];
+        }
+    __syncthreads();
+    // transposed store: tmp[img][col][row0 .. row0+15]  (128 contiguous bytes per column)
+    float2 *dst = p.tmp + img * (size_t)kFKeep * kF;
+    for (int e = threadIdx.x; e < kFKeep * kLinesPerWg; e += 256) {
+        const int col = e / kLinesPerWg, r = e % kLinesPerWg;
+#ifndef TRON_FFT_NO_NT
+        st_nt(&dst[(size_t)col * kF + row0 + r], s_t[col * (kLinesPerWg + 1) + r]);
+#else
+        dst[(size_t)col * kF + row0 + r] = s_t[col * (kLinesPerWg + 1) + r];
+#endif
+    }
+}
+#elif !defined(TRON_FFT_ROWS_NO_DMA)
 __global__ void __launch_bounds__(256) fft512_rows_kernel(const Fft512Params p)
 {
     __shared__ float2 s_t[kFKeep * (kLinesPerWg + 1)];     // exchange regions | line buffers, then [kept col][line], +1 pad
