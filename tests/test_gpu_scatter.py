@@ -172,6 +172,30 @@ def test_scatter_kernel_first_row_of_a_footprint_when_k_minus_W_rounds(oracle):
     assert rel_l2(got, want) <= 2e-6
 
 
+@pytest.mark.parametrize("nt,half", [(3, 0), (5, 0), (3, 1)])
+def test_scatter_kernel_odd_channel_counts(oracle, nt, half):
+    """One coil x nt repetitions = an odd number of channels (the reference asserts one or an even number of COILS, src/tron.cu:963;
+    nt > 1 is defined as nt separate runs): one channel per pass of the scatter kernel (blockIdx.y), 8- or 4-byte loads at the
+    records' 24- / 40- / 12-byte stride.  The binned kernel took these plans until round 5."""
+    nro, npe = 256, 110
+    data = synth.kspace(1, nro, npe * 2, seed=9900 + nt, nt=nt)
+    fl = dict(golden_angle=1, data_undersamp=(npe + 0.5) / nro, prof_slide=npe)
+    src = data
+    if half:
+        h = np.stack([data.real, data.imag]).astype(np.float16)
+        data = np.asfortranarray((h[0].astype(np.float32) + 1j * h[1].astype(np.float32)).astype(np.complex64))
+        src = h
+        fl["input_half"] = 1
+    assert "grid_scatter_kernel" in _kernel_name(data.shape, **fl)
+    got, _ = lib.recon(src, adjoint=True, **fl)
+    again, _ = lib.recon(src, adjoint=True, **fl)
+    assert np.array_equal(got, again)
+    ofl = dict(golden=1, data_undersamp=(npe + 0.5) / nro, prof_slide=npe)
+    for t in range(nt):
+        want, _ = oracle.recon(np.asfortranarray(data[:, t:t + 1]), adjoint=1, **ofl)
+        assert rel_l2(got[:, t:t + 1], want) <= 1e-5, t
+
+
 def test_shapes_the_scatter_kernel_leaves_to_the_arc_kernel():
     os.environ.pop("TRON_GRID_KERNEL", None)              # the plan's own choice
     try:

@@ -587,7 +587,7 @@ static hipError_t launch_scatter_nc(const GridParams &p, int half_in, int first_
     return rs ? launch_scatter_rs<NC, false, true>(p, first_plain, s) : launch_scatter_rs<NC, false, false>(p, first_plain, s);
 }
 
-// The plans the arc kernel takes (grid_arc_supported) with one or two channels and a window of four points per axis; the caller has
+// The plans the arc kernel takes (grid_arc_supported) with one, two or an odd number of channels and a window of four points per axis; the caller has
 // checked scatter_band_is_analytic for the plan's grid and width.
 bool grid_scatter_supported(int nchan, int nxos, int nro, int npe, float W, int half_in)
 {
@@ -595,8 +595,10 @@ bool grid_scatter_supported(int nchan, int nxos, int nro, int npe, float W, int 
     // W = 2 (the reference's default, src/tron.cu:69): four columns per footprint, of which the inner two lie within 1 of the sample, so that the
     // four inner points (within sqrt(2) < W) are always inside their band; the band test's squares are exact; the pair table has 64 pieces
     // per unit.  Other widths keep the arc kernel.
-    return (nchan == 1 || nchan == 2) && W == 2.0f && kb_pair_lut_scale(W, kArcLutEntries) == kScatLutS
-           && grid_arc_supported(nchan, nxos, nro, npe, W, 0);
+    // Channels: one, two, or any ODD count (one coil x nt repetitions; the reference itself takes one or an even number of coils, and the arc
+    // kernel copies coil pairs): odd counts run one channel per pass, blockIdx.y = channel.
+    return (nchan == 1 || nchan == 2 || (nchan & 1)) && W == 2.0f && kb_pair_lut_scale(W, kArcLutEntries) == kScatLutS
+           && grid_arc_supported(nchan == 2 ? 2 : 1, nxos, nro, npe, W, 0) && (long long)nro * npe * nchan < (1ll << 28);
 }
 
 // p.tile_order[first_plain ...] must list the 32x32 tiles; run tables from arc_prep_kernel with ONE batch per run (ArcPrepParams::nrec >= 32767).
