@@ -196,6 +196,27 @@ def test_scatter_kernel_odd_channel_counts(oracle, nt, half):
         assert rel_l2(got[:, t:t + 1], want) <= 1e-5, t
 
 
+@pytest.mark.parametrize("nc,nro,npe,nz", [(1, 512, 402, 4), (1, 256, 300, 2), (3, 256, 120, 2)])
+def test_scatter_kernel_tile_sizes_agree(oracle, nc, nro, npe, nz):
+    """One channel per pass runs on 64 x 64 tiles of eight waves where the grid's centre is a corner of four of them (fewer samples
+    handled twice, the per-slice overheads shared by four times the samples), else on 32 x 32 tiles of four; TRON_SCAT_TILE picks
+    one.  The two differ in their fixed-point scales (per tile), not in what they compute: each within 1e-5 of the oracle, 2e-6 of
+    each other."""
+    nt = nc if nc > 1 else 1
+    data = synth.kspace(1, nro, npe * nz, seed=9950 + nro + npe, nt=nt) if nt > 1 else synth.kspace(1, nro, npe * nz, seed=9950 + nro + npe)
+    fl = dict(golden_angle=1, data_undersamp=(npe + 0.5) / nro, prof_slide=npe)
+    out = {}
+    for tile in ("32", "64"):
+        out[tile] = _child(data, dict(TRON_GRID_KERNEL="scatter", TRON_SCAT_TILE=tile), **fl)
+    assert rel_l2(out["32"], out["64"]) <= 2e-6
+    got, _ = lib.recon(data, adjoint=True, **fl)
+    assert np.array_equal(got, out["64"])                      # 64 is the plan's own choice on these grids
+    ofl = dict(golden=1, data_undersamp=(npe + 0.5) / nro, prof_slide=npe)
+    for t in range(nt):
+        want, _ = oracle.recon(np.asfortranarray(data[:, t:t + 1]), adjoint=1, **ofl)
+        assert rel_l2(out["32"][:, t:t + 1], want) <= 1e-5 and rel_l2(out["64"][:, t:t + 1], want) <= 1e-5
+
+
 def test_shapes_the_scatter_kernel_leaves_to_the_arc_kernel():
     os.environ.pop("TRON_GRID_KERNEL", None)              # the plan's own choice
     try:

@@ -157,6 +157,8 @@ __device__ __forceinline__ void arc_block_window(int X0, int Y0, float W, float 
 // ------------------------------------------------------------------------------------------------------------------------
 // Plan-time pass: the run of every (window, tile), dealt into combs, and every thread's window of it.  grid = (tiles, windows), block = 256.
 struct ArcPrepLds {
+    unsigned short wb[1024];               // flat tables: the member that holds record 64 w of the run (w < 1 024: 65 536 records)
+    int phi2[kArcMaxSpokes];               // flat tables: every entry's record offset, 32 bits
     unsigned s_a[kArcMaxSpokes];
     unsigned s_b[kArcMaxSpokes];
     float2 s_cs[kArcMaxSpokes];
@@ -176,20 +178,22 @@ arc_prep_kernel(const ArcPrepParams p)
     const int tile = blockIdx.x;
     const int w = blockIdx.y;
     const int n = p.nxos, h = n / 2, rmax = n / 2 - 1;
-    const int tpr = n / kArcTile;
-    const int x0 = (tile % tpr) * kArcTile - h, y0 = (tile / tpr) * kArcTile - h;
-    const bool outer = (x0 == 0 || x0 == -kArcTile) && (y0 == 0 || y0 == -kArcTile);
+    const int T = p.flat && p.tile > 0 ? p.tile : kArcTile;     // (grid_scatter_kernel's tables may be made for 64 x 64 tiles)
+    const int tpr = n / T;
+    const int x0 = (tile % tpr) * T - h, y0 = (tile / tpr) * T - h;
+    const bool outer = (x0 == 0 || x0 == -T) && (y0 == 0 || y0 == -T);
     const unsigned short *order = p.order + (size_t)w * p.npe;
     const float *phis = p.phi + (size_t)w * p.npe;
     const float2 *sorted_cs = p.cs + (size_t)w * p.npe;
     int4 *hdr = p.hdr + (size_t)w * p.ntiles + tile;
 
     // line angles: the run is unwrapped at the direction perpendicular to the tile centre (no spoke of the run is near it)
-    float wrap = atan2f((float)y0 + 15.5f, (float)x0 + 15.5f) + 0.5f * kPi;
+    float wrap = atan2f((float)y0 + 0.5f * (float)(T - 1), (float)x0 + 0.5f * (float)(T - 1)) + 0.5f * kPi;
     wrap -= floorf(wrap / kPi) * kPi;
     const float eps = 0.01f;
-    const float bx_lo = (float)x0 - p.W - eps, bx_hi = (float)(x0 + kArcTile - 1) + p.W + eps;
-    const float by_lo = (float)y0 - p.W - eps, by_hi = (float)(y0 + kArcTile - 1) + p.W + eps;
+    const float bx_lo = (float)x0 - p.W - eps, bx_hi = (float)(x0 + T - 1) + p.W + eps;
+    const float by_lo = (float)y0 - p.W - eps, by_hi = (float)(y0 + T - 1) + p.W + eps;
+    const int seg_max = T > kArcTile ? 127 : kArcSeg;           // longest segment through tile + halo (7 bits; 64-tiles: (64 + 6) sqrt(2) = 99)
 
     if (tid == 0) { L.umin = 1 << 30; L.umax = -1; L.total = 0; L.kfail = 0; L.base = 0; }
     __syncthreads();
@@ -240,7 +244,7 @@ arc_prep_kernel(const ArcPrepParams p)
                             neg = rhi < 0;
                             ulo = neg ? -rhi : rlo;
                             len = rhi - rlo + 1;
-                            if (len > kArcSeg) { atomicOr(p.errflag, 2u); len = kArcSeg; }
+                            if (len > seg_max) { atomicOr(p.errflag, 2u); len = seg_max; }
                         }
                     }
                 }
@@ -342,7 +346,8 @@ arc_prep_kernel(const ArcPrepParams p)
         for (int e = 0; e < 3; ++e) {
             if (e_i[e] >= 0) {
                 const int off = e_excl[e] - L.bstart[e_b[e]];
-                L.s_b[e_i[e]] = (L.s_b[e_i[e]] & 0x1ffffu) | ((unsigned)off << 17);
+                L.s_b[e_i[e]] = (L.s_b[e_i[e]] & 0x1ffffu) | ((unsigned)(off & 0x7fff) << 17);
+                if (p.flat) L.phi2[e_i[e]] = off;               // (one batch: the offset can exceed the field's 15 bits; kept whole beside it)
             }
             if (e_first[e] && L.bstart[e_b[e] + 1] - L.bstart[e_b[e]] > p.nrec) bad = true;
         }
@@ -381,10 +386,50 @@ arc_prep_kernel(const ArcPrepParams p)
     for (int i = tid; i < ns; i += kArcThreads) {
         const float2 cs = L.s_cs[i];
         ent[i] = make_uint4(L.s_a[i], L.s_b[i], __float_as_uint(cs.x), __float_as_uint(cs.y));
+        if (p.flat && p.off) p.off[(size_t)w * p.cap + base + i] = (uint32_t)L.phi2[i];
+    }
+    // ---- flat tables: which member holds each record (grid_scatter_kernel looks it up instead of searching the run) ----
+    // Per GROUP of 64 records 80 bytes: 64 x (the record's member minus the member that holds the group's first record), that member
+    // (16 bits), 14 bytes of padding -- +1.25 bytes per 8-byte sample in HBM; the kernel copies a round's groups to LDS by one LDS-DMA
+    // instruction a round ahead and has no walk over the segments left.
+    if (p.flat && p.rec) {
+        const int ngrp = (total + 63) >> 6;
+        if (tid == 0) {
+            int rb = 0;
+            if (total > 0) {
+                rb = atomicAdd(p.ralloc + w, ngrp);
+                if (rb + ngrp > p.rec_cap || total > 65536) { atomicOr(p.errflag, 2048u); rb = -1; }
+            }
+            L.kfail = rb;
+            p.rbase[(size_t)w * p.ntiles + tile] = rb < 0 ? 0 : rb;
+        }
+        __syncthreads();
+        const int rb = L.kfail;
+        if (rb >= 0 && total > 0) {
+            for (int i = tid; i < ns; i += kArcThreads) {
+                const int len = (int)((L.s_b[i] >> 10) & 127u), off = L.phi2[i];
+                if (len > 0)
+                    for (int g = (off + 63) >> 6; (g << 6) < off + len; ++g) L.wb[g] = (unsigned short)i;
+            }
+            __syncthreads();
+            unsigned char *const rec = p.rec + ((size_t)w * p.rec_cap + rb) * 80;
+            for (int g = tid; g < ngrp; g += kArcThreads) *reinterpret_cast<unsigned short *>(rec + (size_t)g * 80 + 64) = L.wb[g];
+            for (int i = tid; i < ns; i += kArcThreads) {
+                const int len = (int)((L.s_b[i] >> 10) & 127u), off = L.phi2[i];
+                for (int k = 0; k < len; ++k) {
+                    const int pos = off + k, d = i - (int)L.wb[pos >> 6];
+                    if (d < 0 || d > 255) atomicOr(p.errflag, 4096u);
+                    rec[(size_t)(pos >> 6) * 80 + (pos & 63)] = (unsigned char)d;
+                }
+            }
+        }
+        __syncthreads();
     }
     // ---- every thread's own run [jlo, jhi] of the list (thread = 2x2 block, as in grid_arc_kernel) ----
-    {
-        const int X0 = x0 + 2 * (lane & 15), Y0 = y0 + 8 * wave + 2 * (lane >> 4);
+    int mw_all = 0;
+    const int bpr = T / 2, nblocks = bpr * bpr;                 // 2x2 blocks per tile row / per tile (256; 1 024 for 64-tiles: four per thread)
+    for (int blk = tid; blk < nblocks; blk += kArcThreads) {
+        const int X0 = x0 + 2 * (blk % bpr), Y0 = y0 + 2 * (blk / bpr);     // (32-tiles: blk = tid = the arc kernel's thread layout)
         int bandlo = 1 << 20, bandhi = -1;                      // radial band of the block's points, src/tron.cu:498-502
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -413,26 +458,28 @@ arc_prep_kernel(const ArcPrepParams p)
             }
             jhi = lo - 1;
         }
-        p.win[((size_t)w * p.ntiles + tile) * kArcThreads + tid] = (uint32_t)jlo | ((uint32_t)(jhi + 1) << 16);
-        if (p.flat) {
-            // grid_scatter_kernel (tron_grid_scatter.hip): ONE batch per run (the record offsets then number the run's samples) and, in
-            // the header's second word, the most spokes whose line can pass one of the tile's blocks -- the bound behind its fixed-point scale
-            int mw = max(jhi - jlo + 1, 0);
+        if (!p.flat) p.win[((size_t)w * p.ntiles + tile) * kArcThreads + tid] = (uint32_t)jlo | ((uint32_t)(jhi + 1) << 16);
+        mw_all = max(mw_all, jhi - jlo + 1);
+    }
+    if (p.flat) {
+        // grid_scatter_kernel (tron_grid_scatter.hip): ONE batch per run (the record offsets then number the run's samples) and, in
+        // the header's second word, the most spokes whose line can pass one of the tile's blocks -- the bound behind its fixed-point scale
+        int mw = max(mw_all, 0);
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) mw = max(mw, __shfl_xor(mw, o));
-            if (lane == 0) atomicMax(&L.umax, mw);
-            __syncthreads();
-            if (tid == 0) {
-                if (K != 1) atomicOr(p.errflag, 1024u);
-                *hdr = make_int4(ns, L.umax, base, total);
-            }
+        for (int o = 32; o > 0; o >>= 1) mw = max(mw, __shfl_xor(mw, o));
+        if (lane == 0) atomicMax(&L.umax, mw);
+        __syncthreads();
+        if (tid == 0) {
+            if (K != 1) atomicOr(p.errflag, 1024u);
+            *hdr = make_int4(ns, L.umax, base, total);
         }
     }
 }
 
 hipError_t launch_arc_prep(const ArcPrepParams &p, int nwindows, hipStream_t s)
 {
-    if (p.npe > kArcMaxNpe || p.nrec < kArcSeg || (p.nxos / 2) % kArcTile != 0) return hipErrorInvalidValue;
+    const int T = p.flat && p.tile > 0 ? p.tile : kArcTile;
+    if (p.npe > kArcMaxNpe || p.nrec < kArcSeg || (T != 32 && T != 64) || (p.nxos / 2) % T != 0 || p.ntiles != (p.nxos / T) * (p.nxos / T)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(arc_prep_kernel, dim3((unsigned)p.ntiles, (unsigned)nwindows), dim3(kArcThreads), 0, s, p);
     return hipGetLastError();
 }

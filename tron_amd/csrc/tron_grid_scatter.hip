@@ -37,40 +37,53 @@
 
 namespace tron {
 
-constexpr int kScatTile = 32;
-constexpr int kScatThreads = 256;
 constexpr int kScatHalo = 4;                        // 2 W for W <= 2: first column of a footprint >= x0 - 2 W
-constexpr int kScatPitch = kScatTile + 2 * kScatHalo;   // 40 points per row and rows per tile
-#ifndef TRON_SCAT_STRIDE
-#define TRON_SCAT_STRIDE 42       // (40, 41, 42, 44 within 1.5 % of each other; 42 the best by a hair)
-#endif
-constexpr int kScatStride = TRON_SCAT_STRIDE;           // 8-byte words between the rows of the tile of sums in LDS
 constexpr int kScatMaxSpokes = 512;                 // = kArcMaxSpokes (arc_prep_kernel)
 
-template <int NC>
+// Tile geometry: 32 x 32 points and four waves, or 64 x 64 and eight (round 5, late: a tile's samples are those within W of it, so a
+// larger tile handles fewer samples twice -- (36 / 32)^2 = 1.27 against (68 / 64)^2 = 1.13 -- and the per-slice overheads of a
+// workgroup are shared by four times the samples).
+template <int TILE>
+struct ScatGeom {
+    static constexpr int kTile = TILE;
+    static constexpr int kPitch = TILE + 2 * kScatHalo;            // points per row and rows of the tile of sums (40 / 72)
+    static constexpr int kStride = kPitch + 2;                      // 8-byte words between its rows in LDS (40, 41, 42, 44: within 1.5 %)
+    static constexpr int kThreads = TILE == 64 ? 512 : 256;
+    static constexpr int kWaves = kThreads / 64;
+    static constexpr int kRing = kPitch * kPitch - TILE * TILE;      // the halo ring's points
+    static constexpr int kBlocksPerThread = (TILE / 2) * (TILE / 2) / kThreads;      // 2x2 blocks of the store: 1 / 2
+};
+
+template <int NC, int TILE>
 struct ScatCfg {
 #ifndef TRON_SCAT_WAVES1
 #define TRON_SCAT_WAVES1 5
 #define TRON_SCAT_R1 6
 #endif
-    static constexpr int WAVES = NC >= 2 ? 4 : TRON_SCAT_WAVES1;   // workgroups per CU (LDS: 19 / 29 units of 1280 bytes; registers: 96 / 128)
-    // iterations (of 64 records per wave) whose samples wait in registers: one round up to 1 536 / 2 048 records per tile
-    static constexpr int R = NC >= 2 ? 8 : TRON_SCAT_R1;
+    // 32-tiles: workgroups per CU (LDS: 21 / 31 units of 1280 bytes; registers: 96 / 128).  64-tiles: two workgroups of eight waves
+    // per CU (LDS 47 units for one channel), i.e. four waves per SIMD.
+    // (two channels: 32-tiles only in practice -- the plan does not make 64-tile tables for them: 100 KB of sums)
+    static constexpr int WAVES = TILE == 64 ? (NC >= 2 ? 2 : 4) : (NC >= 2 ? 3 : TRON_SCAT_WAVES1);
+    // iterations (of 64 records per wave) whose samples wait in registers: one round up to 1 536 / 2 048 records per 32-tile
+    static constexpr int R = TILE == 64 ? 8 : (NC >= 2 ? 8 : TRON_SCAT_R1);
 };
 
 constexpr int kScatLutS = 64;                       // pieces per grid unit of the pair table this kernel copies (kb_pair_lut_scale: 64 for every width it takes)
 
-template <int NC>
+template <int NC, int TILE>
 struct ScatLds {
+    using G = ScatGeom<TILE>;
     // The two stretches of the Kaiser-Bessel pair table (build_kb_pair_lut) a sample can reach, planes c0 | c1 | c2: its first column
     // lies W-1 <= d < W from it (positions (W-1) s .. W s), the third d - 2 (positions (W-3) s .. (W-2) s): 2 x 65 entries of 400.
     float2 lutA[3][kScatLutS + 2];
     float2 lutB[3][kScatLutS + 2];
-    uint4 run[kScatMaxSpokes];                                   // first sample | down << 31, ulo | len << 10 | offset << 17, cos, sin
-    unsigned long long acc[NC][kScatPitch * kScatStride];         // (re << 32) + im, fixed point
+    uint4 run[kScatMaxSpokes];                                   // first sample | down << 31, ulo | len << 10 | (offset & 0x7fff) << 17, cos, sin
+    uint32_t off[kScatMaxSpokes];                                // the entries' record offsets inside the run (whole: a 64-tile's run exceeds 15 bits)
+    unsigned long long acc[NC][G::kPitch * G::kStride];          // (re << 32) + im, fixed point
     unsigned dmax_bits[2];                                        // largest |d| dcf of the rounds so far, by round parity
     unsigned pad[2];
-    unsigned junk[4][64];                                         // where the L2 prefetch of the next slice's samples lands (never read)
+    // a wave's next round of the member table (arc_prep_kernel: 80 bytes per group of 64 records), copied by LDS-DMA a round ahead
+    unsigned char recb[G::kWaves][ScatCfg<NC, TILE>::R * 80];
 };
 
 typedef const __attribute__((address_space(3))) v2f *slds_f2p;
@@ -102,16 +115,18 @@ __device__ __forceinline__ int cvt_rpi(float x)      // floor(x + 0.5): one inst
 #endif
 }
 
-template <int NC, bool HALF, bool RS>
-__global__ void __launch_bounds__(kScatThreads, ScatCfg<NC>::WAVES)
+template <int NC, bool HALF, bool RS, int TILE>
+__global__ void __launch_bounds__((ScatGeom<TILE>::kThreads), (ScatCfg<NC, TILE>::WAVES))
 grid_scatter_kernel(const GridParams p)
 {
     static_assert(NC == 1 || NC == 2, "one or two channels per pass");
-    static_assert((sizeof(ScatLds<NC>) + 1279) / 1280 * ScatCfg<NC>::WAVES <= 128, "ScatCfg::WAVES workgroups do not fit a CU's 128 LDS units of 1280 bytes");
+    using G = ScatGeom<TILE>;
+    constexpr int kScatTile = G::kTile, kScatPitch = G::kPitch, kScatStride = G::kStride, kScatThreads = G::kThreads, kWaves = G::kWaves;
+    static_assert((sizeof(ScatLds<NC, TILE>) + 1279) / 1280 * (ScatCfg<NC, TILE>::WAVES * 4 / kWaves) <= 128, "the workgroups per CU that ScatCfg::WAVES asks for do not fit a CU's 128 LDS units of 1280 bytes");
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    ScatLds<NC> &L = *reinterpret_cast<ScatLds<NC> *>(lds_raw);
+    ScatLds<NC, TILE> &L = *reinterpret_cast<ScatLds<NC, TILE> *>(lds_raw);
 
-    using C = ScatCfg<NC>;
+    using C = ScatCfg<NC, TILE>;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -151,27 +166,43 @@ grid_scatter_kernel(const GridParams p)
     const unsigned nchan_b = (unsigned)p.nchan * (HALF ? 4u : 8u);       // bytes per sample (all channels)
     const float fx0 = (float)(x0 - kScatHalo), fy0 = (float)(y0 - kScatHalo);
 
-    // this thread's 2x2 points of the tile (the store's layout, as in grid_arc_kernel)
-    const int mx = 2 * (lane & 15), my = 8 * wave + 2 * (lane >> 4);
-    unsigned out_off[2];
-#pragma unroll
-    for (int qy = 0; qy < 2; ++qy) {
+    // the store's layout: thread = 2x2 points (32-tiles: as in grid_arc_kernel; 64-tiles: two such blocks per thread)
+    auto block_origin = [&](const int k, int &mx, int &my) {
+        const int blk = tid + k * kScatThreads;
+        mx = 2 * (blk % (kScatTile / 2));
+        my = 2 * (blk / (kScatTile / 2));
+    };
+    auto out_offset = [&](const int mx, const int my, const int qy) -> unsigned {
         const int X0 = x0 + mx, Y = y0 + my + qy;
         const int row = p.out_shift ? (Y < 0 ? Y + n : Y) : Y + h;      // both fftshifts of src/tron.cu:631 folded in
         const int col = p.out_shift ? (X0 < 0 ? X0 + n : X0) : X0 + h;
-        out_off[qy] = (unsigned)(row * n + col) * 8u;
-    }
+        return (unsigned)(row * n + col) * 8u;
+    };
 
     SPROF_DECL;
     // the run table of a slice (<= 512 entries, two per thread) is asked for one slice ahead and waits in registers
-    uint4 pf_ent[2] = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)};
+    constexpr int kEnt = kScatMaxSpokes / kScatThreads;           // entries per thread: 2 / 1
+    uint4 pf_ent[kEnt];
+    uint32_t pf_off[kEnt];
+#pragma unroll
+    for (int k = 0; k < kEnt; ++k) { pf_ent[k] = make_uint4(0u, 0u, 0u, 0u); pf_off[k] = 0u; }
     int4 hdr_next = make_int4(0, 1, 0, 0);
+    int rbase_next = 0;
     auto fetch_table = [&](const int z, const int4 hh) {
         const size_t win = (size_t)z * p.arc_slice_stride;
         const uint4 *ent = p.arc_ent + win * p.arc_cap + hh.z;
+        const uint32_t *eoff = p.arc_off + win * p.arc_cap + hh.z;
 #pragma unroll
-        for (int k = 0; k < 2; ++k)
-            if (tid + k * kScatThreads < hh.x) pf_ent[k] = ent[tid + k * kScatThreads];
+        for (int k = 0; k < kEnt; ++k)
+            if (tid + k * kScatThreads < hh.x) { pf_ent[k] = ent[tid + k * kScatThreads]; pf_off[k] = eoff[tid + k * kScatThreads]; }
+    };
+    // the member table of one round of this wave (R groups of 80 bytes, contiguous: 40 lanes x 16 bytes at R = 8) -> LDS, no registers
+    auto copy_groups = [&](const int z, const int rbase_z, const int total_z, const int r0_z) {
+        const int quota_z = ((total_z + 64 * kWaves - 1) / (64 * kWaves)) << 6;
+        const int g0 = (wave * quota_z >> 6) + r0_z;            // the wave's first group of that round
+        if ((g0 << 6) >= total_z) return;                       // (the wave has no records there)
+        const unsigned char *src = p.arc_rec + ((size_t)z * p.arc_slice_stride * p.arc_rec_cap + rbase_z) * 80;
+        if (lane < (C::R * 80) / 16) lds_dma16_s(src, (unsigned)(g0 * 80 + lane * 16), lds_addr(&L.recb[wave][0]));
     };
     // the tile of sums is all zeros when a slice begins: its halo ring (everything but the 32 x 32 points) is dealt to the threads
     // here and cleared again by each slice's store, which also clears the points it has just read
@@ -184,18 +215,20 @@ grid_scatter_kernel(const GridParams p)
         const int m = k - 2 * top, row = m >> 3, c8 = m & 7;
         return (kScatHalo + row) * kScatStride + (c8 < kScatHalo ? c8 : kScatTile + c8);
     };
-    constexpr int kRing = kScatPitch * kScatPitch - kScatTile * kScatTile;
+    constexpr int kRing = G::kRing;
     auto table_to_lds = [&](const int ns_) {
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < kEnt; ++k) {
             const int i = tid + k * kScatThreads;
-            if (i < ns_) L.run[i] = pf_ent[k];
+            if (i < ns_) { L.run[i] = pf_ent[k]; L.off[i] = pf_off[k]; }
         }
     };
     if (zg * zper < p.nslices) {
         hdr_next = p.arc_hdr[(size_t)(zg * zper) * p.arc_slice_stride * p.ntiles + tile];
+        rbase_next = p.arc_rbase[(size_t)(zg * zper) * p.arc_slice_stride * p.ntiles + tile];
         fetch_table(zg * zper, hdr_next);
         table_to_lds(hdr_next.x);
+        copy_groups(zg * zper, rbase_next, hdr_next.w, 0);
     }
     {
         uint4 *const a4 = reinterpret_cast<uint4 *>(&L.acc[0][0]);
@@ -208,15 +241,17 @@ grid_scatter_kernel(const GridParams p)
         const int z = zg * zper + iz;
         if (z >= p.nslices) break;
         const int4 hdr = hdr_next;
-        const int ns = hdr.x, mwin = hdr.y, total = hdr.w;
+        const int mwin = hdr.y, total = hdr.w, rbase = rbase_next;
         const bool more = iz + 1 < zper && z + 1 < p.nslices;
-        if (more) hdr_next = p.arc_hdr[(size_t)(z + 1) * p.arc_slice_stride * p.ntiles + tile];
+        if (more) {
+            hdr_next = p.arc_hdr[(size_t)(z + 1) * p.arc_slice_stride * p.ntiles + tile];
+            rbase_next = p.arc_rbase[(size_t)(z + 1) * p.arc_slice_stride * p.ntiles + tile];
+        }
         const unsigned char *in = reinterpret_cast<const unsigned char *>(p.nudata) + ((size_t)z * (size_t)p.in_slice_stride + c0) * (HALF ? 4 : 8);
 
         SPROF_MARK(0);                                          // set-up (first slice: window table), table -> LDS
         __syncthreads();                                        // this slice's run table is in LDS, the sums are zero
         SPROF_MARK(1);
-        if (more) fetch_table(z + 1, hdr_next);                 // on its way while this slice is gridded
 
         // lane's sample of member entry e at offset k inside the segment -> byte offset of its first channel
         auto sample_off = [&](const uint4 e, const int k) -> unsigned {
@@ -260,20 +295,9 @@ grid_scatter_kernel(const GridParams p)
         // agrees on the largest density-compensated |re|, |im| so far (-> the fixed-point scale; the sums are rescaled if it grew
         // by a power of two), then scatters from registers.  Most tiles are one round.
         constexpr int R = C::R;
-        const int quota = ((total + 255) >> 8) << 6;
-        const int iters = quota >> 6;                           // per wave, the same for all four
+        const int quota = ((total + 64 * kWaves - 1) / (64 * kWaves)) << 6;
+        const int iters = quota >> 6;                           // per wave, the same for all of them
         const int pbeg = wave * quota, pend = min(total, pbeg + quota);
-        int m_cur = 0;
-        if (pbeg < pend) {                                      // the member that holds record pbeg
-            int found = -1;
-            for (int i = lane; i < ns; i += 64) {
-                const unsigned sb = L.run[i].y;
-                const int off = (int)(sb >> 17), len = (int)((sb >> 10) & 127u);
-                if (len > 0 && off <= pbeg && pbeg < off + len) found = i;
-            }
-            const unsigned long long bm = __ballot(found >= 0);
-            m_cur = bm ? __builtin_amdgcn_readlane(found, (int)__builtin_ctzll(bm)) : 0;
-        }
         SPROF_MARK(2);                                          // first member of the wave's quarter
         float run_max = 0.f;                                    // largest weighted sample of the rounds so far (workgroup-uniform)
         int e2 = 0;
@@ -284,14 +308,11 @@ grid_scatter_kernel(const GridParams p)
             v2f dreg[R][NC];
             unsigned meta[R];                                   // member | radius << 9 | valid << 31
             {
-                // The lane's member.  Candidates: the run entries behind the wave's current member, one per lane (read again when the wave has
-                // moved 32 members on).  A candidate whose segment starts inside the lane's 64 records marks its start in a 64-word
-                // scratch row (ds_max: an empty segment shares its successor's start, the later one wins), every lane reads its own word and a
-                // running maximum over the lanes (DPP) gives the last start at or before it -- no loop over the segments.
-                int cbase = m_cur;
-                unsigned offc = 32767u;                         // (beyond every record)
-                { const int ci = cbase + 1 + lane; if (ci < ns) offc = L.run[ci].y >> 17; }
-                unsigned *const row = &L.junk[wave][0];
+                // The lane's member: looked up, not searched -- arc_prep_kernel left, per group of 64 records, one byte per record (its member
+                // minus the member that holds the group's first record) and that member; this round's groups were copied to LDS by LDS-DMA
+                // while the round before (or the slice before) was scattered.
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the copy has landed (it was issued a round ago)
+                const unsigned char *const grp = &L.recb[wave][0];
 #pragma unroll
                 for (int q = 0; q < R; ++q) {
                     meta[q] = 0u;
@@ -299,39 +320,8 @@ grid_scatter_kernel(const GridParams p)
                     if (r0 + q < iters && pbase < pend) {
                         SPROF_COUNT(12, 1);
                         const int pos = pbase + lane;
-                        if (m_cur - cbase >= 32) {
-                            cbase = m_cur;
-                            const int ci = cbase + 1 + lane;
-                            offc = ci < ns ? L.run[ci].y >> 17 : 32767u;
-                        }
-                        int mem = m_cur;
-                        int cb = cbase;
-                        unsigned oc = offc;
-                        for (;;) {
-                            // (lanes talk through LDS here without a workgroup barrier: the LDS executes a wave's instructions in order; the atomics
-                            // and the wave barriers keep the compiler from forwarding the cleared word to the read)
-                            __hip_atomic_store(&row[lane], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                            __builtin_amdgcn_wave_barrier();
-                            const unsigned rel = oc - (unsigned)pbase;
-                            if (rel < 64u) __hip_atomic_fetch_max(&row[rel], (unsigned)lane + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                            __builtin_amdgcn_wave_barrier();
-                            int v = (int)__hip_atomic_load(&row[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                            // inclusive running maximum over the lanes
-                            v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false));      // row_shr:1
-                            v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false));      // row_shr:2
-                            v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false));      // row_shr:4
-                            v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false));      // row_shr:8
-                            v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false));      // row_bcast:15 into rows 1 and 3
-                            v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false));      // row_bcast:31 into rows 2 and 3
-                            if (v > 0) mem = cb + v;
-                            const unsigned last = (unsigned)__builtin_amdgcn_readlane((int)oc, 63);
-                            if (last >= (unsigned)(pbase + 64) || cb + 65 >= ns) break;
-                            cb += 64;                           // (more than 64 segments start inside 64 records: the next candidates)
-                            const int ci = cb + 1 + lane;
-                            oc = ci < ns ? L.run[ci].y >> 17 : 32767u;
-                        }
-                        m_cur = __builtin_amdgcn_readlane(mem, 63);
-                        meta[q] = (unsigned)mem | ((unsigned)pos << 9);      // (the record's position for now)
+                        const unsigned mem = (unsigned)*reinterpret_cast<const unsigned short *>(grp + q * 80 + 64) + (unsigned)grp[q * 80 + lane];
+                        meta[q] = mem | ((unsigned)pos << 9);            // (the record's position for now)
                     }
                 }
                 SPROF_MARK(3);                                  // walk
@@ -344,7 +334,7 @@ grid_scatter_kernel(const GridParams p)
                     if (r0 + q < iters && pbase < pend) {
                         const int mem = (int)(meta[q] & 511u), pos = (int)(meta[q] >> 9);
                         const uint4 e = L.run[mem];
-                        const int off = (int)(e.y >> 17), len = (int)((e.y >> 10) & 127u);
+                        const int off = (int)L.off[mem], len = (int)((e.y >> 10) & 127u);
                         const int k = pos - off;
                         meta[q] = 0u;
                         if (pos < pend && k >= 0 && k < len) {
@@ -406,27 +396,12 @@ grid_scatter_kernel(const GridParams p)
             }
             // ---- the NEXT slice's samples on their way into L2 (its run table has arrived in registers: every thread holds two entries and
             // touches the 128-byte lines of their segments); that slice's front then waits for L2, not for HBM ----
-#ifdef TRON_SCAT_PREFETCH
-            if (more && r0 == 0) {
-                const unsigned char *const in_next = in + (size_t)p.in_slice_stride * (HALF ? 4 : 8);
-                const unsigned junk = lds_addr(&L.junk[wave][0]);
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const uint4 e = pf_ent[k];
-                    const int len = (int)((e.y >> 10) & 127u);
-                    if (tid + k * kScatThreads < hdr_next.x && len > 0) {
-                        const unsigned o0 = sample_off(e, 0), o1 = sample_off(e, len - 1);
-                        const unsigned hi = max(o0, o1) + (unsigned)(NC * (HALF ? 4 : 8)) - 1u;
-                        unsigned a = min(o0, o1) & ~127u;
-#pragma unroll
-                        for (int i = 0; i < (NC == 1 ? 5 : 8); ++i) {
-                            if (a <= hi) lds_dma4_s(in_next, a, junk);        // (LDS-DMA: no destination register to keep alive; the four bytes land in a scratch row)
-                            a += 128u;
-                        }
-                    }
-                }
-            }
-#endif
+            // ---- the NEXT round's member table on its way (this slice's next round, or the first round of the workgroup's next slice) ----
+            if (r0 + R < iters) copy_groups(z, rbase, total, r0 + R);
+            else if (more) copy_groups(z + 1, rbase_next, hdr_next.w, 0);
+            // ... and the next slice's run table (asked for HERE, behind the front's waits: the counters are in order, a request in front of
+            // them would be waited for with the member table)
+            if (more && r0 == 0) fetch_table(z + 1, hdr_next);
             // ---- back: scatter from registers ----
 #pragma unroll
             for (int q = 0; q < R; ++q) {
@@ -517,6 +492,10 @@ grid_scatter_kernel(const GridParams p)
             for (int c = 0; c < NC; ++c) {
                 if (c < ncb) {
 #pragma unroll
+                    for (int kb = 0; kb < G::kBlocksPerThread; ++kb) {
+                    int mx, my;
+                    block_origin(kb, mx, my);
+#pragma unroll
                     for (int qy = 0; qy < 2; ++qy) {
                         unsigned long long *const s2 = &L.acc[c][(my + qy + kScatHalo) * kScatStride + mx + kScatHalo];
                         float f[4];
@@ -530,12 +509,13 @@ grid_scatter_kernel(const GridParams p)
                             f[2 * qx + 1] = (float)im * os;
                         }
                         float4 v = make_float4(f[0], f[1], f[2], f[3]);
-                        float4 *const o = reinterpret_cast<float4 *>(zbase + (size_t)c * p.out_c * 8 + out_off[qy]);
+                        float4 *const o = reinterpret_cast<float4 *>(zbase + (size_t)c * p.out_c * 8 + out_offset(mx, my, qy));
                         if (p.arc_accumulate) {                             // a later pass over more than kArcMaxNpe spokes per window
                             const float4 old = *o;
                             v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
                         }
                         *o = v;
+                    }
                     }
                 }
                 for (int k = tid; k < kRing; k += kScatThreads) L.acc[c][halo_index(k)] = 0ull;
@@ -562,10 +542,11 @@ extern "C" __attribute__((visibility("default"))) int tron_debug_scat_profile(un
 }
 #endif
 
-template <int NC, bool HALF, bool RS>
-static hipError_t launch_scatter_rs(const GridParams &p, int first_plain, hipStream_t s)
+template <int NC, bool HALF, bool RS, int TILE>
+static hipError_t launch_scatter_tile(const GridParams &p, int first_plain, hipStream_t s)
 {
-    const int tpr = (p.nxos + kScatTile - 1) / kScatTile;
+    using G = ScatGeom<TILE>;
+    const int tpr = p.nxos / TILE;
     GridParams q = p;
     q.tiles_per_row = tpr;
     q.ntiles = tpr * tpr;
@@ -574,9 +555,19 @@ static hipError_t launch_scatter_rs(const GridParams &p, int first_plain, hipStr
     const int ngroups = (p.nslices + q.arc_zper - 1) / q.arc_zper;
     const int chunks = (p.nchan - p.coil0 + NC - 1) / NC;
     dim3 grid((unsigned)((size_t)q.ntiles * ngroups), (unsigned)chunks);
-    const size_t lds = sizeof(ScatLds<NC>);
-    hipLaunchKernelGGL((grid_scatter_kernel<NC, HALF, RS>), grid, dim3(kScatThreads), lds, s, q);
+    const size_t lds = sizeof(ScatLds<NC, TILE>);
+    if (lds > 64 * 1024) {
+        const hipError_t once = allow_dynamic_lds(reinterpret_cast<const void *>(grid_scatter_kernel<NC, HALF, RS, TILE>), (int)lds);
+        if (once != hipSuccess) return once;
+    }
+    hipLaunchKernelGGL((grid_scatter_kernel<NC, HALF, RS, TILE>), grid, dim3(G::kThreads), lds, s, q);
     return hipGetLastError();
+}
+
+template <int NC, bool HALF, bool RS>
+static hipError_t launch_scatter_rs(const GridParams &p, int first_plain, hipStream_t s)
+{
+    return p.scat_tile == 64 ? launch_scatter_tile<NC, HALF, RS, 64>(p, first_plain, s) : launch_scatter_tile<NC, HALF, RS, 32>(p, first_plain, s);
 }
 
 template <int NC>
@@ -605,7 +596,7 @@ bool grid_scatter_supported(int nchan, int nxos, int nro, int npe, float W, int 
 hipError_t launch_grid_scatter(const GridParams &p, int half_in, int first_plain, hipStream_t s)
 {
     const int nc = p.nchan - p.coil0;
-    if (p.out_p != 1 || p.inner_r0 <= 0 || !p.arc_hdr || !p.arc_ent || !p.kb_lut || p.lut_entries > kArcLutEntries || p.npe > kArcMaxNpe || !(p.scat_wsum > 0.f) || (int)p.lut_scale != kScatLutS
+    if (p.out_p != 1 || p.inner_r0 <= 0 || !p.arc_hdr || !p.arc_ent || !p.arc_off || !p.arc_rec || !p.arc_rbase || (p.scat_tile != 32 && p.scat_tile != 64) || (p.nxos / 2) % p.scat_tile != 0 || !p.kb_lut || p.lut_entries > kArcLutEntries || p.npe > kArcMaxNpe || !(p.scat_wsum > 0.f) || (int)p.lut_scale != kScatLutS
         || !grid_scatter_supported(nc, p.nxos, p.nro, p.npe, p.W, half_in) || (reinterpret_cast<uintptr_t>(p.nudata) & (half_in ? 3 : 7)) != 0
         || (nc == 2 && (reinterpret_cast<uintptr_t>(p.nudata) & (half_in ? 7 : 15)) != 0))
         return hipErrorInvalidValue;

@@ -77,6 +77,11 @@ struct GridParams {
     const int4 *arc_hdr;               // [window][tile] -> run length, batches, first entry, records
     const uint4 *arc_ent;              // [window][arc_cap] -> first sample index | down << 31, ulo | len << 10 | offset << 17, cos, sin
     const uint32_t *arc_win;           // [window][tile][256] -> per thread of the tile's workgroup its run of the tile's list: first entry | end << 16
+    const uint32_t *arc_off;           // scatter kernel: [window][arc_cap] -> record offset of every entry inside its run
+    const unsigned char *arc_rec;      //                 [window][arc_rec_cap][80] -> per group of 64 records: 64 member bytes + the group's first member (16 bits)
+    const int *arc_rbase;              //                 [window][tile] -> first group of the tile's run in arc_rec
+    int arc_rec_cap;                   //                 groups per window
+    int scat_tile;                     // scatter kernel: tile edge its tables were made for (32 or 64)
     int arc_cap, arc_nrec;             // entries per window; records per batch the runs were dealt for
     int arc_accumulate;                // the arc kernel adds to the grid instead of storing (passes after the first, npe > kArcMaxNpe)
     int arc_slice_stride;              // windows between consecutive slices: 1 (golden angle) or 0 (every slice has the same angles)
@@ -168,6 +173,13 @@ struct ArcPrepParams {
     int nxos, nro, npe, ntiles, inner_r0, nrec, cap;
     float W;
     int flat;                          // tables for grid_scatter_kernel: one batch per run (nrec >= 32767), hdr.y = the longest block window of the tile
+    int tile;                          // flat tables: tile edge, 32 or 64 (0 = 32)
+    uint32_t *off;                     // flat tables: [window][cap] every entry's record offset inside its run (the entry's own field holds its low 15 bits)
+    unsigned char *rec;                // flat tables: [window][rec_cap][80] per GROUP of 64 records of a run: 64 x (member - the member of the group's first
+                                       //              record), that member (16 bits), padding
+    int *rbase;                        //              [window][tile] the run's first group in rec
+    int *ralloc;                       //              [window] groups handed out so far (zeroed by the caller)
+    int rec_cap;                       //              groups per window
 };
 hipError_t launch_arc_prep(const ArcPrepParams &p, int nwindows, hipStream_t s);
 // one or two channels, W <= 2 (tron_grid_scatter.hip): lane = sample, 64-bit fixed-point sums in LDS; same tables (ArcPrepParams::flat), same call as launch_grid_arc

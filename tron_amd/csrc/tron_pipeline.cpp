@@ -295,13 +295,22 @@ int adjoint_run_raw(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, 
                     for (int q = 0; q < p->arc_passes; ++q) {      // (one pass unless a window holds more than kArcMaxNpe spokes)
                         GridParams ga = g;
                         const size_t tab = (size_t)q * p->arc_nwin + win0;
-                        ga.arc_hdr = p->d_arc_hdr + tab * nt32;
+                        const size_t nt_tab = p->scatter && p->scat_tile == 64 ? (size_t)(d.nxos / 64) * (d.nxos / 64) : nt32;
+                        ga.arc_hdr = p->d_arc_hdr + tab * nt_tab;
                         ga.arc_ent = p->d_arc_ent + tab * p->arc_cap;
-                        ga.arc_win = p->d_arc_win + tab * nt32 * 256;
+                        ga.arc_win = p->d_arc_win ? p->d_arc_win + tab * nt32 * 256 : nullptr;
+                        ga.arc_off = p->d_arc_off ? p->d_arc_off + tab * p->arc_cap : nullptr;
+                        ga.scat_tile = p->scat_tile;
+                        ga.arc_rec = p->d_arc_rec ? p->d_arc_rec + tab * (size_t)p->arc_rec_cap * 80 : nullptr;
+                        ga.arc_rbase = p->d_arc_rbase ? p->d_arc_rbase + tab * nt_tab : nullptr;
+                        ga.arc_rec_cap = p->arc_rec_cap;
                         ga.npe = std::min(d.npe1work, (q + 1) * p->arc_pass_npe) - q * p->arc_pass_npe;
                         ga.arc_accumulate = q > 0;
                         ga.scat_wsum = p->scat_wsum;
-                        if (p->scatter) HIP_TRY(launch_grid_scatter(ga, p->cfg.input_half, relief_parts, st));
+                        if (p->scatter && p->scat_tile == 64) {
+                            ga.tile_order = p->d_tile_order64;          // (its own list of 64-tiles; no inner-tile entries in front)
+                            HIP_TRY(launch_grid_scatter(ga, p->cfg.input_half, 0, st));
+                        } else if (p->scatter) HIP_TRY(launch_grid_scatter(ga, p->cfg.input_half, relief_parts, st));
                         else HIP_TRY(launch_grid_arc(ga, p->cfg.input_half, relief_parts, st));
                     }
                     if (p->centre_kernel) {

@@ -346,15 +346,35 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
                 // a spoke crosses at most 2 * nxos / 32 + 3 tiles (+ their halos): 56 run entries per spoke bound every window
                 p->arc_cap = sub * (2 * (d.nxos / kBinnedTile) + 24);
                 p->arc_nrec = p->scatter ? 32767 : grid_arc_nrec(p->nchan, cfg->input_half);      // (scatter kernel: one batch per run)
+                // Scatter kernel: 64 x 64 tiles where the grid's centre is a corner of four of them, the channels go one per pass (two channels
+                // per pass would need 100 KB of sums) and a centre tile's run -- ~0.6 of a window's spokes -- fits the 512 run entries
+                p->scat_tile = 32;
+                if (p->scatter && p->nchan != 2 && (d.nxos / 2) % 64 == 0 && d.nxos >= 256 && sub <= 800) p->scat_tile = 64;
+                if (const char *e = tuning_env("TRON_SCAT_TILE")) { if (atoi(e) == 32 || (atoi(e) == 64 && (d.nxos / 2) % 64 == 0 && p->nchan != 2)) p->scat_tile = atoi(e); }
+                const size_t nt_tab = p->scatter && p->scat_tile == 64 ? (size_t)(d.nxos / 64) * (d.nxos / 64) : (size_t)nt32;
+                if (p->scatter && p->scat_tile == 64) {
+                    std::vector<int> o64;
+                    build_tile_order(d.nxos, 64, o64);
+                    if ((rc = upload(&p->d_tile_order64, o64.data(), o64.size() * sizeof(int)))) return bail(rc);
+                }
                 rc = upload(&d_order, order.data(), order.size() * sizeof(unsigned short));
                 if (!rc) rc = upload(&d_scs, scs.data(), scs.size() * sizeof(float));
                 p->d_cen_order = d_order;                       // the sorted lists stay: centre kernel
                 p->d_cen_cs = reinterpret_cast<float2 *>(d_scs);
                 const size_t ntab = nwin * (size_t)npass;       // tables [pass][window]
-                if (!rc && (hipMalloc(reinterpret_cast<void **>(&p->d_arc_hdr), ntab * nt32 * sizeof(int4)) != hipSuccess ||
+                if (!rc && (hipMalloc(reinterpret_cast<void **>(&p->d_arc_hdr), ntab * nt_tab * sizeof(int4)) != hipSuccess ||
                             hipMalloc(reinterpret_cast<void **>(&p->d_arc_ent), ntab * p->arc_cap * sizeof(uint4)) != hipSuccess ||
-                            hipMalloc(reinterpret_cast<void **>(&p->d_arc_win), ntab * nt32 * 256 * sizeof(uint32_t)) != hipSuccess))
+                            (p->scatter ? hipMalloc(reinterpret_cast<void **>(&p->d_arc_off), ntab * p->arc_cap * sizeof(uint32_t))        // (scatter kernel: offsets, no thread windows)
+                                        : hipMalloc(reinterpret_cast<void **>(&p->d_arc_win), ntab * nt32 * 256 * sizeof(uint32_t))) != hipSuccess))
                     rc = fail(TRON_ERR_NOMEM, "cannot allocate the arc kernel's run tables");
+                if (!rc && p->scatter) {
+                    // one byte per record of every run (its member; arc_prep_kernel) + 16 bits per 64 records: a sample lies in 1.13 (64-tiles) to
+                    // 1.27 (32-tiles) runs on average, a little more where few spokes make the corner segments count; runs are padded to 64
+                    p->arc_rec_cap = (int)(((size_t)sub * d.nro * 3 / 2) / 64 + nt_tab + 16);     // groups of 64 records per window (+ slack: the kernel copies whole rounds)
+                    if (hipMalloc(reinterpret_cast<void **>(&p->d_arc_rec), (ntab * (size_t)p->arc_rec_cap + 16) * 80) != hipSuccess ||
+                        hipMalloc(reinterpret_cast<void **>(&p->d_arc_rbase), ntab * nt_tab * sizeof(int)) != hipSuccess)
+                        rc = fail(TRON_ERR_NOMEM, "cannot allocate the scatter kernel's record tables");
+                }
                 if (rc) return bail(rc);
                 unsigned int zero = 0;
                 if ((rc = upload(&p->d_errflag, &zero, sizeof(zero)))) return bail(rc);
@@ -390,18 +410,24 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
                         dq_order = d_order; dq_scs = d_scs;
                     }
                     if (!rc) rc = upload(&dq_phi, hp, nwin * nq * sizeof(float));
-                    if (!rc && hipMalloc(reinterpret_cast<void **>(&d_alloc), nwin * sizeof(int)) != hipSuccess) rc = fail(TRON_ERR_NOMEM, "arc tables");
+                    if (!rc && hipMalloc(reinterpret_cast<void **>(&d_alloc), 2 * nwin * sizeof(int)) != hipSuccess) rc = fail(TRON_ERR_NOMEM, "arc tables");
                     if (rc) { drop(); break; }
                     // ON THE PLAN'S STREAM: a memset of device memory on the null stream returns before it has run, and a non-blocking stream
                     // does not wait for it -- arc_prep_kernel then handed out run-table space from whatever the allocation held (round 3's
                     // `hipMemset`: tables that overlapped, or an overflow flag and a silent fall-back to the binned kernel; one first process
                     // in three on a fresh box, most runs with eight plans being created at once)
-                    if (hipMemsetAsync(d_alloc, 0, nwin * sizeof(int), p->stream) != hipSuccess) { drop(); rc = fail(TRON_ERR_HIP, "hipMemsetAsync failed"); break; }
+                    if (hipMemsetAsync(d_alloc, 0, 2 * nwin * sizeof(int), p->stream) != hipSuccess) { drop(); rc = fail(TRON_ERR_HIP, "hipMemsetAsync failed"); break; }
                     ArcPrepParams ap;
                     ap.order = dq_order; ap.phi = dq_phi; ap.cs = reinterpret_cast<const float2 *>(dq_scs);
-                    ap.hdr = p->d_arc_hdr + (size_t)q * nwin * nt32; ap.ent = p->d_arc_ent + (size_t)q * nwin * p->arc_cap;
-                    ap.win = p->d_arc_win + (size_t)q * nwin * nt32 * 256; ap.band = p->d_band; ap.alloc = d_alloc; ap.errflag = p->d_errflag;
-                    ap.nxos = d.nxos; ap.nro = d.nro; ap.npe = nq; ap.ntiles = nt32; ap.inner_r0 = p->relief_r0; ap.nrec = p->arc_nrec;
+                    ap.hdr = p->d_arc_hdr + (size_t)q * nwin * nt_tab; ap.ent = p->d_arc_ent + (size_t)q * nwin * p->arc_cap;
+                    ap.win = p->d_arc_win ? p->d_arc_win + (size_t)q * nwin * nt32 * 256 : nullptr; ap.band = p->d_band; ap.alloc = d_alloc; ap.errflag = p->d_errflag;
+                    ap.off = p->d_arc_off ? p->d_arc_off + (size_t)q * nwin * p->arc_cap : nullptr;
+                    ap.tile = p->scatter ? p->scat_tile : 0;
+                    ap.rec = p->d_arc_rec ? p->d_arc_rec + (size_t)q * nwin * p->arc_rec_cap * 80 : nullptr;
+                    ap.rbase = p->d_arc_rbase ? p->d_arc_rbase + (size_t)q * nwin * nt_tab : nullptr;
+                    ap.ralloc = d_alloc + nwin;
+                    ap.rec_cap = p->arc_rec_cap;
+                    ap.nxos = d.nxos; ap.nro = d.nro; ap.npe = nq; ap.ntiles = (int)nt_tab; ap.inner_r0 = p->relief_r0; ap.nrec = p->arc_nrec;
                     ap.cap = p->arc_cap; ap.W = cfg->kernwidth; ap.flat = p->scatter ? 1 : 0;
                     he = launch_arc_prep(ap, (int)nwin, p->stream);
                     if (he == hipSuccess) he = hipStreamSynchronize(p->stream);
@@ -414,8 +440,10 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
                 if (flag) {   // a trajectory the arc kernel's tables cannot hold: the binned kernel takes all tiles
                     hipMemsetAsync(p->d_errflag, 0, sizeof(flag), p->stream);
                     hipStreamSynchronize(p->stream);
-                    hipFree(p->d_arc_hdr); hipFree(p->d_arc_ent); hipFree(p->d_arc_win);
-                    p->d_arc_hdr = nullptr; p->d_arc_ent = nullptr; p->d_arc_win = nullptr;
+                    hipFree(p->d_arc_hdr); hipFree(p->d_arc_ent); hipFree(p->d_arc_win); hipFree(p->d_arc_off);
+                    hipFree(p->d_arc_rec); hipFree(p->d_arc_rbase);
+                    p->d_arc_hdr = nullptr; p->d_arc_ent = nullptr; p->d_arc_win = nullptr; p->d_arc_off = nullptr;
+                    p->d_arc_rec = nullptr; p->d_arc_rbase = nullptr;
                     hipFree(p->d_cen_order); hipFree(p->d_cen_cs);
                     p->d_cen_order = nullptr; p->d_cen_cs = nullptr;
                     p->arc = false;
@@ -596,6 +624,10 @@ extern "C" int tron_plan_destroy(tron_plan *p)
     hipFree(p->d_split_slots);
     hipFree(p->d_partial);
     hipFree(p->d_tile_order32_relief);
+    hipFree(p->d_tile_order64);
+    hipFree(p->d_arc_off);
+    hipFree(p->d_arc_rec);
+    hipFree(p->d_arc_rbase);
     hipFree(p->d_relief_slots);
     hipFree(p->d_tile_order32_relief_small);
     hipFree(p->d_relief_slots_small);

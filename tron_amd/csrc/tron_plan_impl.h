@@ -91,6 +91,12 @@ struct tron_plan {
     bool arc = false;
     bool scatter = false;                 // ... gridded by grid_scatter_kernel (one or two channels, tron_grid_scatter.hip): same tables, one batch per run
     float scat_wsum = 0;
+    int scat_tile = 32;                   // ... on 32 x 32 or 64 x 64 tiles (its run tables are made for one of them)
+    uint32_t *d_arc_off = nullptr;        // scatter kernel: record offset of every run entry
+    unsigned char *d_arc_rec = nullptr;   //                 per group of 64 records of every run: 80 bytes (arc_prep_kernel)
+    int *d_arc_rbase = nullptr;           //                 [window][tile] first record of the run
+    int arc_rec_cap = 0;
+    int *d_tile_order64 = nullptr;        // 64-tiles, centre first
     int4 *d_arc_hdr = nullptr;
     uint4 *d_arc_ent = nullptr;
     uint32_t *d_arc_win = nullptr;
