@@ -237,7 +237,15 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
                 p->scatter = p->scatter && strcmp(gk, "binned") != 0 && strcmp(gk, "arc") != 0;
                 p->arc = p->arc && strcmp(gk, "binned") != 0;
             }
-            if (p->scatter) p->arc = true;
+            if (p->scatter) {
+                p->arc = true;
+                // The arc formulation starves next to the k-space centre (a block there meets every spoke), which is why the samples |r| < 14 have
+                // a kernel of their own; a sample-driven kernel does not, so its plans leave that kernel only the samples |r| < 5 (a quadrant
+                // tile must still hold one side of a spoke only: more than W sqrt(2) = 2.83): 9 of a spoke's samples instead of 27.
+                int r0 = 5;
+                if (const char *e = tuning_env("TRON_SCAT_R0")) r0 = std::max(3, std::min(atoi(e), p->relief_r0));
+                p->relief_r0 = std::min(p->relief_r0, r0);
+            }
             if (p->arc) {
                 // plan-time pass: every window's spokes sorted by line angle (host), clipped against every tile and dealt
                 // into batches (arc_prep_kernel); the sorted lists are scratch
@@ -370,7 +378,9 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
                 if (!rc && p->scatter) {
                     // one byte per record of every run (its member; arc_prep_kernel) + 16 bits per 64 records: a sample lies in 1.13 (64-tiles) to
                     // 1.27 (32-tiles) runs on average, a little more where few spokes make the corner segments count; runs are padded to 64
-                    p->arc_rec_cap = (int)(((size_t)sub * d.nro * 3 / 2) / 64 + nt_tab + 16);     // groups of 64 records per window (+ slack: the kernel copies whole rounds)
+                    // groups of 64 records per window: a spoke holds nxos - 1 radii (whatever its readout length), a record lies in 1.13-1.27
+                    // runs on average, every run ends on a partly filled group (+ slack: the kernel copies whole rounds)
+                    p->arc_rec_cap = (int)(((size_t)sub * d.nxos * 3 / 2) / 64 + nt_tab + 16);
                     if (hipMalloc(reinterpret_cast<void **>(&p->d_arc_rec), (ntab * (size_t)p->arc_rec_cap + 16) * 80) != hipSuccess ||
                         hipMalloc(reinterpret_cast<void **>(&p->d_arc_rbase), ntab * nt_tab * sizeof(int)) != hipSuccess)
                         rc = fail(TRON_ERR_NOMEM, "cannot allocate the scatter kernel's record tables");
