@@ -1,5 +1,5 @@
-// Gridding kernel of the TRON_KB_FAST path for ONE or TWO channels: every lane takes a SAMPLE and adds it to the 4x4 grid points
-// of its Kaiser-Bessel footprint in a tile of 64-bit fixed-point sums in LDS (integer LDS atomics).
+// Gridding kernel of the TRON_KB_FAST path for ONE channel per pass (any odd channel count, one by one) or TWO: every lane takes a
+// SAMPLE and adds it to the 4x4 grid points of its Kaiser-Bessel footprint in a tile of 64-bit fixed-point sums in LDS (integer atomics).
 //
 // Why a second formulation.  grid_arc_kernel (thread = 2x2 grid points, the samples come to it) spends ~34 VALU instructions per
 // (sample, block) visit of which only 4-8 depend on the coils, visits every sample from ~6 blocks, and runs its radius loop at 0.57
@@ -8,28 +8,34 @@
 // instructions per POINT and visit, so 4x4 points per thread save nothing).  Turned round -- lane = sample -- every sample is
 // handled once: positions and the eight window values once, then 16 point updates.  The updates are LDS atomics; float atomics run
 // at 3 clocks per LANE on this chip (profiles/round1_lds_atomic_rates.txt), 64-bit INTEGER ones hide completely under the arithmetic
-// (tools/probe/scatter.hip: 154 clocks per 64 samples and CU with ds_add_u64, 172 for the arithmetic alone), so the tile holds
-// (re << 32) + im as two 32-bit fixed-point numbers per point and channel, scaled per (tile, slice) by a power of two:
-//   scale   S = 2^e, the largest with  max|d| * dcf_max * M * 4 K(0)^2 * S < 2^30, M = the most spokes whose line can pass any of the
-//           tile's 2x2 blocks (the arc kernel's window rule; arc_prep_kernel leaves it in the run header) and 4 K(0)^2 a bound of the
-//           window products one spoke can add to one point: no sum can leave 32 bits.  What is lost is 2^-25..2^-23 of the
-//           tile's largest sample per added term -- the level of fp32 rounding for data whose magnitude does not vary by orders
-//           of magnitude INSIDE one 32x32 tile (measured: parity_rel_l2_vs_oracle on the bench line; tests/test_gpu_scatter.py).
+// (tools/probe/scatter.hip: 154 clocks per 64 samples and CU with ds_add_u64, 172 for the arithmetic alone) and are exact when
+// lanes of one instruction meet on an address (tools/probe/atom64.hip), so the tile holds (re << 32) + im as two 32-bit fixed-point
+// numbers per point and channel, scaled per (tile, slice) by a power of two:
+//   scale   S = 2^e, the largest with  max(|d| dcf) * M * 4 K(0)^2 * S < 2^31, the maximum over the tile's own samples, M = the most spokes
+//           whose line can pass any of the tile's 2x2 blocks (the arc kernel's window rule; arc_prep_kernel leaves it in the run header)
+//           and 4 K(0)^2 a bound of the window products one spoke can add to one point: no sum can leave 32 bits.  What is lost is
+//           2^-25..2^-23 of the tile's largest weighted sample per added term -- the level of fp32 rounding for data whose magnitude does
+//           not vary by orders of magnitude INSIDE one tile (measured: parity_rel_l2_vs_oracle on the bench line; tests/test_gpu_scatter.py).
 //   order   integer sums do not depend on the order of the additions: bit-identical results run to run by construction.
 // Same (sample, point) pairs as the reference's gridradial2d (src/tron.cu:465-536): |kx - X| < W and |ky - Y| < W strictly (the
-// arc kernel's pair table: exact support, build_kb_pair_lut), band Rlo <= |r| <= Rhi from the host's band table (:498-502,
-// :512, :521), density compensation :412-414, scale :532, (kx, ky) = r (cos, sin) as two fp32 products (:514-515).
+// arc kernel's pair table: exact support, build_kb_pair_lut), band Rlo <= |r| <= Rhi (:498-502, :512, :521) as one exact comparison
+// checked against the host's band table (scatter_band_is_analytic), density compensation :412-414, scale :532, (kx, ky) = r (cos, sin)
+// as two fp32 products (:514-515).
 //
-// Work per (tile, slice), one workgroup of four waves (tables: arc_prep_kernel with ONE batch per run, so that the record offsets
-// number the tile's samples 0 .. total-1):
-//   table    the tile's run of crossing spokes (<= 512 entries, asked for one slice ahead) -> LDS; tile of sums zeroed;
-//   maximum  wave = spoke segment, lane = radius: max |re|, |im| of the tile's samples -> S (the samples then come from L1 / L2 again);
-//   scatter  wave = 64 consecutive records of its quarter of the run: the lane's spoke by a walk over the <= ~3 segments that start
-//            inside the 64 records (wave-uniform, v_readlane), sample -> (kx, ky) -> first column / row of the footprint -> two
-//            pair-table positions per axis -> 4 + 4 window values; d * dcf * S * wx[j] once per column, then per point: * wy[i], two
-//            conversions, one ds_add_u64 under the band test (one LDS read of the point's band, two SDWA compares);
-//   store    thread = 2x2 points: (float)sum * 2^-e * scale, once, coil-planar, FFT-native order (as the arc kernel).
-// The samples |r| < inner_r0 are the centre kernel's (tron_grid_centre.hip), behind this one on the same stream.
+// Work per (tile, slice); a tile is 32 x 32 points and four waves, or 64 x 64 and eight (ScatGeom); tables: arc_prep_kernel with ONE batch
+// per run (ArcPrepParams::flat), so that the record offsets number the tile's samples 0 .. total-1, plus one byte per record naming
+// its member:
+//   front    every wave takes an equal share of the records, 64 per iteration, R iterations per round: the lane's (spoke, radius) from
+//            the member table (80 bytes per 64 records, copied to LDS by one LDS-DMA instruction a round ahead), its run entry from LDS,
+//            its sample by a plain load straight from k-space -- all R loads of a wave in flight together -- into registers;
+//   scale    the largest |d| dcf so far through an LDS maximum and a barrier -> S; sums rescaled if it grew by a power of two;
+//   scatter  sample -> (kx, ky) -> first column / row of the footprint (the reference's own distance test decides a rounded boundary) -> two
+//            pair-table positions per axis -> 4 + 4 window values; d * dcf * S * wx[j] once per column, then per point: * wy[i] (zero outside
+//            the band), two conversions, one ds_add_u64 at an immediate offset;
+//   store    thread = 2x2 points: (float)sum * 2^-e * scale, once, coil-planar, FFT-native order (as the arc kernel); the tile zeroed and
+//            the next slice's run table written for the next slice: three barriers per slice.
+// The samples |r| < inner_r0 (5 in this kernel's plans, tron_plan.cpp) are the centre kernel's (tron_grid_centre.hip), behind this one
+// on the same stream.
 #include <stdlib.h>
 
 #include "tron_device.h"
