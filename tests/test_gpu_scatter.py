@@ -217,6 +217,21 @@ def test_scatter_kernel_tile_sizes_agree(oracle, nc, nro, npe, nz):
         assert rel_l2(out["32"][:, t:t + 1], want) <= 1e-5 and rel_l2(out["64"][:, t:t + 1], want) <= 1e-5
 
 
+@pytest.mark.parametrize("tile", ["32", "64"])
+@pytest.mark.parametrize("nro,npe,nz", [(256, 12, 64), (512, 30, 32), (256, 6, 128)])
+def test_scatter_kernel_empty_runs_between_the_slices_of_one_workgroup(oracle, tile, nro, npe, nz):
+    """Few spokes per window: tiles that no spoke of window z crosses but some spoke of window z + 1 does.  A workgroup grids up to
+    four consecutive slices of its tile and issues the next slice's requests (run table, member table) from inside the current
+    slice's rounds -- an empty run has none (the arc kernel's round-4 bug in another coat, found by running the suite on 32 x 32
+    tiles: a stale member table sent the sample loads out of bounds).  Both tile sizes, against the oracle."""
+    data = synth.kspace(1, nro, npe * nz, seed=9990 + npe)
+    fl = dict(golden_angle=1, data_undersamp=(npe + 0.5) / nro, prof_slide=npe)
+    got = _child(data, dict(TRON_GRID_KERNEL="scatter", TRON_SCAT_TILE=tile), **fl)
+    want, _ = oracle.recon(data, adjoint=1, golden=1, data_undersamp=(npe + 0.5) / nro, prof_slide=npe)
+    for z in range(nz):
+        assert rel_l2(got[..., z], want[..., z]) <= 1e-5, z
+
+
 def test_shapes_the_scatter_kernel_leaves_to_the_arc_kernel():
     os.environ.pop("TRON_GRID_KERNEL", None)              # the plan's own choice
     try:

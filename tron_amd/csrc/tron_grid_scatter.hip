@@ -487,6 +487,12 @@ grid_scatter_kernel(const GridParams p)
             }
             SPROF_MARK(6);                                      // scatter
         }
+        // an empty run (a rim tile no spoke of this window crosses) has no round to issue the next slice's requests from: without
+        // them the next slice of this workgroup would look its members up in a stale table (tests: few spokes per window, 64 slices)
+        if (iters <= 0 && more) {
+            copy_groups(z + 1, rbase_next, hdr_next.w, 0);
+            fetch_table(z + 1, hdr_next);
+        }
         __syncthreads();                                        // every sample of the slice has been added
         SPROF_MARK(7);
 
