@@ -70,6 +70,9 @@ CASES = [
     (1, 256, 100, 2, dict(golden_angle=1, gridos=3.0)),
     (2, 256, 1300, 2, dict(golden_angle=1)),                        # more than 1 024 spokes per window: two passes, the second adds
     (1, 256, 12, 64, dict(golden_angle=1)),                         # few spokes, 4 slices per workgroup: empty runs between them
+    (1, 256, 1300, 2, dict(golden_angle=1)),                        # one channel, two passes of 650 spokes (64-tiles, the second pass adds)
+    (1, 256, 150, 7, dict(golden_angle=1, prof_slide=37)),          # one channel, sliding windows, a slice count that is no multiple of the slices per workgroup
+    (1, 512, 804, 2, dict(golden_angle=1)),                         # config 4's slice shape with one coil: the largest runs a 64-tile sees here
 ]
 
 

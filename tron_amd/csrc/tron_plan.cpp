@@ -242,7 +242,10 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
                 // The arc formulation starves next to the k-space centre (a block there meets every spoke), which is why the samples |r| < 14 have
                 // a kernel of their own; a sample-driven kernel does not, so its plans leave that kernel only the samples |r| < 5 (a quadrant
                 // tile must still hold one side of a spoke only: more than W sqrt(2) = 2.83): 9 of a spoke's samples instead of 27.
-                int r0 = 5;
+                // (A centre tile's run holds every spoke whose line is inside tile + W at radius r0: the quadrant's 90 degrees + 2 asin(W sqrt(2) / r0) --
+                // 0.76 of a window's spokes at r0 = 5, 0.59 at 14 -- and a run has 512 entries: windows (passes) of more than 640 spokes keep 14.)
+                const int npass_ = (d.npe1work + kArcMaxNpe - 1) / kArcMaxNpe, sub_ = (d.npe1work + npass_ - 1) / npass_;
+                int r0 = sub_ <= 640 ? 5 : p->relief_r0;
                 if (const char *e = tuning_env("TRON_SCAT_R0")) r0 = std::max(3, std::min(atoi(e), p->relief_r0));
                 p->relief_r0 = std::min(p->relief_r0, r0);
             }
