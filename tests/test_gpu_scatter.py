@@ -247,3 +247,39 @@ def test_shapes_the_scatter_kernel_leaves_to_the_arc_kernel():
     assert "grid_arc_kernel" in _kernel_name((2, 1, 256, 100, 1), golden_angle=1, data_undersamp=0.39, kernwidth=2.5)     # six points per axis
     assert "grid_arc_kernel" in _kernel_name((2, 1, 256, 100, 1), golden_angle=1, data_undersamp=0.39, kernwidth=1.5)     # the inner points are not always inside their band
     assert "grid_scatter_kernel" in _kernel_name((2, 1, 256, 100, 1), golden_angle=1, data_undersamp=0.39)
+
+
+def test_scatter_kernel_random_shapes_vs_the_bit_exact_gather():
+    """Random one- and three-channel plans on grids that take the scatter kernel (W = 2; 64- and 32-tiles, resampled readouts, sliding
+    windows, complex-half input, few to many spokes, linear and golden angles) against TRON_KB_EXACT on the GPU -- the order-preserving
+    gather that is bit-identical to the reference's sums.  Fixed seed."""
+    rng = np.random.default_rng(20261005)
+    worst = 0.0
+    for it in range(36):
+        nt = int(rng.choice([1, 1, 1, 3]))
+        nro = int(rng.choice([128, 192, 256, 256, 320, 512]))
+        gridos = float(rng.choice([1.5, 2.0, 2.0, 2.0, 2.5, 3.0]))
+        nxos = int((nro // 2) * gridos)
+        if nxos % 64 != 0 or nxos < 128:
+            gridos = 2.0
+        npe = int(rng.integers(3, 40)) if rng.integers(0, 3) == 0 else int(rng.integers(40, 520))
+        nz = int(rng.integers(1, 10))
+        slide = int(rng.integers(1, npe + 1))
+        golden = int(rng.integers(0, 4) != 0)
+        half = bool(rng.integers(0, 4) == 0)
+        fl = dict(golden_angle=golden, data_undersamp=(npe + 0.5) / nro, prof_slide=slide, gridos=gridos, skip_angles=int(rng.integers(0, 40)))
+        data = synth.kspace(1, nro, npe + slide * (nz - 1), seed=7000 + it, nt=nt)
+        src = data
+        if half:
+            h = np.stack([data.real, data.imag]).astype(np.float16)
+            src = h
+            fl["input_half"] = 1
+        desc = f"nt={nt} nro={nro} os={gridos} npe={npe} nz={nz} slide={slide} G={golden} half={half}"
+        name = _kernel_name(data.shape, **fl)
+        assert "grid_scatter_kernel" in name, (desc, name)
+        fast, _ = lib.recon(src, adjoint=True, kb_mode=lib.KB_FAST, **fl)
+        exact, _ = lib.recon(src, adjoint=True, kb_mode=lib.KB_EXACT, **fl)
+        e = rel_l2(fast, exact)
+        worst = max(worst, e)
+        assert e <= 1e-5, (desc, e)
+    assert worst <= 1e-5
