@@ -47,6 +47,11 @@ CASES = [
     (4, 128, 16, lib.KB_EXACT, 4.0, 1, None, "ceil(W) = 4"),
     (4, 192, 16, lib.KB_FAST, 2.0, 1, 64 / 384 + 1e-6, "384^2 grid: rocFFT, grid not transposed"),
     (4, 256, 16, lib.KB_FAST, 2.0, 1, 804.5 / 512, "804 spokes: two clipping rounds per image"),
+    # round 5: the kept records are dealt by the bank class of their footprint's first point (rows of 32 classes, padded while wide)
+    (8, 256, 16, lib.KB_FAST, 2.0, 1, None, "512 spokes: padded rows; lists longer than the kept passes round the centre"),
+    (4, 256, 16, lib.KB_FAST, 2.0, 0, 300.5 / 512, "300 linear spokes: rows with holes next to rows without"),
+    (4, 256, 16, lib.KB_FAST, 2.0, 1, 8.5 / 512, "8 spokes: a few records per tile, every row narrow"),
+    (4, 256, 16, lib.KB_FAST, 3.0, 1, 200.5 / 512, "ceil(W) = 3 with the fast weights: the 40-row tile's classes"),
 ]
 
 
@@ -115,7 +120,7 @@ def test_forward_switches_change_no_bit():
     ref = _forward_in_child(imgs, nimg, {}, **flags)
     assert np.isfinite(ref).all()
     for env in ({"TRON_GRID_ROT": "0"}, {"TRON_GRID_ROT": "4"}, {"TRON_FFT_FWD_COLS_PLAIN": "1"}, {"TRON_FFT_FWD_ROWS_PLAIN": "1"},
-                {"TRON_DEGRID_TILE": "1", "TRON_GRID_ROT": "0"}, {"TRON_DEGRID_SIMPLE": "1"}):
+                {"TRON_DEGRID_TILE": "1", "TRON_GRID_ROT": "0"}, {"TRON_DEGRID_NOSORT": "1"}, {"TRON_DEGRID_SIMPLE": "1"}):
         got = _forward_in_child(imgs, nimg, env, **flags)
         if "TRON_DEGRID_SIMPLE" in env:         # the thread-per-sample kernel: the exact weights' order, fast weights differ in the last bits
             assert rel_l2(got, ref) <= 2e-6, env

@@ -15,6 +15,14 @@
 // clipping and barriers alone 0.74 us, with the gather 1.37, with the stores instead 1.44, everything 1.70 -- the copies and
 // the stores add up as if they shared one path, the gather (LDS ~50 % busy, bank conflicts 2.25-fold measured and 2.7-fold
 // simulated for ANY row pitch: 32 samples along a spoke always meet a short vector of the bank lattice) overlaps them in part.
+// Round 5 (profiles/round5_forward_dealing_ab.log, round5_forward_unkept_records.log): the kept records are dealt by bank class
+// (below: 1.2 LDS cycles per read where the sorted order of round 3 met 1.8; degridding -4 to -5 % in interleaved runs on two boxes).
+// Measured and not kept: three kept passes instead of two; an order of the UNKEPT records other than along their spokes (any fixed
+// permutation inside a 64-record block: 3.0-3.3 cycles per read against 2.7, simulated); the long lists round the centre dealt to
+// several workgroups in equal shares, every record kept and every run 16 images (1.62 against 1.59 us: each share loads the whole
+// tile again, +29 % tile loads).  The records beyond the kept passes -- 21 % of the bench's samples, in the 32 tiles round the
+// centre -- cost 0.40 of 1.62 us (a build that skips them); the drain of an image's stores behind vmcnt(0) costs nothing (a build
+// without the wait).
 //
 // The tile is held as the input planes lie in memory ([col][row] for the fused forward FFT, which stores the grid
 // transposed): the sample loop strides accordingly.  The halo is rounded up to even widths so that a 16-byte piece
@@ -31,6 +39,12 @@ namespace tron {
 constexpr int kDsThreads = 768;     // three waves per SIMD (512 and 1024 threads measured the same within noise)
 constexpr int kDsMaxSpokes = 512;   // spokes clipped per round
 constexpr int kDsMaxBlocks = 512;   // 64-record blocks indexed by the inverse map
+#ifndef TRON_DS_SORT_LONG
+#define TRON_DS_SORT_LONG 1     // a list longer than the kept passes (the tiles round the centre): its first kDsKeep passes are dealt the same way
+#endif
+#ifndef TRON_DS_KEEP
+#define TRON_DS_KEEP 2
+#endif
 constexpr int kDsCoils = 4;         // coils per workgroup (32-byte pieces of the coil-interleaved output lines)
 
 template <int CW>
@@ -145,23 +159,43 @@ __global__ void __launch_bounds__(kDsThreads) degrid_stream_kernel(const DegridP
     // worth is computed once and kept in registers over the run (a tile holds ~1 000 records on average, 1.3 passes of 768;
     // the counters showed VALU and LDS time adding up rather than overlapping, and two thirds of a pass's VALU
     // instructions are this preparation); later passes and the exact weights take the per-record loop.
-    constexpr int kDsKeep = 2;
+    constexpr int kDsKeep = TRON_DS_KEEP;
     const bool same_records = nrounds == 1 && p.trig_img_stride == 0;
     DgPrep<2 * CW> kept[kDsKeep];
 #pragma unroll
     for (int j = 0; j < kDsKeep; ++j) kept[j].own = false;
     if (same_records && TRON_DBG_LT(p, 2)) {
         rd = dg_clip_round<kDsThreads, kDsMaxSpokes, kDsMaxBlocks>(p, L, k0, 0, tid, tx0, ty0, n, nr);
-        if (KB == TRON_KB_FAST && rd.nrec <= kDsKeep * kDsThreads && !p.debug_nosort) {
-            // All records fit the kept passes: they are dealt out SORTED BY THE POINT THEIR FOOTPRINT STARTS AT (counting sort
-            // through the wave stage area, once per run).  The lanes of a wave then gather from neighbouring points of a tile
-            // row -- consecutive LDS addresses -- where the samples of a spoke, 64 in a row, met 2.25-fold bank conflicts
-            // whatever the row pitch.  Records of other tiles' samples drop out here instead of idling a lane every image.
+        if (KB == TRON_KB_FAST && (rd.nrec <= kDsKeep * kDsThreads || TRON_DS_SORT_LONG) && !p.debug_nosort) {
+            // All records fit the kept passes: they are dealt out BY THE BANKS THEIR FOOTPRINT STARTS ON.  Every LDS read of a record
+            // sits at a fixed offset from the point its footprint starts at, and a ds_read_b64 serves a wave in two groups of 32 lanes,
+            // one LDS cycle per distinct address on a group's busiest pair of banks (pair = 8-byte word mod 32): a group whose lanes
+            // start on 32 different pairs gathers all its 16 x coils reads without a conflict.  So: counting sort by start point (round
+            // 3: neighbouring lanes gather neighbouring points; 64 samples along a spoke met 2.7 cycles per read, the sorted order 1.8 --
+            // tools/probe/degrid_deal_sim.py replays the bench's trajectory), then CLASS = start point mod 32, RANK = the record's place
+            // among its class in sorted order, and row r of the deal = the records of rank r, lane = class.  Rows are 32 wide while
+            // every class still has a record of that rank; rows at least kDsRowPad wide keep their holes (a whole group, no
+            // conflict), narrower ones follow each other without gaps (1.2 cycles per read over the bench's tiles at 4 % more lane
+            // slots).  Records of other tiles' samples drop out here instead of idling a lane every image.  Once per run.
             constexpr int EPT = (PLANE + kDsThreads - 1) / kDsThreads;      // points per thread in the scan
+            constexpr int NSTR = (PLANE + 31) / 32;                         // points of one class
+            constexpr int NQ = kDsThreads / 32, EQ = (NSTR + NQ - 1) / NQ;  // ... dealt to NQ threads, EQ each
+#ifndef TRON_DS_ROW_PAD
+#define TRON_DS_ROW_PAD 24
+#endif
+            constexpr int kDsRowPad = TRON_DS_ROW_PAD, kDsMaxRows = 128;     // (-DTRON_DS_ROW_PAD=33: no padded rows; -DTRON_DS_SORTED_DEAL: round 3's order)
             unsigned *hist = reinterpret_cast<unsigned *>(L.stage);         // [PLANE] counts, then first positions
-            unsigned short *perm = reinterpret_cast<unsigned short *>(hist + PLANE);   // [nrec] record ids in sorted order
-            static_assert((PLANE + kDsKeep * kDsThreads / 2) * 4 <= (int)sizeof(L.stage), "sort tables must fit the stage area");
+            unsigned short *perm = reinterpret_cast<unsigned short *>(hist + PLANE);   // [kDsKeep * kDsThreads] record ids by lane slot (0xffff: none)
+            unsigned short *cpre = perm + kDsKeep * kDsThreads;             // [PLANE] records of the point's class at points before it
+            unsigned short *part = cpre + ((PLANE + 1) & ~1);               // [NQ][32] a thread's share of its class
+            unsigned *rowmask = reinterpret_cast<unsigned *>(part + NQ * 32);   // [kDsMaxRows] classes that have a record of rank r
+            unsigned short *rowpos = reinterpret_cast<unsigned short *>(rowmask + kDsMaxRows);   // [kDsMaxRows] first lane slot of row r
+            unsigned short *ccount = rowpos + kDsMaxRows;                   // [32] records per class
+            int *deal = reinterpret_cast<int *>(ccount + 32);               // padded rows (-1: the plain sorted order), lane slots in all; [2..] the row scan's wave sums
+            static_assert(kDsThreads % 32 == 0 && (PLANE * 4 + kDsKeep * kDsThreads * 2 + ((PLANE + 1) & ~1) * 2 + NQ * 64 + kDsMaxRows * 6 + 64 + 4 * (4 + 3 * (kDsMaxRows / 64))) <= (int)sizeof(L.stage),
+                          "sort tables must fit the stage area");
             for (int i = tid; i < PLANE; i += kDsThreads) hist[i] = 0u;
+            for (int i = tid; i < kDsKeep * kDsThreads; i += kDsThreads) perm[i] = 0xffffu;
             __syncthreads();
             int slot[kDsKeep], rank[kDsKeep];
 #pragma unroll
@@ -203,19 +237,98 @@ __global__ void __launch_bounds__(kDsThreads) degrid_stream_kernel(const DegridP
                     run += cnt[e];
                 }
             }
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < kDsKeep; ++j)
-                if (slot[j] >= 0) perm[hist[slot[j]] + rank[j]] = (unsigned short)(tid + j * kDsThreads);
             int nown = 0;
             for (int w = 0; w < kDsThreads / 64; ++w) nown += L.wcnt[w];
+            __syncthreads();
+            {   // per class (start point mod 32): the records at earlier points -- thread (class, q) sums its EQ points, then adds its predecessors' sums
+                const int c = tid & 31, q = tid >> 5;
+                unsigned pc[EQ], psum = 0u;
+#pragma unroll
+                for (int e = 0; e < EQ; ++e) {
+                    const int s_ = c + 32 * (q * EQ + e);
+                    pc[e] = (q * EQ + e < NSTR && s_ < PLANE) ? (s_ + 1 < PLANE ? hist[s_ + 1] : (unsigned)nown) - hist[s_] : 0u;
+                    psum += pc[e];
+                }
+                part[q * 32 + c] = (unsigned short)psum;
+                __syncthreads();
+                unsigned base = 0u;
+                for (int qq = 0; qq < q; ++qq) base += part[qq * 32 + c];
+#pragma unroll
+                for (int e = 0; e < EQ; ++e) {
+                    const int s_ = c + 32 * (q * EQ + e);
+                    if (q * EQ + e < NSTR && s_ < PLANE) cpre[s_] = (unsigned short)base;
+                    base += pc[e];
+                }
+                if (q == NQ - 1) ccount[c] = (unsigned short)base;
+            }
+            __syncthreads();
+            {   // rows: thread = rank (the first kDsMaxRows threads, i.e. two waves)
+                unsigned mask = 0u;
+                int cmax = 0;
+#pragma unroll 8
+                for (int c = 0; c < 32; ++c) {
+                    const int cc = ccount[c];
+                    mask |= (cc > tid ? 1u : 0u) << c;
+                    cmax = max(cmax, cc);
+                }
+                const bool row = tid < kDsMaxRows;
+                const int width = row ? __popc(mask) : 0;
+                // rows at least kDsRowPad wide keep their holes (widths never grow with the rank: those rows are a prefix); the others
+                // follow without gaps: an exclusive scan of their widths -- and of ALL widths, should the holes overflow the kept passes
+                const unsigned long long padded = __ballot(width >= kDsRowPad);
+                if (row && (tid & 63) == 0) deal[2 + wave] = __popcll(padded);
+                __syncthreads();
+                int rfull = 0;
+#pragma unroll
+                for (int w = 0; w < kDsMaxRows / 64; ++w) rfull += deal[2 + w];
+                const int wa = tid >= rfull ? width : 0;
+                int va = wa, vb = width;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int ta = __shfl_up(va, o), tb = __shfl_up(vb, o);
+                    if ((tid & 63) >= o) { va += ta; vb += tb; }
+                }
+                if (row && (tid & 63) == 63) { deal[4 + 2 * wave] = va; deal[5 + 2 * wave] = vb; }
+                __syncthreads();
+                int ba = 0, bb = 0, total_a = 0;
+#pragma unroll
+                for (int w = 0; w < kDsMaxRows / 64; ++w) {
+                    if (w < wave) { ba += deal[4 + 2 * w]; bb += deal[5 + 2 * w]; }
+                    total_a += deal[4 + 2 * w];
+                }
+                const bool holes_fit = rfull * 32 + total_a <= kDsKeep * kDsThreads;
+                if (row) {
+                    rowmask[tid] = mask;
+                    rowpos[tid] = (unsigned short)(holes_fit ? rfull * 32 + ba + va - wa : bb + vb - width);
+                }
+                if (tid == 0) {
+                    // a class of more than kDsMaxRows records (few spokes, all along one line of the bank lattice): round 3's sorted order
+                    deal[0] = cmax > kDsMaxRows ? -1 : (holes_fit ? rfull : 0);
+                    deal[1] = cmax > kDsMaxRows || !holes_fit ? nown : rfull * 32 + total_a;
+#ifdef TRON_DS_SORTED_DEAL
+                    deal[0] = -1; deal[1] = nown;
+#endif
+                }
+            }
+            __syncthreads();
+            const int rfull = deal[0], nslots = deal[1];
+#pragma unroll
+            for (int j = 0; j < kDsKeep; ++j)
+                if (slot[j] >= 0) {
+                    int pos = (int)hist[slot[j]] + rank[j];                   // place in sorted order
+                    if (rfull >= 0) {
+                        const int c = slot[j] & 31, rc = (int)cpre[slot[j]] + rank[j];
+                        pos = rc < rfull ? rc * 32 + c : (int)rowpos[rc] + __popc(rowmask[rc] & ((1u << c) - 1u));
+                    }
+                    perm[pos] = (unsigned short)(tid + j * kDsThreads);
+                }
             __syncthreads();
 #pragma unroll
             for (int j = 0; j < kDsKeep; ++j) {
                 const int idx = tid + j * kDsThreads;
-                if (idx < nown) {
+                if (idx < nslots) {
                     const int rec = perm[idx];
-                    kept[j] = dg_prep<CW, kDsMaxSpokes, HALO, SX, SY>(p, kb, L, rd, rec, rec & 63, tx0, ty0, n, nr, c0);
+                    if (rec != 0xffff) kept[j] = dg_prep<CW, kDsMaxSpokes, HALO, SX, SY>(p, kb, L, rd, rec, rec & 63, tx0, ty0, n, nr, c0);
                 }
             }
             __syncthreads();                                                // the stage area goes back to the waves

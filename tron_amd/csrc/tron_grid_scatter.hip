@@ -168,7 +168,7 @@ grid_scatter_kernel(const GridParams p)
     const slds_f2p lutB = (slds_f2p)(__attribute__((address_space(3))) const void *)&L.lutB[0][0] - iB0;
     const float W = p.W, lscale = p.lut_scale, two_s = 2.0f * p.lut_scale;
     const float dcf_a = p.apply_dcf ? p.dcf_a : 0.0f, dcf_b = p.apply_dcf ? p.dcf_b : 1.0f;
-        const float rs_nro = (float)p.nro, rs_inv = 1.0f / (float)p.nxos;
+    const float rs_nro = (float)p.nro, rs_inv = 1.0f / (float)p.nxos;
     const unsigned nchan_b = (unsigned)p.nchan * (HALF ? 4u : 8u);       // bytes per sample (all channels)
     const float fx0 = (float)(x0 - kScatHalo), fy0 = (float)(y0 - kScatHalo);
 
