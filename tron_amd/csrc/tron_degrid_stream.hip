@@ -20,7 +20,10 @@
 // Measured and not kept: three kept passes instead of two; an order of the UNKEPT records other than along their spokes (any fixed
 // permutation inside a 64-record block: 3.0-3.3 cycles per read against 2.7, simulated); the long lists round the centre dealt to
 // several workgroups in equal shares, every record kept and every run 16 images (1.62 against 1.59 us: each share loads the whole
-// tile again, +29 % tile loads).  The records beyond the kept passes -- 21 % of the bench's samples, in the 32 tiles round the
+// tile again, +29 % tile loads); ONE workgroup for both coil chunks of a (tile, image) at eight coils -- chunk 0's sums of the kept records
+// waiting in registers (149 VGPRs), whole 64-byte sample records stored by four lanes each, lists / sort / preparation once for both --
+// bit-identical and 3 % SLOWER (1.58 against 1.53 us: half the workgroups, and the L2 was merging the 32-byte halves anyway).
+// The records beyond the kept passes -- 21 % of the bench's samples, in the 32 tiles round the
 // centre -- cost 0.40 of 1.62 us (a build that skips them); the drain of an image's stores behind vmcnt(0) costs nothing (a build
 // without the wait).
 //
