@@ -152,6 +152,7 @@ for ty in range(16):
                         tot[f"s{mm}_mem"] = tot.get(f"s{mm}_mem", 0) + (mx > 0).sum()
                         if mm == 4:
                             per_wave[w, b] += mx.sum()
+                            tot["flat4_it"] = tot.get("flat4_it", 0) + lens[:, c0:c0 + mm].sum(1).max()     # one loop over a lane's visits of the chunk
         tot["wg_sum"] = tot.get("wg_sum", 0) + per_wave.sum()
         tot["wg_max"] = tot.get("wg_max", 0) + 4 * per_wave.max(0).sum()
 v = tot["visits"]
@@ -161,5 +162,6 @@ for k, name in (("rad_it", "base"), ("sorted_it", "sorted"), ("flat_it", "flat")
     print(f"  radius loop {name:7s} {tot[k]:7d} wave iterations, lanes active {v / (64 * tot[k]):.3f}")
 print(f"  waves of a workgroup meet at a barrier after every batch: sum of their iterations {tot['wg_sum']:.0f}, 4 x the slowest wave's {tot['wg_max']:.0f} "
       f"-> {tot['wg_sum'] / tot['wg_max']:.3f} of the workgroup's gather time is work")
+print(f"  flat over chunks of 4 (a member switch inside the hot loop): {tot['flat4_it']:7d} wave iterations, lanes active {v / (64 * tot['flat4_it']):.3f}")
 for mm in (3, 4, 6):
     print(f"  sorted in chunks of {mm}: {tot[f's{mm}_it']:7d} wave iterations, lanes active {v / (64 * tot[f's{mm}_it']):.3f}; member visits {tot[f's{mm}_mem']}")
