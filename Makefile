@@ -26,7 +26,7 @@ $(OBJ)/%.o: $(SRC)/%.hip $(wildcard $(SRC)/*.h) $(wildcard include/*.h)
 	@mkdir -p $(OBJ)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(LIB): $(OBJ)/tron_kernels.o $(OBJ)/tron_grid_binned.o $(OBJ)/tron_grid_arc.o $(OBJ)/tron_grid_scatter.o $(OBJ)/tron_grid_centre.o $(OBJ)/tron_fft512.o $(OBJ)/tron_degrid_tile.o $(OBJ)/tron_degrid_stream.o $(OBJ)/tron_cgnr.o $(OBJ)/tron_plan.o $(OBJ)/tron_pipeline.o $(OBJ)/tron_hostio.o $(OBJ)/tron_hostmath.o $(OBJ)/rawarray.o
+$(LIB): $(OBJ)/tron_kernels.o $(OBJ)/tron_grid_binned.o $(OBJ)/tron_grid_arc.o $(OBJ)/tron_grid_scatter.o $(OBJ)/tron_grid_centre.o $(OBJ)/tron_fft512.o $(OBJ)/tron_degrid_tile.o $(OBJ)/tron_degrid_stream.o $(OBJ)/tron_cgnr.o $(OBJ)/tron_traj_dev.o $(OBJ)/tron_traj.o $(OBJ)/tron_plan.o $(OBJ)/tron_pipeline.o $(OBJ)/tron_hostio.o $(OBJ)/tron_hostmath.o $(OBJ)/rawarray.o
 	@mkdir -p tron_amd/lib
 	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) $^ -o $@ $(LDFLAGS) -Wl,--version-script=$(SRC)/exports.map
 

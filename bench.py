@@ -164,6 +164,76 @@ def forward_bench(args, rank, local_rank, world, torch, group, lib):
         print(json.dumps(result), flush=True)
 
 
+def one_coil_field(args, lib, torch, local_rank, undersamp):
+    """SURVEY 8(d) M0 names nc in {1, 8}: the driver's line is the 8-coil workload, and this is the SAME measurement at one coil --
+    same slices, spokes, fences and clock, a plan and buffers of its own -- as a field of that line, with the
+    gridding stage's roofline fraction and a spot check against the oracle."""
+    import ctypes
+    import numpy as np
+    nz = args.slices
+    cfg = lib.default_config(adjoint=1, golden_angle=1, data_undersamp=undersamp, prof_slide=NPE, device=local_rank, kb_mode=lib.KB_FAST,
+                             chunk_slices=args.chunk)
+    dims = lib.derive_dims(cfg, (1, 1, NRO, NPE * nz, 1))
+    plan = lib.Plan(cfg, dims)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(0x54524F4E + 7)
+    kspace = torch.rand(2 * NRO * NPE * nz, device="cuda", generator=g, dtype=torch.float32) * 2 - 1
+    images = torch.empty(2 * NX * NX * nz, device="cuda", dtype=torch.float32)
+    d_in, d_out = ctypes.c_void_p(kspace.data_ptr()), ctypes.c_void_p(images.data_ptr())
+    torch.cuda.synchronize()
+
+    def step():
+        plan.adjoint_device(d_out, d_in, 0, nz, combine=1)
+
+    def fence():
+        torch.cuda.synchronize()
+        plan.sync()
+    for _ in range(max(1, args.warmup)):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    value = nz * args.steps / dt
+    n_sus = max(args.steps, int(min(args.sustain, 2.0) / (dt / args.steps)) + 1) if args.sustain > 0 else 0
+    sus = None
+    if n_sus:
+        t0 = time.perf_counter()
+        for _ in range(n_sus):
+            step()
+        fence()
+        sus = nz * n_sus / (time.perf_counter() - t0)
+    plan.timing(True)
+    plan.timing_reset()
+    for _ in range(3):
+        step()
+    ms, n = plan.timing_get(lib.STAGE_GRID)
+    plan.timing(False)
+    ab = algorithmic_bytes(1)
+    grid_gbps = ab["grid"] * nz * 3 / n / (ms / n * 1e-3) / 1e9 if n else None
+    err = None
+    if not args.no_check:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from oracle import pyoracle
+        host = kspace[: 2 * NRO * NPE].cpu().numpy().view(np.complex64).reshape((1, 1, NRO, NPE, 1), order="F")
+        want, _ = pyoracle.recon(host, adjoint=1, golden=1, data_undersamp=undersamp, prof_slide=NPE)
+        got = images[: 2 * NX * NX].cpu().numpy().view(np.complex64)
+        err = float(np.linalg.norm(got - want.reshape(-1, order="F")) / np.linalg.norm(want))
+        if not err <= 1e-5:
+            raise SystemExit(f"one-coil output disagrees with the oracle: rel L2 {err:.3e}")
+    kname = plan.grid_kernel_name()
+    plan.close()
+    alg = ab["per_slice"] * value / 1e9
+    return dict(value=round(value, 1), unit="slices/s", sustained_slices_per_s=round(sus, 1) if sus else None, steps=args.steps,
+                ms_per_step=round(dt / args.steps * 1e3, 3), algorithmic_frac_of_peak=round(alg / HBM_PEAK_GBPS, 4),
+                target_40pct_slices_per_s=round(0.4 * HBM_PEAK_GBPS * 1e9 / ab["per_slice"], 0),
+                roofline=dict(kernel=kname, achieved=round(grid_gbps, 1) if grid_gbps else None, peak=HBM_PEAK_GBPS, unit="GB/s",
+                              frac=round(grid_gbps / HBM_PEAK_GBPS, 4) if grid_gbps else None, launch_ms=round(ms / n, 4) if n else None),
+                parity_rel_l2_vs_oracle=err, workload=f"{nz} slices x 1 coil, otherwise the line's own workload")
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -188,6 +258,11 @@ def parse_args(argv=None):
     ap.add_argument("--sustain", type=float, default=3.0,
                     help="seconds of back-to-back steps after the timed region for sustained_slices_per_s (0 = skip)")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--no-fresh", action="store_true", help="skip fresh_trajectory_slices_per_s (tron_plan_retarget before every step)")
+    ap.add_argument("--fresh-cycle", type=int, default=4,
+                    help="fresh trajectories: step k grids the spokes whose angle index starts at (k mod this) x slices x spokes, i.e. every "
+                         "step's tables are new; bounded because the reference multiplies the index in fp32 (src/tron.cu:509, SURVEY Q6)")
+    ap.add_argument("--no-one-coil", action="store_true", help="skip the one_coil field of the default (8-coil) line")
     return ap.parse_args(argv)
 
 
@@ -396,27 +471,54 @@ def main():
                          ratio_to_value=round(total_slices * n_sus / dt_sus / value, 4),
                          shader_clock_mhz_start=round(clock0, 0), shader_clock_mhz_end=round(clock1, 0))
 
+    # Fresh trajectories: the timed steps above reuse ONE plan's angle tables, as a NUFFT plan made once per trajectory does; a
+    # continuing golden-angle acquisition never repeats a window, and the reference's one published time (src/tron.cu:973-978,
+    # RUNME4:219) and the cpu_baseline beside `value` both include their set-up.  Here EVERY step is preceded by tron_plan_retarget: new
+    # angle index, new (cos, sin) table (host libm), new sorted lists and run tables (device, on the build stream, while the previous
+    # step is still being gridded); nothing that does not depend on the angles is redone.  Same fences, same clock as `value`.
+    fresh = None
+    if golden and not args.no_fresh:
+        cyc = max(2, args.fresh_cycle)
+        skip_of = lambda k: (zfirst + (k % cyc) * nz) * NPE
+
+        def fresh_step(k):
+            plan.retarget(skip_of(k))
+            step()
+        for k in range(max(2, args.warmup)):
+            fresh_step(k)
+        fence()
+        n_f = max(args.steps, int(1.0 / (dt / args.steps)) + 1)
+        t0 = time.perf_counter()
+        for k in range(n_f):
+            fresh_step(k + 2)
+        fence()
+        dt_f = group.max(time.perf_counter() - t0)
+        rt = plan.retarget_times()
+        fresh = dict(value=round(total_slices * n_f / dt_f, 1), steps=n_f, seconds=round(dt_f, 3), ratio_to_value=round(total_slices * n_f / dt_f / value, 4),
+                     distinct_trajectories=cyc, retarget_host_ms=round(rt["call"] * 1e3, 3), trig_table_host_ms=round(rt["trig"] * 1e3, 3),
+                     note=f"tron_plan_retarget(skip_angles) before every step, skip = (k mod {cyc}) x {nz} x {NPE}: tables of the next step built on the "
+                          "device beside the current step's gridding; bytes equal a fresh plan's (tests/test_gpu_retarget.py)")
+        if rank == 0 and not args.no_check:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from oracle import pyoracle
+            pyoracle.set_threads(max(1, (os.cpu_count() or 1) // world))
+            k_last = n_f + 1
+            host = kspace[: 2 * nc * NRO * NPE].float().cpu().numpy().view(np.complex64).reshape((nc, 1, NRO, NPE, 1), order="F")
+            want, _ = pyoracle.recon(host, adjoint=1, golden=1, data_undersamp=undersamp, prof_slide=NPE, skip_angles=skip_of(k_last))
+            got = images[: 2 * NX * NX].cpu().numpy().view(np.complex64)
+            fresh["parity_rel_l2_vs_oracle"] = float(np.linalg.norm(got - want.reshape(-1, order="F")) / np.linalg.norm(want))
+            if not fresh["parity_rel_l2_vs_oracle"] <= 1e-5:
+                raise SystemExit(f"retargeted output disagrees with the oracle: rel L2 {fresh['parity_rel_l2_vs_oracle']:.3e}")
+        plan.retarget(zfirst * NPE)              # back to the plan's own angles for what follows
+        step()
+        fence()
+
     # per-kernel durations, measured live with hipEvents on the library's own stream
     ab = algorithmic_bytes(nc, args.half)
     roofline = None
     stages = {}
     if rank == 0:
         reps = max(2, min(args.steps, 5))
-        # In the timed region gridding and FFT launches of consecutive batches overlap on two streams; a kernel's OWN
-        # duration is measured with the two lanes serialised (each kernel alone on the GPU).  Both are reported.
-        overlapped = {}
-        two_lanes = plan.two_lanes(True)
-        if two_lanes:
-            plan.timing(True)
-            plan.timing_reset()
-            for _ in range(reps):
-                step()
-            for st, name in {lib.STAGE_GRID: "grid", lib.STAGE_FFT: "fft"}.items():
-                ms, n = plan.timing_get(st)
-                if n:
-                    overlapped[name] = round(ms / n, 4)
-            plan.timing(False)
-            plan.two_lanes(False)
         plan.timing(True)
         plan.timing_reset()
         for _ in range(reps):
@@ -426,7 +528,6 @@ def main():
             if n:
                 stages[name] = (ms, n)
         plan.timing(False)
-        plan.two_lanes(True)
         tot = sum(ms for ms, _ in stages.values())
         dom = max(stages, key=lambda k: stages[k][0])
         ms, n = stages[dom]
@@ -447,13 +548,11 @@ def main():
                         frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=traffic, traffic_stale=stale, traffic_source=note,
                         bytes_per_launch=int(bytes_per_launch), units_per_launch=units_per_launch,
                         launch_ms=round(ms / n, 4), stage_share={k: round(v[0] / tot, 3) for k, v in stages.items()},
-                        two_lanes=two_lanes,
-                        launch_ms_overlapped=overlapped if two_lanes else None,
-                        frac_overlapped=(round(bytes_per_launch / (overlapped[dom] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
-                                         if two_lanes and dom in overlapped else None),
-                        measured=("kernel alone: the plan's two lanes (gridding || FFT passes of the next batch, as in the timed region) "
-                                  "serialised for this timing pass; launch_ms_overlapped = the same launches while overlapped"
-                                  if two_lanes else "kernel alone (the plan runs one lane)"))
+                        measured="hipEvents round the stage's launches on the plan's stream (one stream: every kernel runs alone)")
+
+    one_coil = None
+    if (rank == 0 and world == 1 and nc == 8 and golden and not args.half and args.kb == "fast" and NPE == 402 and not args.no_one_coil):
+        one_coil = one_coil_field(args, lib, torch, local_rank, undersamp)
 
     result = None
     if rank == 0:
@@ -483,22 +582,6 @@ def main():
         else:
             err = None
         alg_gbps = ab["per_slice"] * value / world / 1e9      # per GPU, SURVEY 8(d)'s algorithmic bytes (not measured traffic)
-        # what a plain device-to-device copy reaches on this GPU (read + write bytes): the practical HBM ceiling
-        copy_gbps = None
-        try:
-            a = torch.empty(1 << 28, device="cuda", dtype=torch.float32)
-            b = torch.empty_like(a)
-            b.copy_(a)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(5):
-                b.copy_(a)
-            e1.record()
-            torch.cuda.synchronize()
-            copy_gbps = round(5 * 2 * a.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
-            del a, b
-        except Exception:
-            copy_gbps = None
         per_gpu = f"{nz} slices/GPU/step" if args.scaling == "weak" else f"{total_slices} slices/step in total ({nz} on rank 0)"
         result = {
             "metric": "2D slices/sec gridded (512^2 grid, 512x402 golden-angle) + achieved HBM GB/s",
@@ -514,11 +597,13 @@ def main():
                        "parallelism": f"slices sharded over {world} GPU(s), one process each, no collective on the data path (gloo barrier only)",
                        **({"ranks_share_one_gpu": True} if share and ndev < world else {})},
             "algorithmic_gbps_per_gpu": round(alg_gbps, 1), "algorithmic_frac_of_peak": round(alg_gbps / HBM_PEAK_GBPS, 4),
-            "copy_ceiling_gbps": copy_gbps, "algorithmic_frac_of_copy_ceiling": round(alg_gbps / copy_gbps, 4) if copy_gbps else None,
-            "copy_ceiling_guide_gbps": 6290.0,      # MI355X_MICROARCH.md: float4 copy, 79 % of the 8 TB/s spec
+            "copy_ceiling_guide_gbps": 6290.0,      # MI355X_MICROARCH.md: float4 copy, 79 % of the 8 TB/s spec (round 5's own torch copy probe read 5.0 TB/s and is gone)
             "coil_slices_per_s": round(value * nc, 1),
             # the same step() for >= --sustain seconds right after the timed steps (value / ms_per_step above are the driver's K steps)
             "sustained_slices_per_s": sustained["value"] if sustained else None, "sustained": sustained,
+            # every step on NEW spoke angles (tron_plan_retarget inside the clock): VERDICT round 5, item 1
+            "fresh_trajectory_slices_per_s": fresh["value"] if fresh else None, "fresh_trajectory": fresh,
+            "one_coil": one_coil,
             "burn_in_attempts": json.loads(os.environ["TRON_BENCH_BURNT"]) if os.environ.get("TRON_BENCH_BURNT", "").startswith("[") else None,
             "parity_rel_l2_vs_oracle": err,
             # plan creation is outside the timed region (value = steady state of a plan made once per trajectory); the reference's one

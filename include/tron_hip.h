@@ -183,11 +183,18 @@ int tron_degridradial2d(tron_plan *plan, void *d_nudata, const void *d_udata);
 /* Waits for everything the plan has launched. */
 int tron_plan_sync(tron_plan *plan);
 
-/* Adjoint plans with at least two full batches run gridding and the FFT passes of consecutive batches on two streams
-   (the reference alternates two streams per slice, src/tron.cu:732-734).  enable = 0 serialises the two lanes -- each
-   kernel then runs alone, which is what a per-kernel duration should be measured on -- enable = 1 restores the plan's
-   default.  *had_two_lanes (may be NULL) reports whether the plan has a second lane at all. */
-int tron_plan_two_lanes(tron_plan *plan, int enable, int *had_two_lanes);
+/* A continuing acquisition on ONE plan: every later call on `plan` grids / degrids with the spoke-angle index starting at
+   `skip_angles` -- the reference's `-s` flag, i.e. the kernel argument of src/tron.cu:509, 555 (PHI * float(pe + skip)), which the
+   reference can change from call to call at no cost because it evaluates the angles per thread.  Here the angles live in tables
+   (the (cos, sin) list, the angle-sorted spoke lists, the gridding kernels' run tables); a plan holds two sets of them, and this
+   call builds the idle set for the new angles ON THE DEVICE, asynchronously, on a stream of its own beside whatever the plan has
+   queued (host: the (cos, sin) table by libm, a fraction of a millisecond on a few threads).  The next call on the plan waits for
+   that build -- not for the queued work -- and reads the new set.  Results are those of a plan created with this skip_angles,
+   bit for bit.  Nothing that does not depend on the angles (code objects, Kaiser-Bessel and deapodisation tables, tile orders,
+   work buffers) is redone.  Linear angles do not depend on skip_angles: a no-op for golden_angle = 0.
+   tron_plan_retarget_times: host seconds the last call took, of which the (cos, sin) table. */
+int tron_plan_retarget(tron_plan *plan, int skip_angles);
+int tron_plan_retarget_times(const tron_plan *plan, double seconds[2]);
 /* Names the gridding kernel(s) the plan's adjoint launches (measurement tooling); a static string. */
 const char *tron_plan_grid_kernel_name(const tron_plan *plan);
 /* Names the degridding kernel the plan's most recent forward launch ran ("" before the first one): degrid_stream_kernel

@@ -43,7 +43,14 @@
  *     nchan > 6 works instead of overflowing the stack array;
  *   - the FFT (cuFFT in the reference, tron.cu:205-220,632,645) is an unnormalised DFT
  *     evaluated in double precision and rounded once to float: any correct FFT agrees
- *     with it to fp32 rounding.
+ *     with it to fp32 rounding;
+ *   - gridradial2d visits the grid points in plain raster order.  The reference's 4x4-blocked
+ *     tid -> (X, Y) map (tron.cu:472-494: nblocky = nxos / 4, Y = zid / 4 + 4 by, X = zid % 4 + 4 bx)
+ *     is a permutation of the raster ONLY when nxos % 4 == 0 -- every BASELINE shape (512, 256).
+ *     For other sizes (18, 10, 25 ... in the test matrix) the reference never visits the columns
+ *     >= 4 floor(nxos / 4) and indexes rows >= nxos out of bounds (:494, :534): undefined
+ *     behaviour.  This file defines full raster coverage there; tests on such sizes pin
+ *     oracle-defined behaviour, not the reference's.
  */
 #include <math.h>
 #include <stddef.h>
@@ -254,10 +261,12 @@ void oracle_precompensate(cfloat *nudata, const int nchan, const int nro, const 
 
 /* ------------------------------------------------------------------ interpolators */
 
-/* tron.cu:465-536.  One "thread" per Cartesian point; the 4x4-blocked tid->(X,Y) map of
-   :488-494 only permutes which thread owns which point, so points are visited in plain
-   raster order here.  The running sum order per point (pe ascending; aligned r loop
-   then anti-aligned r loop) is the reference's. */
+/* tron.cu:465-536.  One "thread" per Cartesian point.  For nxos % 4 == 0 the 4x4-blocked
+   tid->(X,Y) map of :488-494 only permutes which thread owns which point, so points are
+   visited in plain raster order here; for other sizes the reference's map leaves columns
+   unvisited and overruns the rows, and raster coverage is this file's DEFINED replacement
+   (header, "deliberate deviations").  The running sum order per point (pe
+   ascending; aligned r loop then anti-aligned r loop) is the reference's. */
 void oracle_gridradial2d(cfloat *udata, const cfloat *nudata, const int nxos,
     const int nchan, const int nro, const int npe, const float kernwidth, const float gridos,
     const int skip_angles, const int flag_golden_angle)

@@ -14,6 +14,21 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: takes more than ~20 s (mostly CPU-oracle time); skipped unless --runslow or TRON_RUN_SLOW=1 -- every "
+                                       "SURVEY section-8 row keeps parity tests that are not slow")
+
+
+def pytest_addoption(parser):
+    parser.addoption("--runslow", action="store_true", default=False, help="also run the tests marked slow")
+
+
+def pytest_collection_modifyitems(config, items):
+    if config.getoption("--runslow") or os.environ.get("TRON_RUN_SLOW") == "1":
+        return
+    skip = pytest.mark.skip(reason="slow: run with --runslow (or TRON_RUN_SLOW=1)")
+    for item in items:
+        if item.get_closest_marker("slow"):
+            item.add_marker(skip)
 
 
 def rel_l2(a, b):

@@ -17,10 +17,10 @@ def test_the_first_gpu_process_of_this_session_ran_clean(_first_process_on_a_fre
 
 
 def test_an_injected_first_process_fault_is_reported():
-    """TRON_INJECT_COLD_FAULT=<path> (tron_plan.cpp): the first plan creation that finds <path> missing fails, later ones run.
+    """TRON_DEBUG=cold_fault=<path> (tron_plan.cpp): the first plan creation that finds <path> missing fails, later ones run.
     The burn-in then needs a second attempt -- and the verdict says so instead of passing."""
     with tempfile.TemporaryDirectory() as tmp:
-        attempts = conftest.run_burn_in(dict(TRON_INJECT_COLD_FAULT=os.path.join(tmp, "first_plan_failed")))
+        attempts = conftest.run_burn_in(dict(TRON_DEBUG="cold_fault=" + os.path.join(tmp, "first_plan_failed")))
     assert len(attempts) == 2 and attempts[0]["rc"] not in (0, None) and attempts[1]["rc"] == 0, attempts
     assert "injected cold-start fault" in attempts[0]["stderr"]
     ok, msg = conftest.cold_start_verdict(attempts)

@@ -63,7 +63,7 @@ def test_stream_kernel_equals_tile_kernel_bit_for_bit(monkeypatch, nc, nx, nimg,
         flags["data_undersamp"] = us
     got, name = _forward(imgs, nimg, **flags)
     assert name == "degrid_stream_kernel", what
-    monkeypatch.setenv("TRON_DEGRID_TILE", "1")
+    monkeypatch.setenv("TRON_DEGRID_KERNEL", "tile")
     ref, rname = _forward(imgs, nimg, **flags)
     assert rname == "degrid_tile_kernel"
     assert np.isfinite(got.view(np.float32)).all()
@@ -112,17 +112,16 @@ def _forward_in_child(imgs, nimg, env, **flags):
 
 
 def test_forward_switches_change_no_bit():
-    """The forward grid's line rotation (DegridParams::in_rot) only moves points in memory, and the forward FFT passes with the
-    LDS-DMA prefetch run the same line transform as the ones without: every switch must leave the samples bit-identical."""
+    """The forward grid's line rotation (DegridParams::in_rot) only moves points in memory, and the tile kernel
+    samples what the streaming kernel samples: every switch must leave the samples bit-identical."""
     nc, nimg = 8, 16
     imgs = [synth.image(nc, 256, seed=9700 + k) for k in range(nimg)]
     flags = dict(golden_angle=1, data_undersamp=32 / 512 + 1e-6)
     ref = _forward_in_child(imgs, nimg, {}, **flags)
     assert np.isfinite(ref).all()
-    for env in ({"TRON_GRID_ROT": "0"}, {"TRON_GRID_ROT": "4"}, {"TRON_FFT_FWD_COLS_PLAIN": "1"}, {"TRON_FFT_FWD_ROWS_PLAIN": "1"},
-                {"TRON_DEGRID_TILE": "1", "TRON_GRID_ROT": "0"}, {"TRON_DEGRID_NOSORT": "1"}, {"TRON_DEGRID_SIMPLE": "1"}):
+    for env in ({"TRON_GRID_ROT": "0"}, {"TRON_GRID_ROT": "4"}, {"TRON_DEGRID_KERNEL": "tile", "TRON_GRID_ROT": "0"}, {"TRON_DEGRID_KERNEL": "simple"}):
         got = _forward_in_child(imgs, nimg, env, **flags)
-        if "TRON_DEGRID_SIMPLE" in env:         # the thread-per-sample kernel: the exact weights' order, fast weights differ in the last bits
+        if env.get("TRON_DEGRID_KERNEL") == "simple":         # the thread-per-sample kernel: the exact weights' order, fast weights differ in the last bits
             assert rel_l2(got, ref) <= 2e-6, env
         else:
             assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), env

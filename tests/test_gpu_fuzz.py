@@ -19,6 +19,7 @@ def test_random_shapes_fast_vs_exact_vs_oracle(oracle):
     assert worst <= 1e-5
 
 
+@pytest.mark.slow      # 112 s, nearly all of it the CPU oracle's CGNR; tests/test_gpu_cgnr.py, test_gpu_round2.py keep each feature's own parity tests
 def test_random_shapes_round2_features_vs_oracle(oracle):
     """CGNR, Walsh combination, nt > 1, chunked / pinned host pipeline on random shapes, against the oracle."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

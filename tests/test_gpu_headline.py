@@ -119,11 +119,25 @@ def test_config2_linear_256_image_to_512x512_spokes_and_back(oracle, kb):
     assert rel_l2(back, back_want) <= TOL
 
 
+@pytest.mark.parametrize("kb", [lib.KB_FAST, lib.KB_EXACT])
+def test_config2_at_its_literal_wording_256_readout_402_linear_spokes_1_coil(oracle, kb):
+    """BASELINE config 2 as BASELINE.json words it: "256^2 grid, 256-pt readout x 402 linear-radial spokes, 1 coil" =
+    `tron -a -u 2 in.ra` on [1, 1, 256, 402, 1]: nro 256 -> nx 128, nxos 256, all 402 spokes in one window (402 <= 256 * 2,
+    src/tron.cu:916), linear angles (src/tron.cu:509).  (The RUNME1 / RUNME3 shape of the same config is the test above.)"""
+    data = synth.kspace(1, 256, 402, seed=synth.SEED_BASE + 26)
+    want, p = oracle.recon(data, adjoint=1, data_undersamp=2.0)
+    assert (p.nxos, p.nx, p.npe1work, p.nz) == (256, 128, 402, 1)
+    got, dims = lib.recon(data, adjoint=True, kb_mode=kb, data_undersamp=2.0)
+    assert (dims.nxos, dims.nx, dims.npe1work, dims.nz) == (256, 128, 402, 1)
+    assert got.shape == want.shape and np.isfinite(got).all()
+    assert rel_l2(got, want) <= TOL
+
+
 @pytest.mark.timeout(1800)
-def test_device_resident_256_slices_two_lanes_as_the_bench_times_them(oracle):
+def test_device_resident_256_slices_as_the_bench_times_them(oracle):
     """What bench.py times, under pytest: `tron_nufft_adj_radial2d` on 256 slices x 8 coils resident in HBM = two 128-slice
-    gridding launches with the FFT lane beside them, called twice in a row (the second call's first launches run beside the
-    first call's last FFT passes); slices 0 / 127 / 128 / 255 of the second call against the oracle.  The stream is assembled from
+    batches (gridding, then the fused FFT passes, on the plan's one stream), called twice in a row without a synchronisation
+    between the calls; slices 0 / 127 / 128 / 255 of the second call against the oracle.  The stream is assembled from
     eight 32-slice blocks (one seeded generator call each); the oracle grids a block with the global angle index of its first
     spoke (-s, src/tron.cu:509)."""
     nc, nz, npe, blk = 8, 256, 402, 32
@@ -142,7 +156,6 @@ def test_device_resident_256_slices_two_lanes_as_the_bench_times_them(oracle):
             if k in (0, 3, 4, 7):
                 kept[k] = data
         d_out = lib.DeviceBuffer(dims.out_bytes)
-        assert plan.two_lanes(True), "a 256-slice plan of 8 coils runs gridding || FFT"
         plan.adjoint_device(d_out.ptr, d_in.ptr, 0, nz, 1)
         plan.adjoint_device(d_out.ptr, d_in.ptr, 0, nz, 1)
         plan.sync()

@@ -30,9 +30,9 @@ def test_fresh_processes_launch_immediately_without_faults(tmp_path):
         if r.returncode != 0:
             # name the failing stage: same run, synchronising after every launch
             dbg = subprocess.run([TRON, "-a", "-G", "-u", "0.7852", src, dst], capture_output=True, text=True, timeout=120,
-                                 env=dict(os.environ, TRON_SYNC_EACH="1"))
+                                 env=dict(os.environ, TRON_DEBUG="sync"))
             pytest.fail(f"process {i} of {NPROC} failed (rc {r.returncode}): {r.stderr[-400:]}\n"
-                        f"TRON_SYNC_EACH=1 rerun rc {dbg.returncode}: {dbg.stderr[-400:]}")
+                        f"TRON_DEBUG=sync rerun rc {dbg.returncode}: {dbg.stderr[-400:]}")
         out = open(dst, "rb").read()
         if first is None:
             first = out

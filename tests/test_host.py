@@ -105,6 +105,30 @@ def test_trig_table_bitexact(oracle, adjoint, golden):
         assert tuple(tab[z * d.prof_slide + pe]) == (c, s)
 
 
+@pytest.mark.parametrize("skip", [0, 99_991, 1_000_003, 16_000_000, 250_000_000, -7])
+def test_trig_table_bitexact_at_large_angle_indices_and_on_many_threads(skip):
+    """The golden-angle wrap (src/tron.cu:372-378: fmodf(PHI * float(pe + skip), 2 pi)) is evaluated by an exact double-precision
+    remainder instead of glibc's bit-by-bit fmodf (tron_hostmath.cpp: exact_fmodf_pos), and tables of more than 8 192 entries are
+    filled by several threads (tron_plan_retarget's host share): every entry must still be sincosf of libm's fmodf, bit for bit --
+    also where fp32 no longer resolves the angle and for a negative index."""
+    nz, npe = 130, 402
+    cfg = lib.default_config(adjoint=1, golden_angle=1, data_undersamp=0.7852, prof_slide=npe, skip_angles=skip)
+    d = lib.derive_dims(cfg, (1, 1, 512, npe * nz, 1))
+    n = (d.nz - 1) * d.prof_slide + d.npe1work
+    assert n == nz * npe > 8192
+    tab = np.zeros((n, 2), np.float32)
+    lib.check(lib.load().tron_host_trig_table(ctypes.byref(cfg), ctypes.byref(d), tab.ctypes.data_as(ctypes.c_void_p), n))
+    idx = (np.arange(n, dtype=np.int64) + skip).astype(np.float32)
+    x = (ref_numpy.PHI * idx).astype(np.float32)
+    twopi = np.float32(2.0 * np.pi)
+    t = np.fmod(x, twopi).astype(np.float32)                  # numpy's float32 fmod = C fmodf
+    t = np.where(t < 0, (t + twopi).astype(np.float32), t)
+    for i in list(range(0, n, 53)) + [n - 1]:
+        assert np.float32(ref_numpy.modang(x[i])) == t[i]     # (numpy really is libm here)
+        s, c = ref_numpy.sincosf(t[i])
+        assert tab[i, 0] == c and tab[i, 1] == s, (skip, i)
+
+
 @pytest.mark.parametrize("nxos,W", [(64, 2.0), (48, 1.5), (33, 2.5)])
 def test_band_table_bitexact(nxos, W):
     band = np.zeros((nxos, nxos), np.uint32)

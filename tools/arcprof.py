@@ -1,11 +1,10 @@
 """Where a wave of the arc gridding kernel spends its cycles, phase by phase, and how full its loops run (kernel work tooling).
-Needs a -DTRON_ARC_PROFILE build of tron_grid_arc.hip copied over tron_amd/lib/libtronhip.so:
-    tools/build_variants.sh aprof:"-DTRON_ARC_PROFILE":tron_grid_arc.hip     (then, on the GPU box)
+Needs a -DTRON_PHASE_CLOCK build of tron_grid_arc.hip copied over tron_amd/lib/libtronhip.so:
+    tools/build_variants.sh aprof:"-DTRON_PHASE_CLOCK":tron_grid_arc.hip     (then, on the GPU box)
     cp tron_amd/lib/libtronhip_aprof.so tron_amd/lib/libtronhip.so; python tools/arcprof.py [coils] [slices]"""
 import ctypes, os, sys
 os_env_ = __import__("os").environ; os_env_.setdefault("TRON_TUNING", "1")   # the library reads TRON_* switches only under TRON_TUNING=1
 import numpy as np
-os.environ.setdefault("TRON_DUAL_STREAM", "0")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tron_amd import lib
 nc = int(sys.argv[1]) if len(sys.argv) > 1 else 8

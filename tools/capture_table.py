@@ -3,7 +3,7 @@
 import json, os, sys
 d = sys.argv[1] if len(sys.argv) > 1 else "profiles"
 pre = sys.argv[2] if len(sys.argv) > 2 else ("round5_" if d == "profiles" else "")
-ROWS = ["default", "one_lane", "nc6", "nc4", "nc2", "nc1", "half", "half_nc6", "half_nc1", "804spokes", "cfg4_share", "32slices", "exact", "linear_nc1",
+ROWS = ["default", "nc6", "nc4", "nc2", "nc1", "half", "half_nc6", "half_nc1", "804spokes", "cfg4_share", "32slices", "exact", "linear_nc1",
         "forward", "binned_kernel", "cfg4_strong_2ranks_shared_gpu"]
 print("| line | short | sustained (ratio; clock MHz) | roofline.frac | traffic / algorithmic | parity | kernel |")
 print("|---|---|---|---|---|---|---|")

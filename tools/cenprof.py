@@ -1,10 +1,9 @@
 """Where a wave of the centre gridding kernel (tron_grid_centre.hip) spends its cycles (kernel work tooling).
-Needs a -DTRON_CEN_PROFILE build copied over tron_amd/lib/libtronhip.so:
-    tools/build_variants.sh cprof:"-DTRON_CEN_PROFILE":tron_grid_centre.hip     (then, on the GPU box)
+Needs a -DTRON_PHASE_CLOCK build copied over tron_amd/lib/libtronhip.so:
+    tools/build_variants.sh cprof:"-DTRON_PHASE_CLOCK":tron_grid_centre.hip     (then, on the GPU box)
     cp tron_amd/lib/libtronhip_cprof.so tron_amd/lib/libtronhip.so; python tools/cenprof.py [coils] [slices]"""
 import ctypes, os, sys
 os.environ.setdefault("TRON_TUNING", "1")
-os.environ.setdefault("TRON_DUAL_STREAM", "0")
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tron_amd import lib

@@ -8,7 +8,7 @@ def run(tile_only, nc, nimg, kbm, W=2.0, golden=1):
     code = f'''
 import os, sys
 os.environ["TRON_TUNING"]="1"
-{"os.environ['TRON_DEGRID_TILE']='1'" if tile_only else ""}
+{"os.environ['TRON_DEGRID_KERNEL']='tile'" if tile_only else ""}
 sys.path.insert(0, "{ROOT}")
 import numpy as np
 from tron_amd import lib

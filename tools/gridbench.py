@@ -37,7 +37,7 @@ with lib.Plan(cfg, dims) as plan:
         print('sync error (ignored for timing):', str(e)[:80])
     dt = time.perf_counter() - t0
     cs = nc * nz * reps
-    line = f"nc={nc} nz={nz} kb={'fast' if kb else 'exact'} skip={os.environ.get('TRON_DEBUG_SKIP','0')}: total {dt/cs*1e6:.3f} us/coil-slice ({nz*reps/dt:.0f} slices/s)"
+    line = f"nc={nc} nz={nz} kb={'fast' if kb else 'exact'}: total {dt/cs*1e6:.3f} us/coil-slice ({nz*reps/dt:.0f} slices/s)"
     for st, name in ((lib.STAGE_GRID, "grid"), (lib.STAGE_FFT, "fft"), (lib.STAGE_POST, "post")):
         ms, n = plan.timing_get(st)
         line += f" | {name} {ms/cs*1e3:.3f}"

@@ -1,13 +1,12 @@
 """Where a gridding wave spends its cycles, phase by phase (kernel work tooling).
-Needs a -DTRON_BIN_PROFILE build of the gridding kernel copied over tron_amd/lib/libtronhip.so:
-    tools/build_variants.sh prof:"-DTRON_BIN_PROFILE"       (then, on the GPU box)
+Needs a -DTRON_PHASE_CLOCK build of the gridding kernel copied over tron_amd/lib/libtronhip.so:
+    tools/build_variants.sh prof:"-DTRON_PHASE_CLOCK"       (then, on the GPU box)
     cp tron_amd/lib/libtronhip_prof.so tron_amd/lib/libtronhip.so; python tools/gridprof.py [coils] [slices]
-Prints shader-clock cycles per wave and phase (tron_grid_binned.hip: PROF_MARK slots), TRON_DUAL_STREAM=0 so that the
+Prints shader-clock cycles per wave and phase (tron_grid_binned.hip: PROF_MARK slots); the
 gridding kernel runs alone."""
 import ctypes, os, sys
 os_env_ = __import__("os").environ; os_env_.setdefault("TRON_TUNING", "1")   # the library reads TRON_* switches only under TRON_TUNING=1
 import numpy as np
-os.environ.setdefault("TRON_DUAL_STREAM", "0")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tron_amd import lib
 nc = int(sys.argv[1]) if len(sys.argv) > 1 else 8

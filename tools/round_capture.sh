@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage (GPU box): bash tools/round_capture.sh <tag>  -- the evidence set of a round: per-workload HBM traffic captures
 # (tools/traffic.sh), bench.py lines of the default and the secondary workloads, rocprofv3 --kernel-trace --stats of the default
-# bench command (two lanes and one lane) and of the forward bench, SQ counters and the arc kernel's phase clock, the host-buffer
+# bench command and of the forward bench, SQ counters and the arc kernel's phase clock, the host-buffer
 # and CLI measurements.  Everything lands under gpurun_out/<tag>/ (+ gpurun_out/traffic/); the caller copies it to profiles/.
 export TRON_TUNING=1
 tag=${1:-round}; R=$GRAFT_REPO_ROOT; out=$R/gpurun_out/$tag; mkdir -p $out
@@ -40,15 +40,13 @@ b 32slices $NI --slices 32
 b exact $NI --kb exact
 b forward $NI --forward
 b linear_nc1 $NI --linear --coils 1
-TRON_DUAL_STREAM=0 python bench.py $NI > $out/bench_one_lane.json 2> $out/bench_one_lane.err
 TRON_GRID_KERNEL=binned python bench.py $NI > $out/bench_binned_kernel.json 2> $out/bench_binned_kernel.err
 TRON_BENCH_SHARE_GPU=1 python bench.py $NI --gpus 2 --scaling strong --spokes 804 > $out/bench_cfg4_strong_2ranks_shared_gpu.json 2> $out/bench_cfg4_strong_2ranks_shared_gpu.err
 # (no burn-in child under rocprofv3: it inherits the profiler and writes a <pid>_kernel_stats.csv of its own -- round 4's forward stats
 #  file was the child's; and the CSV kept is the one with the most dispatches, i.e. the bench process's)
 ( cd /tmp && export TMPDIR=/tmp TRON_BENCH_NO_BURN_IN=1 && rocprofv3 --kernel-trace --stats -d $out/stats --output-format csv -- python3 $R/bench.py --cpu-slices 0 --no-irt --no-check > $out/stats.log 2>&1
-  TRON_DUAL_STREAM=0 rocprofv3 --kernel-trace --stats -d $out/stats_one_lane --output-format csv -- python3 $R/bench.py --cpu-slices 0 --no-irt --no-check > $out/stats_one_lane.log 2>&1
   rocprofv3 --kernel-trace --stats -d $out/stats_forward --output-format csv -- python3 $R/bench.py --cpu-slices 0 --no-irt --no-check --forward > $out/stats_forward.log 2>&1 )
-for k in stats stats_one_lane stats_forward; do
+for k in stats stats_forward; do
   best=$(for f in $(find $out/$k -name "*kernel_stats.csv"); do echo "$(awk -F, 'NR>1{gsub(/"/,"",$2); s+=$2} END{print s+0}' $f) $f"; done | sort -n | tail -1 | cut -d' ' -f2)
   cp $best $out/${k}.csv
 done
@@ -73,7 +71,7 @@ python tools/fwdbench.py 8 64 fast > $out/fwdbench.log 2>&1
 for n in 8 6 4 2 1; do python tools/gridbench.py $n 128 fast 5 2>&1 | tail -1; done > $out/gridbench.log
 timeout 120 tools/probe/cumask_main > $out/cu_mask_probe.txt 2>&1
 TRON_GRID_KERNEL=binned python tools/gridbench.py 8 128 fast 5 2>&1 | tail -1 >> $out/gridbench.log
-TRON_DUAL_STREAM=0 bash tools/ktrace.sh $tag tools/gridbench.py 8 128 fast 3 > $out/ktrace_one_lane.log 2>&1
+bash tools/ktrace.sh $tag tools/gridbench.py 8 128 fast 3 > $out/ktrace.log 2>&1
 WARM=20 python tools/gridbench.py 8 128 fast 20 2>&1 | tail -1 > $out/gridbench_warm.log
 python tools/config1.py /tmp/c1 > $out/config1.json 2> $out/config1.err
-rm -rf $out/stats $out/stats_one_lane $out/stats_forward $out/sq $out/sq1 $out/sqf gpurun_out/$tag/sq gpurun_out/$tag/sq1 gpurun_out/$tag/sqf
+rm -rf $out/stats $out/stats_forward $out/sq $out/sq1 $out/sqf gpurun_out/$tag/sq gpurun_out/$tag/sq1 gpurun_out/$tag/sqf

@@ -1,11 +1,10 @@
 """Where a wave of the scatter gridding kernel spends its cycles, phase by phase (kernel work tooling).
-Needs a -DTRON_SCAT_PROFILE build of tron_grid_scatter.hip copied over tron_amd/lib/libtronhip.so:
-    tools/build_variants.sh sprof:"-DTRON_SCAT_PROFILE":tron_grid_scatter.hip     (then, on the GPU box)
+Needs a -DTRON_PHASE_CLOCK build of tron_grid_scatter.hip copied over tron_amd/lib/libtronhip.so:
+    tools/build_variants.sh sprof:"-DTRON_PHASE_CLOCK":tron_grid_scatter.hip     (then, on the GPU box)
     cp tron_amd/lib/libtronhip_sprof.so tron_amd/lib/libtronhip.so; python tools/scatprof.py [coils] [slices]"""
 import ctypes, os, sys
 os.environ.setdefault("TRON_TUNING", "1")
 import numpy as np
-os.environ.setdefault("TRON_DUAL_STREAM", "0")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tron_amd import lib
 nc = int(sys.argv[1]) if len(sys.argv) > 1 else 1

@@ -14,7 +14,7 @@ t0 = time.perf_counter()
 ra.write(inp, synth.kspace(6, 512, 20271, seed=synth.SEED_BASE + 3))
 print(f"wrote {inp}: {os.path.getsize(inp)} B in {time.perf_counter()-t0:.1f} s")
 for mode in ("fast", "exact"):
-    env = dict(os.environ, TRON_KB_MODE=mode)
+    env = dict(os.environ, TRON_OPTIONS=f"kb={mode}")
     for rep in range(2):
         t0 = time.perf_counter()
         r = subprocess.run([os.path.join(ROOT, "tron_amd/bin/tron"), "-v", "-u", "0.4", "-d", "21", "-a", "-G", inp, out], capture_output=True, text=True, env=env)

@@ -368,8 +368,7 @@ hipError_t launch_coil_combine(float2 *out, const float2 *coil, int nimg, int nc
     const size_t work = (size_t)nimg * nimg * nt;
     if (mode == 1) {
         if (nc > kWalshMaxCoils) return hipErrorInvalidValue;
-        static const bool old_kernel = tuning_env("TRON_WALSH_KERNEL") && strcmp(tuning_env("TRON_WALSH_KERNEL"), "pixel") == 0;   // before/after timing
-        if (!old_kernel && nc >= 2 && nc <= 8 && npatch <= 4) {
+        if (nc >= 2 && nc <= 8 && npatch <= 4) {
             switch (nc) {
                 case 2: launch_walsh_tile<2>(out, coil, nimg, nt, npatch, nslices, s); break;
                 case 3: launch_walsh_tile<3>(out, coil, nimg, nt, npatch, nslices, s); break;

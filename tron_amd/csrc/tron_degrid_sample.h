@@ -331,7 +331,7 @@ __device__ __forceinline__ void dg_sample_loop(const DegridParams &p, const KbCo
 {
     const float W = p.W;
     const int nrec = rd.nrec;
-    for (int rec = first_rec + tid; rec < nrec && TRON_DBG_LT(p, 1); rec += NT) {
+    for (int rec = first_rec + tid; rec < nrec; rec += NT) {
         if (KB == TRON_KB_FAST) {
             const DgPrep<2 * CW> P = dg_prep<CW, MAXSP, HALO, SX, SY>(p, kb, L, rd, rec, tid & 63, tx0, ty0, n, nr, c0);
             if (P.own) dg_gather_store<CPB, CW, PLANE, SX, SY, ROLLED>(p, L, tile_off, P, dst, ncb);

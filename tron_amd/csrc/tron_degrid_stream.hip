@@ -42,12 +42,8 @@ namespace tron {
 constexpr int kDsThreads = 768;     // three waves per SIMD (512 and 1024 threads measured the same within noise)
 constexpr int kDsMaxSpokes = 512;   // spokes clipped per round
 constexpr int kDsMaxBlocks = 512;   // 64-record blocks indexed by the inverse map
-#ifndef TRON_DS_SORT_LONG
-#define TRON_DS_SORT_LONG 1     // a list longer than the kept passes (the tiles round the centre): its first kDsKeep passes are dealt the same way
-#endif
-#ifndef TRON_DS_KEEP
-#define TRON_DS_KEEP 2
-#endif
+constexpr bool kDsSortLong = true;   // a list longer than the kept passes (the tiles round the centre): its first kDsKeep passes are dealt the same way
+constexpr int kDsKeepPasses = 2;
 constexpr int kDsCoils = 4;         // coils per workgroup (32-byte pieces of the coil-interleaved output lines)
 
 template <int CW>
@@ -162,14 +158,14 @@ __global__ void __launch_bounds__(kDsThreads) degrid_stream_kernel(const DegridP
     // worth is computed once and kept in registers over the run (a tile holds ~1 000 records on average, 1.3 passes of 768;
     // the counters showed VALU and LDS time adding up rather than overlapping, and two thirds of a pass's VALU
     // instructions are this preparation); later passes and the exact weights take the per-record loop.
-    constexpr int kDsKeep = TRON_DS_KEEP;
+    constexpr int kDsKeep = kDsKeepPasses;
     const bool same_records = nrounds == 1 && p.trig_img_stride == 0;
     DgPrep<2 * CW> kept[kDsKeep];
 #pragma unroll
     for (int j = 0; j < kDsKeep; ++j) kept[j].own = false;
-    if (same_records && TRON_DBG_LT(p, 2)) {
+    if (same_records) {
         rd = dg_clip_round<kDsThreads, kDsMaxSpokes, kDsMaxBlocks>(p, L, k0, 0, tid, tx0, ty0, n, nr);
-        if (KB == TRON_KB_FAST && (rd.nrec <= kDsKeep * kDsThreads || TRON_DS_SORT_LONG) && !p.debug_nosort) {
+        if (KB == TRON_KB_FAST && (rd.nrec <= kDsKeep * kDsThreads || kDsSortLong)) {
             // All records fit the kept passes: they are dealt out BY THE BANKS THEIR FOOTPRINT STARTS ON.  Every LDS read of a record
             // sits at a fixed offset from the point its footprint starts at, and a ds_read_b64 serves a wave in two groups of 32 lanes,
             // one LDS cycle per distinct address on a group's busiest pair of banks (pair = 8-byte word mod 32): a group whose lanes
@@ -183,10 +179,7 @@ __global__ void __launch_bounds__(kDsThreads) degrid_stream_kernel(const DegridP
             constexpr int EPT = (PLANE + kDsThreads - 1) / kDsThreads;      // points per thread in the scan
             constexpr int NSTR = (PLANE + 31) / 32;                         // points of one class
             constexpr int NQ = kDsThreads / 32, EQ = (NSTR + NQ - 1) / NQ;  // ... dealt to NQ threads, EQ each
-#ifndef TRON_DS_ROW_PAD
-#define TRON_DS_ROW_PAD 24
-#endif
-            constexpr int kDsRowPad = TRON_DS_ROW_PAD, kDsMaxRows = 128;     // (-DTRON_DS_ROW_PAD=33: no padded rows; -DTRON_DS_SORTED_DEAL: round 3's order)
+            constexpr int kDsRowPad = 24, kDsMaxRows = 128;     // (33: no padded rows)
             unsigned *hist = reinterpret_cast<unsigned *>(L.stage);         // [PLANE] counts, then first positions
             unsigned short *perm = reinterpret_cast<unsigned short *>(hist + PLANE);   // [kDsKeep * kDsThreads] record ids by lane slot (0xffff: none)
             unsigned short *cpre = perm + kDsKeep * kDsThreads;             // [PLANE] records of the point's class at points before it
@@ -308,9 +301,6 @@ __global__ void __launch_bounds__(kDsThreads) degrid_stream_kernel(const DegridP
                     // a class of more than kDsMaxRows records (few spokes, all along one line of the bank lattice): round 3's sorted order
                     deal[0] = cmax > kDsMaxRows ? -1 : (holes_fit ? rfull : 0);
                     deal[1] = cmax > kDsMaxRows || !holes_fit ? nown : rfull * 32 + total_a;
-#ifdef TRON_DS_SORTED_DEAL
-                    deal[0] = -1; deal[1] = nown;
-#endif
                 }
             }
             __syncthreads();
@@ -346,12 +336,12 @@ __global__ void __launch_bounds__(kDsThreads) degrid_stream_kernel(const DegridP
     const int first_rec = (same_records && KB == TRON_KB_FAST) ? kDsKeep * kDsThreads : 0;
     for (int k = k0; k < k1; ++k) {
         const int buf = (k - k0) & 1;
-        if (!same_records && TRON_DBG_LT(p, 2)) rd = dg_clip_round<kDsThreads, kDsMaxSpokes, kDsMaxBlocks>(p, L, k, 0, tid, tx0, ty0, n, nr);
+        if (!same_records) rd = dg_clip_round<kDsThreads, kDsMaxSpokes, kDsMaxBlocks>(p, L, k, 0, tid, tx0, ty0, n, nr);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this thread's pieces of image k have landed
         __syncthreads();                                        // ... everybody's; and nobody still samples the other buffer
         if (k + 1 < k1) fetch(k + 1, buf ^ 1);
         float2 *dst = p.nudata + (size_t)k * p.nro * p.npe * p.nrep;
-        if (TRON_DBG_LT(p, 1)) {
+        {
             const bool pairs = ncb == kDsCoils && (p.nrep & 1) == 0;      // whole 16-byte pieces
 #pragma unroll
             for (int j = 0; j < kDsKeep; ++j) {
@@ -363,7 +353,7 @@ __global__ void __launch_bounds__(kDsThreads) degrid_stream_kernel(const DegridP
                 }
             }
         }
-        for (int r = 0; r < nrounds && TRON_DBG_LT(p, 2); ++r) {
+        for (int r = 0; r < nrounds; ++r) {
             if (r > 0) {
                 __syncthreads();                                // the lists of the round before are no longer read
                 rd = dg_clip_round<kDsThreads, kDsMaxSpokes, kDsMaxBlocks>(p, L, k, r * kDsMaxSpokes, tid, tx0, ty0, n, nr);

@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(kDgThreads) degrid_tile_kernel(const DegridPar
     if (tid < 8) L.tile[TS * TS * CPB + tid] = make_float2(0.f, 0.f);
 
     float2 *dst = p.nudata + (size_t)k * p.nro * p.npe * p.nrep;
-    for (int round0 = 0; round0 < p.npe && TRON_DBG_LT(p, 2); round0 += kDgMaxSpokes) {
+    for (int round0 = 0; round0 < p.npe; round0 += kDgMaxSpokes) {
         const DgRound rd = dg_clip_round<kDgThreads, kDgMaxSpokes, kDgMaxBlocks>(p, L, k, round0, tid, tx0, ty0, n, nr);
         // (keeping the tile loads in flight across the first clip round was tried: the registers it pins cost more
         //  than the exposed latency, 2.78 -> 2.91 us per coil image; two records per thread side by side, to overlap one's
@@ -139,9 +139,6 @@ static hipError_t launch_degrid_tile_cpb(const DegridParams &p, int kb_mode, hip
 template <int CW>
 static hipError_t launch_degrid_tile_cw(const DegridParams &p, int kb_mode, hipStream_t s)
 {
-    static const int force = tuning_env("TRON_DEGRID_CPB") ? atoi(tuning_env("TRON_DEGRID_CPB")) : 0;   // tuning knob
-    if (force == 2) return launch_degrid_tile_cpb<2, CW>(p, kb_mode, s);
-    if (force == 1) return launch_degrid_tile_cpb<1, CW>(p, kb_mode, s);
     if (p.nrep >= 4) return launch_degrid_tile_cpb<4, CW>(p, kb_mode, s);
     if (p.nrep >= 2) return launch_degrid_tile_cpb<2, CW>(p, kb_mode, s);
     return launch_degrid_tile_cpb<1, CW>(p, kb_mode, s);

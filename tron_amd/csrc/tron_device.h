@@ -9,14 +9,6 @@
 
 namespace tron {
 
-// Timing-bisection knob (TRON_DEBUG_SKIP, tools/bisect.sh): compiled in only with -DTRON_DEBUG_KNOBS
-// (tools/build_variants.sh debug:"-DTRON_DEBUG_KNOBS"); production kernels carry no debug branches.
-#ifdef TRON_DEBUG_KNOBS
-#define TRON_DBG_LT(p, n) ((p).debug < (n))
-#else
-#define TRON_DBG_LT(p, n) true
-#endif
-
 // ------------------------------------------------------------------------- Kaiser-Bessel
 
 // src/tron.cu:304-321, op for op: the coefficient literals are doubles, so both Horner chains

@@ -236,112 +236,6 @@ __device__ __forceinline__ int crop_index(int k) { return k < kFKeep / 2 ? k + k
 // line buffers live in the part of the transposition tile the exchange regions leave unused until the end.  The
 // twiddles come from LDS so that no compiler-tracked global load (whose wait would drain the DMA, the counters being
 // in-order) sits between the copy's issue and its use.
-#if !defined(TRON_FFT_ROWS_NO_DMA) && defined(TRON_FFT_ROWS_TWO_LINES)
-// Round 5 experiment, NOT the default (measured slower, see the end of this comment): TWO lines on their way per wave, as in pass 2 since round 4.  The pass is bound by memory latency -- with one line in
-// flight a wave waits ~3.6 us for a line it transforms in ~1.8 -- so every wave copies lines j + 1 and j + 2 while it transforms line j.
-// The LDS for the second set of line buffers comes from the twiddle table (a lane's fourteen twiddles wait in registers, which also
-// takes 14 LDS reads out of every line) and from three workgroups per CU instead of four (50 KiB each).  A line's copy is up to four
-// LDS-DMA instructions, fewer where the row's 128-point pieces lie outside the sampled disc: the count is wave-uniform (a ballot per
-// piece) and the wait in front of line j names the pieces of line j + 1 that may still fly.
-// Measured (same box, interleaved, 8 coils x 128 slices): FFT stage 0.725-0.741 us per coil-slice against 0.680-0.717 with one line in flight
-// and four workgroups per CU; bench.py 68.1 k against 69.1 k slices/s.  With four lines per wave the deeper prefetch does not make up for the
-// fourth workgroup; it would take workgroups that walk the coils of their row block (more lines per wave) to pay.
-__device__ __forceinline__ void wait_vmcnt_le(const int n)      // n wave-uniform, 0..4
-{
-    switch (n) {
-    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-    }
-}
-
-__global__ void __launch_bounds__(256, 3) fft512_rows_kernel(const Fft512Params p)
-{
-    constexpr int kElems = 4 * kXch + 8 * kF > kFKeep * (kLinesPerWg + 1) ? 4 * kXch + 8 * kF : kFKeep * (kLinesPerWg + 1);
-    __shared__ float2 s_t[kElems];                         // exchange regions | two line buffers per wave, then [kept col][line], +1 pad
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const size_t img = blockIdx.y;
-    const int row0 = blockIdx.x * kLinesPerWg;
-    const float2 *src = p.in + img * (size_t)kF * kF;
-    float2 *xch = s_t + wave * kXch;
-    const unsigned lbuf = lds_addr(s_t + 4 * kXch + wave * 2 * kF);          // this wave's two line buffers: a line as it lies in memory
-    // the gridded spokes fill a disc of radius nxos/2 - 1 + W (src/tron.cu:498-502): 21 % of the square is zero and is
-    // neither copied nor read from the buffer
-    auto row_lim = [&](const int row) {
-        const int Y = row < kF / 2 ? row : row - kF;
-        return p.rzero2 > 0 ? p.rzero2 - Y * Y : 0x7fffffff;
-    };
-    auto inside = [&](const int col, const int lim) {
-        const int X = col < kF / 2 ? col : col - kF;
-        return X * X <= lim;
-    };
-    auto copy_line = [&](const int lr, const int b) -> int {   // up to 4 x (64 lanes x 16 bytes = two points per lane); returns the instructions issued
-        const int lim = row_lim(row0 + lr);
-        const float2 *line = src + (size_t)(row0 + lr) * kF;
-        int issued = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int col = k * 128 + 2 * lane;
-            const bool want = inside(col, lim) || inside(col + 1, lim);
-            if (__ballot(want) != 0ull) {
-                ++issued;
-                if (want) lds_dma16(line + col, lbuf + (unsigned)((b * kF + k * 128) * (int)sizeof(float2)));
-            }
-        }
-        return issued;
-    };
-    v2f twa[8], twb[8];
-    fft512_lane_twiddles(p.tw, lane, twa, twb);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the twiddles are in: from here on only the copies count
-    int fly[4];                                             // DMA instructions of line j (wave-uniform)
-    fly[0] = copy_line(wave * 4, 0);
-    fly[1] = copy_line(wave * 4 + 1, 1);
-    fly[2] = fly[3] = 0;
-    float2 keep[4][4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int lr = wave * 4 + j;
-        const int lim = row_lim(row0 + lr);
-        float2 v[8];
-        wait_vmcnt_le(j < 3 ? fly[j + 1] : 0);              // line j has landed (the pieces of line j + 1 may still fly)
-        const unsigned buf = lbuf + (unsigned)((j & 1) * kF * (int)sizeof(float2));
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const float2 t = lds_ld64(buf + (unsigned)((q * 64 + lane) * (int)sizeof(float2)));
-            v[q] = inside(q * 64 + lane, lim) ? t : make_float2(0.f, 0.f);
-        }
-        if (j < 2) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the buffer has been read: line j + 2 may overwrite it
-            fly[j + 2] = copy_line(lr + 2, j & 1);
-        }
-        fft512_inv_tw(v, xch, [&](const int k) { return twa[k]; }, [&](const int k) { return twb[k]; }, lane);
-        // keep k = lane + 64*j2 for j2 in {0,1,6,7}
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) keep[j][jj] = v[jj < 2 ? jj : jj + 4];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const int j2 = jj < 2 ? jj : jj + 4;
-            s_t[crop_index(lane + 64 * j2) * (kLinesPerWg + 1) + wave * 4 + j] = keep[j][jj];
-        }
-    __syncthreads();
-    // transposed store: tmp[img][col][row0 .. row0+15]  (128 contiguous bytes per column)
-    float2 *dst = p.tmp + img * (size_t)kFKeep * kF;
-    for (int e = threadIdx.x; e < kFKeep * kLinesPerWg; e += 256) {
-        const int col = e / kLinesPerWg, r = e % kLinesPerWg;
-#ifndef TRON_FFT_NO_NT
-        st_nt(&dst[(size_t)col * kF + row0 + r], s_t[col * (kLinesPerWg + 1) + r]);
-#else
-        dst[(size_t)col * kF + row0 + r] = s_t[col * (kLinesPerWg + 1) + r];
-#endif
-    }
-}
-#elif !defined(TRON_FFT_ROWS_NO_DMA)
 __global__ void __launch_bounds__(256) fft512_rows_kernel(const Fft512Params p)
 {
     __shared__ float2 s_t[kFKeep * (kLinesPerWg + 1)];     // exchange regions | line buffers, then [kept col][line], +1 pad
@@ -409,78 +303,15 @@ __global__ void __launch_bounds__(256) fft512_rows_kernel(const Fft512Params p)
     float2 *dst = p.tmp + img * (size_t)kFKeep * kF;
     for (int e = threadIdx.x; e < kFKeep * kLinesPerWg; e += 256) {
         const int col = e / kLinesPerWg, r = e % kLinesPerWg;
-#ifndef TRON_FFT_NO_NT
         st_nt(&dst[(size_t)col * kF + row0 + r], s_t[col * (kLinesPerWg + 1) + r]);
-#else
-        dst[(size_t)col * kF + row0 + r] = s_t[col * (kLinesPerWg + 1) + r];
-#endif
     }
 }
-#else
-__global__ void __launch_bounds__(256) fft512_rows_kernel(const Fft512Params p)
-{
-    // one LDS buffer: the waves' exchange regions while the lines are transformed, then the transposition tile (the kept
-    // outputs wait in registers in between): 35 KiB instead of 53, i.e. four workgroups per CU instead of three
-    __shared__ float2 s_t[kFKeep * (kLinesPerWg + 1)];     // [kept col][line], +1 pad
-    static_assert(kFKeep * (kLinesPerWg + 1) >= 4 * kXch, "exchange regions must fit the transposition tile");
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const size_t img = blockIdx.y;
-    const int row0 = blockIdx.x * kLinesPerWg;
-    const float2 *src = p.in + img * (size_t)kF * kF;
-    float2 *xch = s_t + wave * kXch;
-    float2 keep[4][4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int lr = wave * 4 + j;
-        const float2 *line = src + (size_t)(row0 + lr) * kF;
-        float2 v[8];
-        // the gridded spokes fill a disc of radius nxos/2 - 1 + W (src/tron.cu:498-502): 21 % of the square is zero
-        // (prefetching the next line here costs occupancy: measured 308 -> 380 us per 512 images)
-        const int row = row0 + lr;
-        const int Y = row < kF / 2 ? row : row - kF;
-        const int lim = p.rzero2 > 0 ? p.rzero2 - Y * Y : 0x7fffffff;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int col = q * 64 + lane;
-            const int X = col < kF / 2 ? col : col - kF;
-            v[q] = X * X <= lim ? line[col] : make_float2(0.f, 0.f);
-        }
-        fft512_inv(v, xch, p.tw, lane);
-        // keep k = lane + 64*j2 for j2 in {0,1,6,7}
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) keep[j][jj] = v[jj < 2 ? jj : jj + 4];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const int j2 = jj < 2 ? jj : jj + 4;
-            s_t[crop_index(lane + 64 * j2) * (kLinesPerWg + 1) + wave * 4 + j] = keep[j][jj];
-        }
-    __syncthreads();
-    // transposed store: tmp[img][col][row0 .. row0+15]  (128 contiguous bytes per column)
-    float2 *dst = p.tmp + img * (size_t)kFKeep * kF;
-    for (int e = threadIdx.x; e < kFKeep * kLinesPerWg; e += 256) {
-        const int col = e / kLinesPerWg, r = e % kLinesPerWg;
-#ifndef TRON_FFT_NO_NT
-        st_nt(&dst[(size_t)col * kF + row0 + r], s_t[col * (kLinesPerWg + 1) + r]);
-#else
-        dst[(size_t)col * kF + row0 + r] = s_t[col * (kLinesPerWg + 1) + r];
-#endif
-    }
-}
-#endif
 
 // grid = (256/16, nslices); block = 256.  Column FFTs + crop + deapodise + root-sum-of-squares.
 // SINGLE (one channel): the deapodised complex image passes through (src/tron.cu:265-266).  Otherwise only sum |.|^2 is
 // carried across the coils and the (positive) deapodisation factor is applied once at the end, sqrt(sum |v|^2) / w =
 // sqrt(sum |v / w|^2) up to fp32 rounding: 16 accumulators instead of 16 + 16 factors + 32 pass-through values per
 // thread took the kernel from 182 VGPRs (2 waves per SIMD) to 4 waves per SIMD.
-#ifndef TRON_FFT_COLS_WAVES
-#define TRON_FFT_COLS_WAVES 3
-#endif
-#ifndef TRON_FFT_COLS_NO_DMA
 // The next line (4 KiB, contiguous) is copied global -> LDS by LDS-DMA while the current one is transformed, as in pass 1:
 // 16 registers fewer than the register prefetch it replaces, so the kernel fits four waves per SIMD.
 // LPW = columns per wave (4 LPW per workgroup).  A 64-slice launch has 16 x 64 = 1 024 workgroups of 16 columns = exactly
@@ -529,11 +360,7 @@ __global__ void __launch_bounds__(256, 3) fft512_cols_post_kernel(const Fft512Pa
         const unsigned dst = lbuf + (unsigned)((i & 1) * kF * (int)sizeof(float2));
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-#ifndef TRON_FFT_NO_NT
             lds_dma16_nt(line + k * 128 + 2 * lane, dst + (unsigned)(k * 128 * sizeof(float2)));
-#else
-            lds_dma16(line + k * 128 + 2 * lane, dst + (unsigned)(k * 128 * sizeof(float2)));
-#endif
         }
     };
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the twiddles are in: from here on only the copies count
@@ -603,81 +430,6 @@ __global__ void __launch_bounds__(256, 3) fft512_cols_post_kernel(const Fft512Pa
         dst[(size_t)row * kFKeep + col0 + cc] = s_t[row * (kCols + 1) + cc];
     }
 }
-#else
-template <bool SINGLE, int LPW_UNUSED>
-__global__ void __launch_bounds__(256, TRON_FFT_COLS_WAVES) fft512_cols_post_kernel(const Fft512Params p)
-{
-    __shared__ float2 s_t[kFKeep * (kLinesPerWg + 1)];     // [kept row][col in block]; the exchange regions until then
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int z = blockIdx.y;
-    const int col0 = blockIdx.x * kLinesPerWg;
-    float2 *xch = s_t + wave * kXch;
-    float val[4][4];
-    float2 single[SINGLE ? 4 : 1][4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            val[j][jj] = 0.f;
-            if (SINGLE) single[j][jj] = make_float2(0.f, 0.f);
-        }
-    // software pipeline over the nchan x 4 lines of this wave: line i+1 is in flight while line i is transformed
-    const float2 *base = p.in + (size_t)z * p.nchan * (size_t)kFKeep * kF + (size_t)(col0 + wave * 4) * kF;
-    float2 nxt[8];
-    // the intermediate is written once by pass 1 and read once here: streaming (non-temporal) accesses on both sides took
-    // the two passes from 1.160 to 1.104 us per coil-slice (same-box A/B; the loads 2.5 %, the stores 2.5 %);
-    // non-temporal loads of the gridded data in pass 1 gained nothing
-#ifndef TRON_FFT_NO_NT
-#define TRON_COLS_LD(ptr) ld_nt(ptr)
-#else
-#define TRON_COLS_LD(ptr) (*(ptr))
-#endif
-#pragma unroll
-    for (int q = 0; q < 8; ++q) nxt[q] = TRON_COLS_LD(&base[q * 64 + lane]);
-    for (int c = 0; c < p.nchan; ++c) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float2 v[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = nxt[q];
-            {
-                const int jn = (j + 1) & 3, cn = c + (j == 3 ? 1 : 0);
-                if (cn < p.nchan) {
-                    const float2 *line = base + (size_t)cn * kFKeep * kF + (size_t)jn * kF;
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) nxt[q] = TRON_COLS_LD(&line[q * 64 + lane]);
-                }
-            }
-            fft512_inv(v, xch, p.tw, lane);
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                const int j2 = jj < 2 ? jj : jj + 4;
-                const float2 u = v[j2];
-                if (SINGLE) single[j][jj] = u;
-                else val[j][jj] += u.x * u.x + u.y * u.y;                     // src/tron.cu:262 (the factor 1/w^2 is applied below)
-            }
-        }
-    }
-    __syncthreads();                                       // every wave is done with its exchange region
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const int j2 = jj < 2 ? jj : jj + 4;
-            const int rowc = crop_index(lane + 64 * j2);
-            const float inv = p.inv_deapod[rowc * kFKeep + col0 + wave * 4 + j];   // src/tron.cu:398-400
-            const float2 o = SINGLE ? make_float2(single[j][jj].x * inv, single[j][jj].y * inv)     // src/tron.cu:259-266
-                                    : make_float2(sqrtf(val[j][jj]) * inv, 0.f);
-            s_t[rowc * (kLinesPerWg + 1) + wave * 4 + j] = o;
-        }
-    __syncthreads();
-    float2 *dst = p.out + (size_t)z * kFKeep * kFKeep;
-    for (int e = threadIdx.x; e < kFKeep * kLinesPerWg; e += 256) {
-        const int row = e / kLinesPerWg, cc = e % kLinesPerWg;
-        dst[(size_t)row * kFKeep + col0 + cc] = s_t[row * (kLinesPerWg + 1) + cc];
-    }
-}
-#endif
 
 hipError_t launch_fft512_adjoint(const float2 *grid, float2 *tmp, float2 *out, const float2 *tw, const float *inv_deapod, int rzero,
                                  int nchan, int nslices, hipStream_t s)
@@ -690,15 +442,10 @@ hipError_t launch_fft512_adjoint(const float2 *grid, float2 *tmp, float2 *out, c
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     p.in = tmp;
-#ifndef TRON_FFT_COLS_NO_DMA
     // 8 columns per workgroup (4 from launches of fewer than 32 slices on, so that the chip is still full): three workgroups per CU hold
     // 768 at a time, and 16 columns each made a 128-slice launch 2.67 rounds of them (221 us; 8 columns: 196, 4 columns: 224)
     int lpw = nslices >= 32 ? 2 : 1;
     if (nchan == 1) lpw = nslices >= 64 ? 4 : lpw;          // one channel: a wave's lines are its columns only, 16 per workgroup amortise its set-up
-    if (const char *e = tuning_env("TRON_FFT_LPW")) lpw = atoi(e) == 4 ? 4 : (atoi(e) == 2 ? 2 : 1);   // tuning knob
-#else
-    const int lpw = 4;
-#endif
     const dim3 grid_c(kFKeep / (4 * lpw), nslices);
     if (nchan == 1) {
         if (lpw == 4) hipLaunchKernelGGL((fft512_cols_post_kernel<true, 4>), grid_c, dim3(256), 0, s, p);
@@ -723,9 +470,6 @@ int fft512_coils_partials(int nslices)
 hipError_t launch_fft512_adjoint_coils(const float2 *grid, float2 *tmp, float2 *out, const float2 *tw, const float *inv_deapod, int rzero,
                                        int nchan, int nslices, float scale, double *partial, hipStream_t s)
 {
-#ifdef TRON_FFT_COLS_NO_DMA
-    return hipErrorNotSupported;
-#else
     Fft512Params p;
     p.rzero2 = rzero > 0 ? rzero * rzero : 0;
     p.in = grid; p.tmp = tmp; p.out = out; p.tw = tw; p.inv_deapod = inv_deapod; p.nchan = nchan; p.nslices = nslices;
@@ -740,7 +484,6 @@ hipError_t launch_fft512_adjoint_coils(const float2 *grid, float2 *tmp, float2 *
     else if (lpw == 2) hipLaunchKernelGGL((fft512_cols_post_kernel<true, 2, true>), grid_c, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((fft512_cols_post_kernel<true, 1, true>), grid_c, dim3(256), 0, s, p);
     return hipGetLastError();
-#endif
 }
 
 // ------------------------------------------------------------------------------------ forward head
@@ -878,60 +621,6 @@ __global__ void __launch_bounds__(256) fft512_fwd_rows_lds_kernel(const Fft512Fw
     }
 }
 
-// grid = (512/16, nimg*nchan); block = 256.  Column k2 of the row-transformed block, written as one contiguous
-// line: out is the TRANSPOSE of the FFT-native grid, out[k2][k1] (the degridding kernel swaps its indices instead).
-__global__ void __launch_bounds__(256) fft512_fwd_cols_kernel(const Fft512FwdParams p)
-{
-    __shared__ float2 s_t[kFKeep * (kLinesPerWg + 1)];          // [row][col in block]; reused as the exchange regions
-    static_assert(kFKeep * (kLinesPerWg + 1) >= 4 * kXch, "exchange regions must fit the transposition buffer");
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int ci = blockIdx.y;
-    const int col0 = blockIdx.x * kLinesPerWg;
-    const float2 *src = p.tmp + (size_t)ci * kFKeep * kF;
-    float2 *dst = p.out + (size_t)ci * kF * kF;
-    constexpr int NLD = kFKeep * kLinesPerWg / 256;
-    float2 ld[NLD];
-#pragma unroll
-    for (int it = 0; it < NLD; ++it) {                          // all 128-byte segment loads in flight together
-        const int e = threadIdx.x + it * 256;
-        ld[it] = src[(size_t)(e / kLinesPerWg) * kF + col0 + (e % kLinesPerWg)];
-    }
-#pragma unroll
-    for (int it = 0; it < NLD; ++it) {
-        const int e = threadIdx.x + it * 256;
-        s_t[(e / kLinesPerWg) * (kLinesPerWg + 1) + (e % kLinesPerWg)] = ld[it];
-    }
-    __syncthreads();
-    // FFT-input row sr = 64q + lane holds padded row (sr + 256) % 512 = 128 + r:  q = 0,1 -> r = 128 + sr; q = 6,7 -> r = sr - 384
-    float2 in[4][4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int cc = wave * 4 + j;
-        in[j][0] = s_t[(128 + lane) * (kLinesPerWg + 1) + cc];
-        in[j][1] = s_t[(192 + lane) * (kLinesPerWg + 1) + cc];
-        in[j][2] = s_t[(lane) * (kLinesPerWg + 1) + cc];
-        in[j][3] = s_t[(64 + lane) * (kLinesPerWg + 1) + cc];
-    }
-    __syncthreads();
-    float2 *xch = s_t + wave * kXch;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        float2 v[8];
-        v[0] = cconj(in[j][0]); v[1] = cconj(in[j][1]); v[6] = cconj(in[j][2]); v[7] = cconj(in[j][3]);
-        v[2] = v[3] = v[4] = v[5] = make_float2(0.f, 0.f);
-        fft512_inv(v, xch, p.tw, lane);
-        const int k2 = col0 + wave * 4 + j;
-        float2 *line = dst + (size_t)k2 * kF;
-        const int yc = k2 < kF / 2 ? k2 : k2 - kF;              // FFT-native index -> centred coordinate
-#pragma unroll
-        for (int j2 = 0; j2 < 8; ++j2) {
-            const int k1 = lane + 64 * j2;
-            const int xc = k1 < kF / 2 ? k1 : k1 - kF;
-            if (p.rzero2 <= 0 || xc * xc + yc * yc <= p.rzero2) line[(k1 + p.rot) & (kF - 1)] = cconj(v[j2]);
-        }
-    }
-}
-
 // Pass 1 the same way (see fft512_fwd_cols_dma_kernel below for the scheme): one workgroup of 1 024 threads walks
 // kFwdRowSteps steps of `rows` consecutive image rows with all their coils -- a contiguous piece of the coil-interleaved
 // image, copied as it lies -- and the 1/w factors of those rows; wave = line (row, coil).  grid = (256 / (rows * steps), nimg).
@@ -994,9 +683,10 @@ __global__ void __launch_bounds__(kFwdRowThreads) fft512_fwd_rows_dma_kernel(con
     }
 }
 
-// Pass 2 with the next block on its way while the current one is transformed.  fft512_fwd_cols_kernel loads a 256 x 16
-// block, waits, transforms and stores, four workgroups per CU overlapping by chance: 3.5 TB/s of its own traffic, where the
-// adjoint passes reach 4.8 with their LDS-DMA prefetch.  Here one workgroup of 1 024 threads (16 waves = the 16 columns
+// Pass 2: column k2 of the row-transformed block, written as one contiguous line -- out is the TRANSPOSE of the FFT-native grid,
+// out[k2][k1] (the degridding kernel swaps its indices instead) -- with the next block on its way while the current one is
+// transformed.  (Until round 6 a plain form stood beside it that loaded a 256 x 16 block, waited, transformed and stored, four
+// workgroups per CU overlapping by chance: 3.5 TB/s of its own traffic, where this one reaches 4.4.)  One workgroup of 1 024 threads (16 waves = the 16 columns
 // of a block, four waves per SIMD as there) owns the CU and walks kFwdColBlocks consecutive column blocks of one coil
 // image: block b + 1 is copied global -> LDS (global_load_lds_dwordx4: no registers) into the second of two 32 KiB
 // buffers while block b is transformed.  A buffer holds the block as it lies in memory, [row][16 columns], the 16-byte
@@ -1005,10 +695,7 @@ __global__ void __launch_bounds__(kFwdRowThreads) fft512_fwd_rows_dma_kernel(con
 // land, and the stores are never waited for.  Twiddles come from LDS (a compiler-tracked global load between the
 // copy's issue and its use would make the compiler's s_waitcnt drain the copy).
 constexpr int kFwdColThreads = 1024;
-#ifndef TRON_FWD_COL_BLOCKS
-#define TRON_FWD_COL_BLOCKS 8
-#endif
-constexpr int kFwdColBlocks = TRON_FWD_COL_BLOCKS;   // column blocks per workgroup
+constexpr int kFwdColBlocks = 8;                   // column blocks per workgroup
 constexpr int kFwdColBuf = kFKeep * kLinesPerWg;   // float2 per buffer
 constexpr size_t kFwdColLds = (2 * kFwdColBuf + (kFwdColThreads / 64) * kXch + kF) * sizeof(float2);
 
@@ -1074,8 +761,7 @@ hipError_t launch_fft512_forward(const float2 *img, float2 *tmp, float2 *out, co
         int rows = 16 / nchan;                                  // about 16 lines per workgroup
         if (rows < 1) rows = 1;
         while (kFKeep % rows) --rows;
-        static const bool rows_plain = tuning_env("TRON_FFT_FWD_ROWS_PLAIN") != nullptr;   // tuning knob: the pass without the LDS-DMA prefetch
-        if (!rows_plain && kFKeep % (rows * kFwdRowSteps) == 0) {
+        if (kFKeep % (rows * kFwdRowSteps) == 0) {
             const size_t lds = ((kFwdRowThreads / 64) * kXch + kF + 2 * (size_t)rows * kFKeep * nchan) * sizeof(float2)
                                + 2 * (size_t)rows * kFKeep * sizeof(float);             // <= 146 KiB
             const hipError_t once = allow_dynamic_lds(reinterpret_cast<const void *>(fft512_fwd_rows_dma_kernel), 160 * 1024);
@@ -1090,10 +776,7 @@ hipError_t launch_fft512_forward(const float2 *img, float2 *tmp, float2 *out, co
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    static const bool cols_plain = tuning_env("TRON_FFT_FWD_COLS_PLAIN") != nullptr;     // tuning knob: the pass without the LDS-DMA prefetch
-    if (cols_plain) {
-        hipLaunchKernelGGL(fft512_fwd_cols_kernel, dim3(kF / kLinesPerWg, nimg * nchan), dim3(256), 0, s, p);
-    } else {
+    {
         const hipError_t once = allow_dynamic_lds(reinterpret_cast<const void *>(fft512_fwd_cols_dma_kernel), (int)kFwdColLds);
         if (once != hipSuccess) return once;
         hipLaunchKernelGGL(fft512_fwd_cols_dma_kernel, dim3(kF / kLinesPerWg / kFwdColBlocks, nimg * nchan), dim3(kFwdColThreads), kFwdColLds, s, p);

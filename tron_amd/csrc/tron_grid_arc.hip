@@ -53,37 +53,18 @@ constexpr int kArcSeg = 64;            // longest spoke segment through tile + h
 constexpr float kPi = 3.14159265358979f;
 
 // one and two coils: five workgroups per CU (83 / 94 VGPRs) beat four with larger batches by 3-4 % / 1 % (same-box A/B)
-#ifndef TRON_ARC_NREC1
-#define TRON_ARC_NREC1 1776
-#define TRON_ARC_WAVES1 5
-#endif
-#ifndef TRON_ARC_NREC2
-#define TRON_ARC_NREC2 888
-#define TRON_ARC_WAVES2 5
-#endif
+constexpr int kArcNrec1 = 1776, kArcWaves1 = 5, kArcNrec2 = 888, kArcWaves2 = 5;
 template <int CPB>
 struct ArcCfg {
     // sample records per batch.  One buffer: same-box A/B at 8 coils, gridding us per coil-slice: two buffers of 304 records
     // (batch b + 1 copied while batch b is gathered) 1.69-1.70, of 256 1.72-1.75; ONE buffer of 608 1.58-1.59 -- half the
     // batches means twice the comb members per thread and batch, and the lanes of a wave run far more evenly.
     // Three workgroups per CU at 6 and 8 coils (the accumulators allow 3 waves per SIMD anyway), four below.
-#ifdef TRON_ARC_NREC
-    static constexpr int NREC = TRON_ARC_NREC;
-#else
     // LDS is handed out in units of 1280 bytes on gfx950 (160 KiB / 128): WAVES workgroups per CU need ArcLds <= 42 / 32 / 25 units
     // for 3 / 4 / 5 (a first build of this table at 54 144 bytes ran TWO workgroups per CU, not three, and hid a 25 % saving)
-    static constexpr int NREC = CPB >= 8 ? 560 : (CPB >= 6 ? 744 : (CPB >= 4 ? 720 : (CPB >= 2 ? TRON_ARC_NREC2 : TRON_ARC_NREC1)));
-#endif
-#ifdef TRON_ARC_WAVES
-    static constexpr int WAVES = TRON_ARC_WAVES;               // (experiments: fewer, larger workgroups per CU beside an FFT workgroup)
-#else
-    static constexpr int WAVES = CPB >= 6 ? 3 : (CPB >= 4 ? 4 : (CPB >= 2 ? TRON_ARC_WAVES2 : TRON_ARC_WAVES1));
-#endif
-#ifdef TRON_ARC_DOUBLE_BUFFER
-    static constexpr int NBUF = 2;
-#else
+    static constexpr int NREC = CPB >= 8 ? 560 : (CPB >= 6 ? 744 : (CPB >= 4 ? 720 : (CPB >= 2 ? kArcNrec2 : kArcNrec1)));
+    static constexpr int WAVES = CPB >= 6 ? 3 : (CPB >= 4 ? 4 : (CPB >= 2 ? kArcWaves2 : kArcWaves1));
     static constexpr int NBUF = 1;
-#endif
 };
 
 // samples in LDS: [coil pair][record] float4 for even coil counts, [re | im][record] float for one coil
@@ -114,9 +95,9 @@ int grid_arc_nrec(int nchan, int half_in)  // records per batch for a plan of nc
     return nchan >= 3 ? ArcCfg<4>::NREC : (nchan >= 2 ? ArcCfg<2>::NREC : ArcCfg<1>::NREC);
 }
 
-// Phase clock of tools/arcprof.py (-DTRON_ARC_PROFILE builds only): shader-clock cycles per wave and phase plus loop
+// Phase clock of tools/arcprof.py (-DTRON_PHASE_CLOCK builds only): shader-clock cycles per wave and phase plus loop
 // counters, summed over all waves of all launches since the last read; production builds carry none of it.
-#ifdef TRON_ARC_PROFILE
+#ifdef TRON_PHASE_CLOCK
 constexpr int kArcProfSlots = 16, kArcProfCopies = 4096;
 __device__ unsigned long long g_arc_prof[kArcProfCopies * kArcProfSlots];
 #define APROF_DECL unsigned prof_acc[kArcProfSlots] = {}; unsigned long long prof_t = __builtin_readcyclecounter(); const unsigned long long prof_c0 = prof_t, prof_r0 = __builtin_amdgcn_s_memrealtime()
@@ -704,14 +685,11 @@ grid_arc_kernel(const GridParams p)
                 mlo = jlo <= b ? 0 : (int)(((float)(jlo - b + K - 1) + 0.5f) * rcpK);
                 mhi = (int)(((float)(jhi - b) + 0.5f) * rcpK);
             }
-#ifdef TRON_ARC_SKIP_OUTER
-            mhi = -1;
-#endif
             // member -> descriptor: radii << 28 | first record << 17 | run entry << 8 | first radius - bandlo (0: no visit)
             auto clip = [&](const int m) -> unsigned {
                 unsigned dsc = 0u;
                 if (m <= mhi) {
-#ifdef TRON_ARC_PROFILE
+#ifdef TRON_PHASE_CLOCK
                     { const unsigned long long bm_ = __ballot(1); if (lane == __builtin_ctzll(bm_)) { APROF_COUNT(12, 1); APROF_COUNT(13, __popcll(bm_)); } }
 #endif
                     const int i = b + K * m;
@@ -771,9 +749,7 @@ grid_arc_kernel(const GridParams p)
                 lds_barrier();
             }
             APROF_MARK(5);
-#ifndef TRON_ARC_SKIP_DMA
             if (C::NBUF == 2 && b + 1 < K) issue(b + 1);
-#endif
             APROF_MARK(2);
             const unsigned buf = dbase + (unsigned)(b & (C::NBUF - 1)) * kBufBytes;
 
@@ -786,14 +762,9 @@ grid_arc_kernel(const GridParams p)
             // would reach 0.69 but pays a member switch inside the hot loop (measured in round 3: slower).
             // (bottom-tested: hipcc keeps two copies of the accumulators across a top-tested loop with a wave-uniform exit)
             if (any_member) do {
-#ifdef TRON_ARC_SKIP_INNER
-                acc[0][0].x += (float)(desc[0] + desc[1] + desc[2] + desc[3]); desc[0] = desc[1] = desc[2] = desc[3] = 0u;
-#endif
-#ifndef TRON_ARC_NO_SORT
 #define TRON_ARC_CSWAP(a, b) { const unsigned hi_ = max(desc[a], desc[b]), lo_ = min(desc[a], desc[b]); desc[a] = hi_; desc[b] = lo_; }
                 TRON_ARC_CSWAP(0, 1) TRON_ARC_CSWAP(2, 3) TRON_ARC_CSWAP(0, 2) TRON_ARC_CSWAP(1, 3) TRON_ARC_CSWAP(1, 2)
 #undef TRON_ARC_CSWAP
-#endif
 #pragma unroll 1
                 for (int k = 0; k < 4; ++k) {                                                 // (one copy of the radius loop; k is wave-uniform)
                     const unsigned dk = k == 0 ? desc[0] : (k == 1 ? desc[1] : (k == 2 ? desc[2] : desc[3]));
@@ -806,7 +777,7 @@ grid_arc_kernel(const GridParams p)
                         v2f ufv = {uf0, uf0};
                         const v2f csv = {cs.x, cs.y};
                         do {
-#ifdef TRON_ARC_PROFILE
+#ifdef TRON_PHASE_CLOCK
                             { const unsigned long long bm_ = __ballot(1); if (lane == __builtin_ctzll(bm_)) { APROF_COUNT(14, 1); APROF_COUNT(15, __popcll(bm_)); } }
 #endif
                             // (kx, ky) = u (cos, sin) and the distances to the block's first column / row, op for op src/tron.cu:514-516;
@@ -900,7 +871,7 @@ grid_arc_kernel(const GridParams p)
     APROF_FLUSH;
 }
 
-#ifdef TRON_ARC_PROFILE
+#ifdef TRON_PHASE_CLOCK
 extern "C" __attribute__((visibility("default"))) int tron_debug_arc_profile(unsigned long long *out, int n)   // reads and clears the phase clock
 {
     static unsigned long long h[kArcProfCopies * kArcProfSlots];

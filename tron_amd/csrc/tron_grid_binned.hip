@@ -35,10 +35,7 @@ namespace tron {
 
 constexpr int kBinTile = 32;
 constexpr int kBinThreads = 256;
-#ifndef TRON_BIN_MAXSPOKES
-#define TRON_BIN_MAXSPOKES 512
-#endif
-constexpr int kBinMaxSpokes = TRON_BIN_MAXSPOKES;   // accepted spokes kept per clip round
+constexpr int kBinMaxSpokes = 512;   // accepted spokes kept per clip round
 
 template <int CPB, int CW>
 struct BinCfg {
@@ -53,11 +50,7 @@ struct BinCfg {
     // beats larger batches (measured on one box, gridding us per coil-slice, 36 KiB of records -> this:
     // 4 coils 3.51 -> 3.13, 2 coils 5.96 -> 5.45, 1 coil 11.1 -> 9.9; 8 coils at 24/28 KiB: 2.28 -> 2.45)
     static constexpr int REC_BYTES = 2 * NWP * 4 + CPB * 8 + 8 + 4 + 1;
-#ifdef TRON_BIN_REC_KB
-    static constexpr int REC_KB = TRON_BIN_REC_KB;
-#else
     static constexpr int REC_KB = CPB >= 8 ? 36 : (CPB >= 6 ? 30 : (CPB >= 2 ? 24 : 28));   // 6 coils: 256 records too
-#endif
     static constexpr int NREC_RAW = (REC_KB * 1024) / REC_BYTES;
     static constexpr int NREC = NREC_RAW >= 512 ? 512 : (NREC_RAW / 64) * 64;
     static constexpr int SLOT = 64;                          // longest spoke segment through tile + halo
@@ -95,9 +88,9 @@ struct BinLds {
 //                          __syncthreads() there would wait for them.
 enum { kInRegs32 = 0, kInRegs16 = 1, kInLdsDma = 2 };
 
-// Phase clock of tools/gridprof.py (-DTRON_BIN_PROFILE builds only): shader-clock cycles per wave and phase, summed
+// Phase clock of tools/gridprof.py (-DTRON_PHASE_CLOCK builds only): shader-clock cycles per wave and phase, summed
 // over all waves of all launches since the last read; production builds carry none of it.
-#ifdef TRON_BIN_PROFILE
+#ifdef TRON_PHASE_CLOCK
 constexpr int kProfSlots = 16, kProfCopies = 4096;               // copies: same-address atomics would dominate the kernel
 __device__ unsigned long long g_bin_prof[kProfCopies * kProfSlots];
 #define PROF_DECL unsigned prof_acc[kProfSlots] = {}; unsigned long long prof_t = __builtin_readcyclecounter()
@@ -109,11 +102,8 @@ __device__ unsigned long long g_bin_prof[kProfCopies * kProfSlots];
 #define PROF_FLUSH
 #endif
 
-#ifndef TRON_BIN_WAVES
-#define TRON_BIN_WAVES 3
-#endif
 template <int CPB, int CW, int IN>
-__global__ void __launch_bounds__(kBinThreads, TRON_BIN_WAVES)
+__global__ void __launch_bounds__(kBinThreads, 3)
 grid_binned_kernel(const GridParams p)
 {
     constexpr bool HALF = IN == kInRegs16;
@@ -201,7 +191,7 @@ grid_binned_kernel(const GridParams p)
     const int cx0 = x0 - CW, cy0 = y0 - CW;                     // base cell (0,0) of the histogram
 
     PROF_DECL;
-    for (int round0 = pe_lo; round0 < pe_hi && TRON_DBG_LT(p, 4); round0 += kBinMaxSpokes) {
+    for (int round0 = pe_lo; round0 < pe_hi; round0 += kBinMaxSpokes) {
         // ---- clip: one thread per spoke (kBinMaxSpokes / 256 spokes each), accepted spokes compacted in acquisition
         //      order together with the exclusive scan of their segment lengths: one exchange of per-wave totals ------
         constexpr int NCH = kBinMaxSpokes / kBinThreads;
@@ -379,9 +369,9 @@ grid_binned_kernel(const GridParams p)
 
         int sp0 = 0, sp1 = 0;
         PROF_MARK(0);                                           // setup + clip + segment scan
-        if (nacc > 0 && TRON_DBG_LT(p, 3)) sp1 = prefetch(0, 0);
+        if (nacc > 0) sp1 = prefetch(0, 0);
         PROF_MARK(1);                                           // first prefetch
-        while (sp0 < nacc && TRON_DBG_LT(p, 3)) {
+        while (sp0 < nacc) {
             const int nrec = pf_cnt;
 
             float pf_kx[RPT], pf_ky[RPT];
@@ -397,7 +387,7 @@ grid_binned_kernel(const GridParams p)
 #pragma unroll
                 for (int j = 0; j < RPT; ++j) {
                     const int rec = tid + j * kBinThreads;
-                    if (rec < nrec && TRON_DBG_LT(p, 2)) {
+                    if (rec < nrec) {
                         const int r = pf_r[j];
                         const int ro = (p.nro == n ? r : (r * p.nro) / n) + p.nro / 2;   // src/tron.cu:517,519 (truncating division)
                         const float2 *src = reinterpret_cast<const float2 *>(in_bytes) + ((size_t)p.nro * pf_pe[j] + ro) * p.nchan + c0;
@@ -417,7 +407,7 @@ grid_binned_kernel(const GridParams p)
 #pragma unroll
             for (int j = 0; j < RPT; ++j) {
                 const int rec = tid + j * kBinThreads;
-                if (rec >= nrec || !TRON_DBG_LT(p, 2)) continue;
+                if (rec >= nrec) continue;
                 const int r = pf_r[j];
                 const float kx = pf_kx[j], ky = pf_ky[j];
                 const int fx = (int)floorf(kx), fy = (int)floorf(ky);
@@ -548,7 +538,7 @@ grid_binned_kernel(const GridParams p)
 
             // ---- D. apply: each thread walks the 2CW+1 cell rows its 2x2 points can see as ONE loop
             //         (row ranges concatenated), so a wave runs max-over-lanes(total), not sum of row maxima
-            if (TRON_DBG_LT(p, 1)) {
+            {
                 constexpr int NR = 2 * CW + 1;
                 int delta[NR], cum[NR + 1];
                 cum[0] = 0;
@@ -734,15 +724,12 @@ static hipError_t launch_binned_cpb(const GridParams &p, int half_in, hipStream_
     const int entries = p.tile_entries > 0 ? p.tile_entries : q.ntiles;
     dim3 grid((unsigned)((size_t)entries * q.nslices), (unsigned)chunks);
     size_t lds = sizeof(BinLds<CPB, CW>);
-    if (p.lds_pad > 0 && (size_t)p.lds_pad > lds && p.lds_pad <= 64 * 1024) lds = (size_t)p.lds_pad;   // fewer workgroups per CU (two-lane pipeline)
     // sample path: complex-half and odd coil counts / slice groups / unaligned streams go through registers; fp32 with
     // even coil counts (16-byte coil pairs) is copied global -> LDS directly
     int in_mode = half_in ? kInRegs16 : kInRegs32;
-#ifndef TRON_BIN_NO_LDS_DMA
     if (!half_in && CPB % 2 == 0 && p.vslices <= 1 && (p.nchan & 1) == 0 && (p.coil0 & 1) == 0
         && (reinterpret_cast<uintptr_t>(p.nudata) & 15) == 0)
         in_mode = kInLdsDma;
-#endif
     if (lds > 64 * 1024) {   // above the default dynamic-LDS limit: raise it once per instantiation and device
         const void *fns[3] = {reinterpret_cast<const void *>(grid_binned_kernel<CPB, CW, kInRegs32>),
                               reinterpret_cast<const void *>(grid_binned_kernel<CPB, CW, kInRegs16>),
@@ -758,7 +745,7 @@ static hipError_t launch_binned_cpb(const GridParams &p, int half_in, hipStream_
         hipLaunchKernelGGL((grid_binned_kernel<CPB, CW, (CPB % 2 == 0 ? kInLdsDma : kInRegs32)>), grid, dim3(kBinThreads), lds, s, q);
     else
         hipLaunchKernelGGL((grid_binned_kernel<CPB, CW, kInRegs32>), grid, dim3(kBinThreads), lds, s, q);
-    if (q.nsplit_slots > 0 && !p.no_reduce)
+    if (q.nsplit_slots > 0)
         hipLaunchKernelGGL(grid_reduce_parts_kernel, dim3((unsigned)((size_t)q.nsplit_slots * q.nslices),
                                                           (unsigned)(p.vslices > 1 ? p.vslices * p.nchan : p.nchan - p.coil0)),
                            dim3(kBinThreads), 0, s, q);
@@ -776,10 +763,6 @@ static hipError_t launch_binned_cw(const GridParams &p, int half_in, hipStream_t
         return launch_binned_cpb<2, CW>(p, half_in, s);
     }
     const int nc = p.nchan - p.coil0;
-    static const int force = tuning_env("TRON_GRID_CPB") ? atoi(tuning_env("TRON_GRID_CPB")) : 0;   // tuning knob
-    if (force == 8) return launch_binned_cpb<8, CW>(p, half_in, s);
-    if (force == 6) return launch_binned_cpb<6, CW>(p, half_in, s);
-    if (force == 4) return launch_binned_cpb<4, CW>(p, half_in, s);
     // one padded 8-coil pass beats two 4-coil passes: the per-sample work (weights, sort) is paid per pass
     // (6 coils: 3.3 vs 4.9 us per coil-slice; 12 coils: 4.1 vs 4.4); passes of 6 coils where they pad less than passes of 8
     // (5, 6, 10, 12 coils: the whole-body data set has 6) -- fp32 input only, complex-half loads come in fours
@@ -805,21 +788,8 @@ hipError_t launch_grid_binned(const GridParams &p, int half_in, hipStream_t s)
     }
 }
 
-// The reduce pass on its own: the arc kernel (tron_grid_arc.hip) stores the plain tiles between the inner tile's parts
-// (launch_grid_binned with no_reduce) and this.
-hipError_t launch_grid_reduce(const GridParams &p, hipStream_t s)
-{
-    if (p.nsplit_slots <= 0 || p.vslices > 1) return hipErrorInvalidValue;
-    const int tpr = (p.nxos + kBinTile - 1) / kBinTile;
-    GridParams q = p;
-    q.tiles_per_row = tpr;
-    q.ntiles = tpr * tpr;
-    hipLaunchKernelGGL(grid_reduce_parts_kernel, dim3((unsigned)((size_t)q.nsplit_slots * q.nslices), (unsigned)(p.nchan - p.coil0)),
-                       dim3(kBinThreads), 0, s, q);
-    return hipGetLastError();
-}
 
-#ifdef TRON_BIN_PROFILE
+#ifdef TRON_PHASE_CLOCK
 extern "C" __attribute__((visibility("default"))) int tron_debug_grid_profile(unsigned long long *out, int n)   // reads and clears the phase clock
 {
     static unsigned long long h[kProfCopies * kProfSlots];

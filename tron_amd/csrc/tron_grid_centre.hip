@@ -42,11 +42,6 @@ namespace tron {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-#ifdef TRON_CEN_OCC
-#define TRON_CEN_OCC_ATTR __attribute__((amdgpu_waves_per_eu(TRON_CEN_OCC)))     // (measured for the 8-coil form, 98 registers: held to 96 for a fifth wave per SIMD, no faster)
-#else
-#define TRON_CEN_OCC_ATTR
-#endif
 constexpr int kCenTicketWords = 8 * 16;                         // GridParams::cen_ticket: a counter per XCD, 64 bytes apart; then one per busy (slice, chunk, block)
 constexpr int kCenWaves = 4;                                   // waves per workgroup, each on its own (block, slice)
 
@@ -63,8 +58,8 @@ struct CenLds {
 };
 
 // LPV lanes per visit, each with one coil pair (16 bytes of the sample; one coil: LPV = 1, 8 bytes): chunks of 2 LPV coils
-// Phase clock (-DTRON_CEN_PROFILE builds only, tools/cenprof.py): shader-clock cycles per wave and phase, summed over the launch
-#ifdef TRON_CEN_PROFILE
+// Phase clock (-DTRON_PHASE_CLOCK builds only, tools/cenprof.py): shader-clock cycles per wave and phase, summed over the launch
+#ifdef TRON_PHASE_CLOCK
 constexpr int kCenProfCopies = 256;
 __device__ unsigned long long g_cen_prof[kCenProfCopies * 16];
 #define CPROF_DECL unsigned cprof[16] = {}; unsigned long long cprof_t = __builtin_readcyclecounter(); const unsigned long long cprof_0 = cprof_t, cprof_r0 = __builtin_amdgcn_s_memrealtime()
@@ -92,7 +87,7 @@ __device__ __forceinline__ int wave_incl_scan_add(int v)
 }
 
 template <int LPV, bool ONE, bool HALF>
-__global__ void __launch_bounds__(64 * kCenWaves) TRON_CEN_OCC_ATTR
+__global__ void __launch_bounds__(64 * kCenWaves)
 grid_centre_kernel(const GridParams p)
 {
     static_assert(LPV == 1 || LPV == 2 || LPV == 4, "lanes per visit");
@@ -404,7 +399,6 @@ static hipError_t launch_centre_lpv(const GridParams &p, hipStream_t s)
         int occ = 0, cus = 0;
         if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, grid_centre_kernel<LPV, ONE, HALF>, 64 * kCenWaves, 0)) != hipSuccess) return e;
         if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
-        if (const char *e = tuning_env("TRON_CEN_WGS")) { fprintf(stderr, "centre kernel <%d,%d,%d>: %d workgroups per CU by the occupancy query, %d CUs; TRON_CEN_WGS=%s\n", LPV, (int)ONE, (int)HALF, occ, cus, e); occ = atoi(e); }   // tuning knob
         wgs_per_xcd[dev] = std::max(1, occ) * std::max(1, cus / 8);
     }
     const int per_chunk = ONE ? 1 : 2 * LPV;
@@ -434,7 +428,7 @@ hipError_t launch_grid_centre(const GridParams &p, int half_in, hipStream_t s)
     return half_in ? launch_centre_lpv<4, false, true>(p, s) : launch_centre_lpv<4, false, false>(p, s);
 }
 
-#ifdef TRON_CEN_PROFILE
+#ifdef TRON_PHASE_CLOCK
 extern "C" __attribute__((visibility("default"))) int tron_debug_cen_profile(unsigned long long *out)   // reads and clears the phase clock (16 slots)
 {
     static unsigned long long h[kCenProfCopies * 16];

@@ -62,16 +62,13 @@ struct ScatGeom {
 
 template <int NC, int TILE>
 struct ScatCfg {
-#ifndef TRON_SCAT_WAVES1
-#define TRON_SCAT_WAVES1 5
-#define TRON_SCAT_R1 6
-#endif
+    static constexpr int kScatWaves1 = 5, kScatR1 = 6;
     // 32-tiles: workgroups per CU (LDS: 21 / 31 units of 1280 bytes; registers: 96 / 128).  64-tiles: two workgroups of eight waves
     // per CU (LDS 47 units for one channel), i.e. four waves per SIMD.
     // (two channels: 32-tiles only in practice -- the plan does not make 64-tile tables for them: 100 KB of sums)
-    static constexpr int WAVES = TILE == 64 ? (NC >= 2 ? 2 : 4) : (NC >= 2 ? 3 : TRON_SCAT_WAVES1);
+    static constexpr int WAVES = TILE == 64 ? (NC >= 2 ? 2 : 4) : (NC >= 2 ? 3 : kScatWaves1);
     // iterations (of 64 records per wave) whose samples wait in registers: one round up to 1 536 / 2 048 records per 32-tile
-    static constexpr int R = TILE == 64 ? 8 : (NC >= 2 ? 8 : TRON_SCAT_R1);
+    static constexpr int R = TILE == 64 ? 8 : (NC >= 2 ? 8 : kScatR1);
 };
 
 constexpr int kScatLutS = 64;                       // pieces per grid unit of the pair table this kernel copies (kb_pair_lut_scale: 64 for every width it takes)
@@ -94,9 +91,9 @@ struct ScatLds {
 
 typedef const __attribute__((address_space(3))) v2f *slds_f2p;
 
-// Phase clock of tools/scatprof.py (-DTRON_SCAT_PROFILE builds only): shader-clock cycles per wave and phase, summed over all waves
+// Phase clock of tools/scatprof.py (-DTRON_PHASE_CLOCK builds only): shader-clock cycles per wave and phase, summed over all waves
 // of all launches since the last read, plus loop counters; production builds carry none of it.
-#ifdef TRON_SCAT_PROFILE
+#ifdef TRON_PHASE_CLOCK
 constexpr int kScatProfSlots = 16, kScatProfCopies = 4096;
 __device__ unsigned long long g_scat_prof[kScatProfCopies * kScatProfSlots];
 #define SPROF_DECL unsigned prof_acc[kScatProfSlots] = {}; unsigned long long prof_t = __builtin_readcyclecounter(); const unsigned long long prof_c0 = prof_t, prof_r0 = __builtin_amdgcn_s_memrealtime()
@@ -112,13 +109,9 @@ __device__ unsigned long long g_scat_prof[kScatProfCopies * kScatProfSlots];
 
 __device__ __forceinline__ int cvt_rpi(float x)      // floor(x + 0.5): one instruction (v_cvt_i32_f32 truncates, rndne + cvt are two)
 {
-#ifdef TRON_SCAT_RN
-    return __float2int_rn(x);
-#else
     int r;
     asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x));
     return r;
-#endif
 }
 
 template <int NC, bool HALF, bool RS, int TILE>
@@ -372,7 +365,7 @@ grid_scatter_kernel(const GridParams p)
             __syncthreads();
             SPROF_MARK(5);
             const float new_max = __uint_as_float(L.dmax_bits[slot]);
-            // S = 2^e: every sum of the tile stays inside 32 bits: max (|d| dcf) * (spokes that can reach one point) * (4 K(0)^2 per spoke) * S < 2^31
+            // S = 2^e: every sum of the tile stays inside 32 bits: max (|d| dcf) * (spokes that can reach one point) * (1.75 K(0)^2 per spoke, GridParams::scat_wsum) * S < 2^31
             if (new_max > run_max || !have_scale) {
                 int e_new = 0;
                 const float bound = new_max * (float)max(mwin, 1) * p.scat_wsum;
@@ -540,7 +533,7 @@ grid_scatter_kernel(const GridParams p)
     SPROF_FLUSH;
 }
 
-#ifdef TRON_SCAT_PROFILE
+#ifdef TRON_PHASE_CLOCK
 extern "C" __attribute__((visibility("default"))) int tron_debug_scat_profile(unsigned long long *out, int n)   // reads and clears the phase clock
 {
     static unsigned long long h[kScatProfCopies * kScatProfSlots];

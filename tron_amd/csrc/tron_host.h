@@ -4,6 +4,7 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <string>
 #include <vector>
 
 #include "../../include/tron_hip.h"
@@ -16,11 +17,14 @@ int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 // Tuning / debugging switches of the library are read from the environment ONLY when TRON_TUNING=1 is set
 // as well: a library caller's behaviour does not depend on stray TRON_* variables.
 const char *tuning_env(const char *name);
+bool debug_token(const char *name, std::string *value = nullptr);   // a token of TRON_DEBUG (`sync`, `poison`, `cold_fault=<path>`)
 
 float grid_spoke_angle(int pe, int npe, int skip, int golden);
 float degrid_spoke_angle(int pe, int npe, int skip, int golden);
 size_t trig_table_size(const tron_config &cfg, const tron_dims &d);
 void build_trig_table(const tron_config &cfg, const tron_dims &d, float *cos_sin, size_t n);
+void build_trig_table_mt(const tron_config &cfg, const tron_dims &d, float *cos_sin, size_t n, int max_threads);
+float exact_fmodf_pos(float x, float y);      // fmodf for 0 <= x, 0 < y, x / y < 2^28 (the golden-angle wrap), bit for bit
 void build_trig_table_window(int npe, int skip, int golden, float *cos_sin);
 void build_band_table(int nxos, float kernwidth, uint32_t *band);
 bool scatter_band_is_analytic(int nxos, float kernwidth, const uint32_t *band);   // (u - W)^2 <= X^2 + Y^2 <= (u + W)^2 reproduces the table (tron_grid_scatter.hip)
@@ -42,10 +46,8 @@ double kb_peak(float kernwidth);      // the window's value at 0
 // build_kb_pair_lut fills coef[3][cap][2] and returns the entries used
 int kb_pair_lut_scale(float kernwidth, int cap);
 int build_kb_pair_lut(float kernwidth, int cap, float *coef, float *scale, int *bias, double *err);
-// centre kernel: per window and block of `groups` its run of the angle-sorted spoke list (first | count << 16)
-void build_centre_windows(const float *phi, size_t nwindows, int npe, const int *groups, int ngroups, float W, uint32_t *out);
-// arc gridding kernel: per window of npe spokes (cos_sin + 2 * stride * z), the spokes in ascending line angle (mod pi)
-void build_arc_tables(const float *cos_sin, size_t nwindows, size_t stride, int npe, unsigned short *order, float *phi);
+// centre kernel: per block of `groups` the angular window of its run of a window's angle-sorted spoke list: out[4 g] = (lo, hi, all | wrap << 1, share)
+void build_centre_group_windows(const int *groups, int ngroups, float W, float *out);
 double kb_poly_fit(float kernwidth, float *poly, int nterms);
 void dcf_constants(int nro, int npe1work, float *a, float *b);
 float grid_scale(int nxos, int npe);

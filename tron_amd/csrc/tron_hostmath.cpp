@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/tron_hip.h"
@@ -23,11 +24,25 @@ namespace tron {
 
 static const float kGoldenAngle = 1.9416089796736116f;   // PHI, src/tron.cu:90
 
+// fmodf(x, y) for finite x >= 0, y > 0 with x / y < 2^28: the same VALUE as libm's -- fmod is exact by definition (x - trunc(x / y) y,
+// always representable), so any exact evaluation returns the same bits -- at a tenth of glibc's cost (its fmodf subtracts bit by bit: 40 ns
+// for the quotients ~ 10^5 the golden-angle index produces, and the (cos, sin) table of a 256-slice plan is 10^5 of them).
+// In double: q = trunc(x / y) is within one of the true quotient (x / y carries a relative error of 2^-53, q < 2^28), q y has at most
+// 28 + 24 bits and is exact, so is the difference; one correction step lands in [0, y).  tests/test_host.py compares it with fmodf.
+float exact_fmodf_pos(float x, float y)
+{
+    const double xd = x, yd = y;
+    double r = xd - floor(xd / yd) * yd;
+    if (r < 0.0) r += yd;
+    if (r >= yd) r -= yd;
+    return (float)r;
+}
+
 // src/tron.cu:372-378
 static float wrap_angle(float x)
 {
     const float two_pi = 2.f * M_PI;
-    float y = fmodf(x, two_pi);
+    float y = (x >= 0.f && x < 1.0e9f) ? exact_fmodf_pos(x, two_pi) : fmodf(x, two_pi);
     return y < 0.f ? y + two_pi : y;
 }
 
@@ -76,6 +91,30 @@ void build_trig_table(const tron_config &cfg, const tron_dims &d, float *cos_sin
     }
 }
 
+// The same table on up to `max_threads` host threads (tron_plan_retarget: 100 k entries between two batches of a 3.5 ms step);
+// every entry is computed exactly as above, whichever thread does it.
+void build_trig_table_mt(const tron_config &cfg, const tron_dims &d, float *cos_sin, size_t n, int max_threads)
+{
+    const size_t per_thread = 8192;                           // (~0.2 ms of libm each: below that a thread costs more than it saves)
+    int nth = (int)std::min<size_t>((n + per_thread - 1) / per_thread, (size_t)std::max(1, max_threads));
+    if (nth <= 1) { build_trig_table(cfg, d, cos_sin, n); return; }
+    auto part = [&](int t) {
+        const size_t i0 = n * t / nth, i1 = n * (t + 1) / nth;
+        for (size_t i = i0; i < i1; ++i) {
+            float a = cfg.adjoint ? grid_spoke_angle((int)i, d.npe1work, cfg.skip_angles, cfg.golden_angle)
+                                  : degrid_spoke_angle((int)i, d.npe1work, cfg.skip_angles, cfg.golden_angle);
+            float sn, cn;
+            sincosf(a, &sn, &cn);
+            cos_sin[2 * i] = cn;
+            cos_sin[2 * i + 1] = sn;
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nth; ++t) th.emplace_back(part, t);
+    part(0);
+    for (auto &x : th) x.join();
+}
+
 void build_trig_table_window(int npe, int skip, int golden, float *cos_sin)
 {
     for (int i = 0; i < npe; ++i) {
@@ -86,12 +125,28 @@ void build_trig_table_window(int npe, int skip, int golden, float *cos_sin)
     }
 }
 
+// Rows [0, n) of a table dealt to a few host threads (plan creation: the band and deapodisation tables are 260 k and 65 k libm
+// calls at the metric shape, 5 of the 40 ms a plan took in round 5); every entry is computed by the same expression whichever
+// thread does it.  Small tables stay on the caller's thread.
+template <typename F>
+static void for_rows(int n, size_t work_per_row, F body)
+{
+    static const int hw = std::max(1, std::min(8, (int)std::thread::hardware_concurrency() / 2));
+    const int nth = (int)std::min<size_t>((size_t)hw, std::max<size_t>(1, (size_t)n * work_per_row / 32768));
+    if (nth <= 1 || n < 2 * nth) { for (int r = 0; r < n; ++r) body(r); return; }
+    std::vector<std::thread> th;
+    auto part = [&](int t) { for (int r = (int)((long long)n * t / nth); r < (int)((long long)n * (t + 1) / nth); ++r) body(r); };
+    for (int t = 1; t < nth; ++t) th.emplace_back(part, t);
+    part(0);
+    for (auto &x : th) x.join();
+}
+
 // Radial band of every Cartesian point, src/tron.cu:498-502: a sample of signed radius r on any
 // spoke can contribute to the point only if Rlo <= |r| <= Rhi.
 void build_band_table(int nxos, float kernwidth, uint32_t *band)
 {
     const int h = nxos / 2;
-    for (int yy = 0; yy < nxos; ++yy)
+    for_rows(nxos, (size_t)nxos, [&](int yy) {
         for (int xx = 0; xx < nxos; ++xx) {
             int X = xx - h, Y = yy - h;
             float R = hypotf((float)X, (float)Y);
@@ -100,6 +155,7 @@ void build_band_table(int nxos, float kernwidth, uint32_t *band)
             if (Rhi < 0) { Rhi = 0; Rlo = 1; }                // nxos < 2: empty band
             band[(size_t)yy * nxos + xx] = (uint32_t)Rlo | ((uint32_t)Rhi << 16);
         }
+    });
 }
 
 // grid_scatter_kernel tests the band as (u - W)^2 <= X^2 + Y^2 <= (u + W)^2 (u - W clamped at 0) instead of reading this table.  For integer u
@@ -155,13 +211,15 @@ static float kb_hat(float u, float kernwidth)
 // x coordinate of :395); the kernel's "/= w" is a multiplication by 1.0f/w (float2math.h:23).
 void build_deapod_table(int n, float kernwidth, float sigma, float *inv_weight)
 {
-    for (size_t id = 0; id < (size_t)n * n; ++id) {
-        float x = id / float(n) - (n + 1) / 2;
-        float y = float(id % n) - (n + 1) / 2;
-        float scale = 1.f / n / sigma;
-        float wgt = kb_hat(x * scale, kernwidth) * kb_hat(y * scale, kernwidth);
-        inv_weight[id] = 1.0f / (wgt > 0.f ? wgt : 1.f);
-    }
+    for_rows(n, (size_t)n * 4, [&](int row) {
+        for (size_t id = (size_t)row * n; id < (size_t)(row + 1) * n; ++id) {
+            float x = id / float(n) - (n + 1) / 2;
+            float y = float(id % n) - (n + 1) / 2;
+            float scale = 1.f / n / sigma;
+            float wgt = kb_hat(x * scale, kernwidth) * kb_hat(y * scale, kernwidth);
+            inv_weight[id] = 1.0f / (wgt > 0.f ? wgt : 1.f);
+        }
+    });
 }
 
 // The same for a non-square grid (forward plans only; "TODO: implement non-square images", src/tron.cu:945): rows and
@@ -180,6 +238,25 @@ const char *tuning_env(const char *name)
 {
     static const bool on = [] { const char *t = getenv("TRON_TUNING"); return t && atoi(t) != 0; }();
     return on ? getenv(name) : nullptr;
+}
+
+// TRON_DEBUG (under TRON_TUNING=1): comma-separated debugging / test hooks -- `sync`, `poison`, `cold_fault=<path>`.
+bool debug_token(const char *name, std::string *value)
+{
+    const char *e = tuning_env("TRON_DEBUG");
+    if (!e) return false;
+    const std::string all(e), key(name);
+    size_t pos = 0;
+    while (pos <= all.size()) {
+        const size_t end = std::min(all.find(',', pos), all.size());
+        const std::string tok = all.substr(pos, end - pos);
+        if (tok == key || tok.compare(0, key.size() + 1, key + "=") == 0) {
+            if (value) *value = tok.size() > key.size() ? tok.substr(key.size() + 1) : std::string();
+            return true;
+        }
+        pos = end + 1;
+    }
+    return false;
 }
 
 // Density compensation constants, src/tron.cu:408-409
@@ -339,10 +416,12 @@ int build_kb_pair_lut(float kernwidth, int cap, float *coef, float *scale, int *
     return imax + b + 1;
 }
 
-// Centre kernel (tron_grid_centre.hip): per window and 2x2 block (col | row << 8 of the origin-centred 32 x 32 square) the block's run
-// of the angle-sorted spoke list, first entry | entries << 16, circular.  The arc kernel's rule: a spoke of line angle phi reaches
-// the block's footprint only if its line passes within (W + 1/2)(|cos phi| + |sin phi|) of the block centre (tron_grid_arc.hip).
-void build_centre_windows(const float *phi, size_t nwindows, int npe, const int *groups, int ngroups, float W, uint32_t *out)
+// Centre kernel (tron_grid_centre.hip): the angular window of every 2x2 block (col | row << 8 of the origin-centred 32 x 32 square) --
+// the arc kernel's rule: a spoke of line angle phi reaches the block's footprint only if its line passes within
+// (W + 1/2)(|cos phi| + |sin phi|) of the block centre (tron_grid_arc.hip).  out[4 g] = (lo, hi, all | wrap << 1, expected share of a
+// window's spokes): the block's run of a window's angle-sorted list is [lower_bound(lo), upper_bound(hi)), circular when `wrap`, the whole
+// list when `all`; traj_centre_windows_kernel (tron_traj_dev.hip) does the searches per window on the device.  Geometry only: no angle enters.
+void build_centre_group_windows(const int *groups, int ngroups, float W, float *out)
 {
     const float pi = 3.14159265358979f;
     for (int g = 0; g < ngroups; ++g) {
@@ -357,38 +436,10 @@ void build_centre_windows(const float *phi, size_t nwindows, int npe, const int 
         T -= floorf(T / pi) * pi;
         const float tlo = T - D, thi = T + D;
         const bool wrap = tlo < 0.f || thi >= pi;
-        const float a = tlo < 0.f ? tlo + pi : tlo, b = thi >= pi ? thi - pi : thi;
-        for (size_t w = 0; w < nwindows; ++w) {
-            const float *ph = phi + w * npe;
-            int first = 0, count = npe;
-            if (!all) {
-                const int na = (int)(std::lower_bound(ph, ph + npe, a) - ph), nb = (int)(std::upper_bound(ph, ph + npe, b) - ph);
-                first = na;
-                count = wrap ? npe - na + nb : nb - na;
-                count = std::max(0, std::min(count, npe));
-            }
-            out[w * ngroups + g] = (uint32_t)(first % std::max(npe, 1)) | ((uint32_t)count << 16);
-        }
-    }
-}
-
-void build_arc_tables(const float *cos_sin, size_t nwindows, size_t stride, int npe, unsigned short *order, float *phi)
-{
-    std::vector<std::pair<float, int>> key(npe);
-    for (size_t z = 0; z < nwindows; ++z) {
-        const float *t = cos_sin + 2 * stride * z;
-        for (int k = 0; k < npe; ++k) {
-            float a = atan2f(t[2 * k + 1], t[2 * k]);
-            if (a < 0.f) a += (float)M_PI;
-            if (a >= (float)M_PI) a -= (float)M_PI;
-            if (a < 0.f) a = 0.f;
-            key[k] = {a, k};
-        }
-        std::stable_sort(key.begin(), key.end(), [](const std::pair<float, int> &x, const std::pair<float, int> &y) { return x.first < y.first; });
-        for (int k = 0; k < npe; ++k) {
-            order[z * npe + k] = (unsigned short)key[k].second;
-            phi[z * npe + k] = key[k].first;
-        }
+        out[4 * g] = tlo < 0.f ? tlo + pi : tlo;
+        out[4 * g + 1] = thi >= pi ? thi - pi : thi;
+        out[4 * g + 2] = (float)((all ? 1 : 0) | (wrap ? 2 : 0));
+        out[4 * g + 3] = all ? 1.0f : fminf(1.0f, 2.0f * D / pi);
     }
 }
 
@@ -476,7 +527,6 @@ bool build_centre_relief_order(int nxos, int tile, int npe, float W, int max_par
     slots.clear();
     // an inner sample's footprint (floor(k) - ceil(W) + 1 .. floor(k) + ceil(W)) must stay inside the inner tile
     inner_r0 = tile / 2 - (int)ceilf(W);
-    if (const char *e = tuning_env("TRON_INNER_R0")) inner_r0 = std::max(4, std::min(inner_r0, atoi(e)));   // (A/B: a smaller inner tile load)
     if (nxos < 4 * tile || (nxos / 2) % tile != 0 || inner_r0 < 8 || nxos / 2 - 1 < inner_r0) return false;
     std::vector<int> plain;
     build_tile_order(nxos, tile, plain);
@@ -595,7 +645,7 @@ extern "C" int tron_host_trig_table(const tron_config *cfg, const tron_dims *dim
 {
     if (!cfg || !dims || !cos_sin) return tron::fail(TRON_ERR_INVALID, "tron_host_trig_table: null argument");
     if (n > trig_table_size(*cfg, *dims)) return tron::fail(TRON_ERR_INVALID, "tron_host_trig_table: table has only %zu entries", trig_table_size(*cfg, *dims));
-    build_trig_table(*cfg, *dims, cos_sin, n);
+    build_trig_table_mt(*cfg, *dims, cos_sin, n, 8);          // (the plan's own builder: tables of more than 8 192 entries on several threads)
     return TRON_OK;
 }
 

@@ -60,7 +60,6 @@ struct GridParams {
     float kb_poly[kKbPolyTerms];  // fast mode: highest power first, includes the 0.5/W factor
     int skip_outside;        // binned kernel: tiles wholly beyond radius nxos/2-1+W (always zero, src/tron.cu:498-502) are not stored;
                              // only set when the consumer (launch_fft512_adjoint) does not read them either
-    int debug;               // TRON_DEBUG_SKIP: 1 = skip the gather phase, 2 = skip staging too (timing experiments only)
     // binned kernel, split tiles (small launches: the k-space-centre tiles are dealt to several workgroups each)
     int tile_entries;        // entries of tile_order (0: ntiles plain tile ids)
     int nsplit_slots;        // split tiles per slice (0: none); slot s is tile split_slots[s] & 0xffff with (>> 20) & 15 parts
@@ -71,8 +70,6 @@ struct GridParams {
     int vslices, nslices_total;
     int inner_r0;            // binned kernel, centre relief (0: off): samples |r| < inner_r0 are gridded by the origin-centred inner tile
                              // (entry tile id == ntiles, dealt over spoke ranges; slot 0 of split_slots), the four centre tiles take |r| >= inner_r0
-    int lds_pad;             // binned kernel: request at least this much LDS per workgroup (0: what it needs); leaves CU room for a second lane
-    int no_reduce;           // binned kernel: do not launch grid_reduce_parts_kernel (the caller does, after the arc kernel has stored the centre tiles)
     // arc kernel (tron_grid_arc.hip): per (window, tile) the run of crossing spokes, dealt into batches at plan time
     const int4 *arc_hdr;               // [window][tile] -> run length, batches, first entry, records
     const uint4 *arc_ent;              // [window][arc_cap] -> first sample index | down << 31, ulo | len << 10 | offset << 17, cos, sin
@@ -131,9 +128,7 @@ struct DegridParams {
     int in_transposed;        // degrid_tile_kernel: input planes are stored [col][row] (fused forward FFT)
     int in_rot;               // ... with every line rotated: point i of a line lies at (i + in_rot) mod its length (the streaming kernel's halo:
                               // a tile's row segments then start on a 128-byte line, three lines each instead of four)
-    int debug;                // TRON_DEBUG_SKIP (timing bisection): 1 = no sample loop, 2 = tile load only
     int group_end[4];         // degrid_stream_kernel: tile_order positions [group_end[c-1], group_end[c]) take runs of 2^c images (c = 4: the rest)
-    int debug_nosort;         // degrid_stream_kernel (tuning knob TRON_DEGRID_NOSORT): the kept records in list order, not sorted by footprint
     int group_max;            // ... capped by this (a quarter of the launch's images at most); < 4: degrid_tile_kernel only (8 images of 8 coils: 2.07 vs 1.79 us per coil image there)
     int n, nrep, nro, npe, nimg;
     int nrows;                // simple kernel only: rows of a non-square grid (0: n); n is then the column count
@@ -147,10 +142,8 @@ hipError_t launch_grid(const GridParams &p, int kb_mode, int half_in, hipStream_
 hipError_t launch_grid_binned(const GridParams &p, int half_in, hipStream_t s);
 constexpr int kBinnedTile = 32;
 // TRON_KB_FAST, fp32 input, even coil counts, centre relief active (tron_grid_arc.hip): the plain tiles of p.tile_order
-// (entries [first_plain, first_plain + ntiles)) are gridded by the arc kernel; the caller launches the inner tile's parts
-// (binned kernel, no_reduce) before and launch_grid_reduce after it
+// (entries [first_plain, first_plain + ntiles)) are gridded by the arc kernel, which leaves the samples |r| < p.inner_r0 to launch_grid_centre
 hipError_t launch_grid_arc(const GridParams &p, int half_in, int first_plain, hipStream_t s);
-hipError_t launch_grid_reduce(const GridParams &p, hipStream_t s);
 // the samples |r| < p.inner_r0 ADDED to the grid the arc kernel has stored (tron_grid_centre.hip): same stream, behind launch_grid_arc
 hipError_t launch_grid_centre(const GridParams &p, int half_in, hipStream_t s);
 hipError_t warm_grid_centre();
@@ -182,6 +175,28 @@ struct ArcPrepParams {
     int rec_cap;                       //              groups per window
 };
 hipError_t launch_arc_prep(const ArcPrepParams &p, int nwindows, hipStream_t s);
+// The lists arc_prep_kernel reads, built on the device from the (cos, sin) table (tron_traj_dev.hip): every window's spokes in ascending
+// line angle, ties in acquisition order; windows of more than kArcMaxNpe spokes also per pass of `sub` spokes.
+struct TrajSortParams {
+    const float2 *trig;                // (cos, sin) per spoke; window w = entries [w win_stride, w win_stride + npe)
+    int win_stride, nwin, npe, npass, sub;
+    unsigned short *order;             // out, [window][npe]: see ArcPrepParams
+    float *phi;
+    float2 *cs;
+    unsigned short *order_q;           // out (npass > 1), [pass][window][spokes of the pass]
+    float *phi_q;
+    float2 *cs_q;
+};
+hipError_t launch_traj_sort(const TrajSortParams &p, hipStream_t s);
+// ... and the centre kernel's block windows (GridParams::cen_win) from the sorted line angles
+struct TrajCentreParams {
+    const float *phi;                  // [window][npe] ascending line angles
+    const float4 *gwin;                // [block] angular window of the block's run: (lo, hi, all | wrap << 1, 0), build_centre_group_windows
+    uint32_t *out;                     // [window][block] first entry | entries << 16
+    int nwin, npe, ngroups;
+};
+hipError_t launch_traj_centre_windows(const TrajCentreParams &p, hipStream_t s);
+hipError_t warm_traj();
 // one or two channels, W <= 2 (tron_grid_scatter.hip): lane = sample, 64-bit fixed-point sums in LDS; same tables (ArcPrepParams::flat), same call as launch_grid_arc
 bool grid_scatter_supported(int nchan, int nxos, int nro, int npe, float W, int half_in);
 hipError_t launch_grid_scatter(const GridParams &p, int half_in, int first_plain, hipStream_t s);

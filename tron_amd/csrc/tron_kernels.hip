@@ -138,7 +138,7 @@ grid_tile_kernel(const GridParams p)
                     nsp = s + 1;
                 }
             }
-            if (TRON_DBG_LT(p, 2)) {
+            {
 #pragma unroll
                 for (int it = 0; it < (C::NSP * C::LPS) / 64; ++it) {
                     const int s = it * (64 / C::LPS) + lane / C::LPS;    // staged spoke this lane works on
@@ -183,7 +183,7 @@ grid_tile_kernel(const GridParams p)
             __syncthreads();
             // ---- 3. gather: each lane collects, for its 2x2 points, the staged samples whose
             //         footprint covers them, in the reference's summation order ---------------
-            for (int s = 0; s < nsp && TRON_DBG_LT(p, 1); ++s) {
+            for (int s = 0; s < nsp; ++s) {
                 const int src = sp_lane[s];
                 const float sct = __shfl(ct, src), sst = __shfl(st, src);     // wave-uniform
                 const int srlo = __shfl(rlo, src), srhi = __shfl(rhi, src);

@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -97,14 +98,31 @@ int main(int argc, char *argv[])
     }
     const char *infile = argv[optind];
     const char *outfile = optind + 1 < argc ? argv[optind + 1] : "img_tron.ra";   // src/tron.cu:877
-    if (const char *kb = getenv("TRON_KB_MODE")) cfg.kb_mode = strcmp(kb, "exact") == 0 ? TRON_KB_EXACT : TRON_KB_FAST;
-    if (const char *cc = getenv("TRON_CGNR_CONSISTENT")) cfg.cgnr_consistent = atoi(cc) != 0;
-    if (const char *cb = getenv("TRON_COIL_COMBINE")) cfg.coil_combine = strcmp(cb, "walsh") == 0 ? 1 : 0;
-    if (const char *wp = getenv("TRON_WALSH_PATCH")) cfg.walsh_patch = atoi(wp);
-    if (const char *ng = getenv("TRON_GPUS")) {
-        if (atoi(ng) > 1 && gpu_list.empty()) {
-            multi_gpu = true;
-            for (int g = 0; g < atoi(ng); ++g) gpu_list.push_back(g);
+    // What the reference's getopt string has no letter for (its flags are kept exactly, src/tron.cu:813): TRON_OPTIONS, a comma-separated
+    // list -- kb=exact|fast (Kaiser-Bessel mode, default fast), gpus=N (one worker per GPU, as -g all), combine=walsh|sos, patch=N
+    // (Walsh patch half-width), cgnr_consistent=1.  They become tron_config fields; the library itself reads no such variable.
+    if (const char *opts = getenv("TRON_OPTIONS")) {
+        std::string all(opts);
+        size_t pos = 0;
+        while (pos <= all.size()) {
+            const size_t end = std::min(all.find(',', pos), all.size());
+            const std::string tok = all.substr(pos, end - pos);
+            const size_t eq = tok.find('=');
+            const std::string key = tok.substr(0, eq), val = eq == std::string::npos ? std::string() : tok.substr(eq + 1);
+            if (key == "kb") cfg.kb_mode = val == "exact" ? TRON_KB_EXACT : TRON_KB_FAST;
+            else if (key == "cgnr_consistent") cfg.cgnr_consistent = atoi(val.c_str()) != 0;
+            else if (key == "combine") cfg.coil_combine = val == "walsh" ? 1 : 0;
+            else if (key == "patch") cfg.walsh_patch = atoi(val.c_str());
+            else if (key == "gpus") {
+                if (atoi(val.c_str()) > 1 && gpu_list.empty()) {
+                    multi_gpu = true;
+                    for (int g = 0; g < atoi(val.c_str()); ++g) gpu_list.push_back(g);
+                }
+            } else if (!key.empty()) {
+                fprintf(stderr, "tron: TRON_OPTIONS: unknown option '%s' (kb, gpus, combine, patch, cgnr_consistent)\n", key.c_str());
+                return 1;
+            }
+            pos = end + 1;
         }
     }
 

@@ -8,7 +8,6 @@ namespace tron {
 int drain_timers(tron_plan *p)
 {
     HIP_TRY(hipStreamSynchronize(p->stream));
-    if (p->stream2) HIP_TRY(hipStreamSynchronize(p->stream2));
     for (int s = 0; s < STAGE_COUNT; ++s) {
         for (auto &pr : p->ev[s]) {
             float ms = 0.f;
@@ -103,7 +102,6 @@ int stage_check(tron_plan *p, const char *what)
 {
     if (!p->sync_each) return TRON_OK;
     hipError_t e = hipStreamSynchronize(p->stream);
-    if (e == hipSuccess && p->stream2) e = hipStreamSynchronize(p->stream2);
     if (e != hipSuccess) return fail(TRON_ERR_HIP, "stage '%s' failed: %s", what, hipGetErrorString(e));
     fprintf(stderr, "[tronhip] stage %s ok\n", what);
     return TRON_OK;
@@ -127,8 +125,6 @@ void fill_grid_consts(const tron_plan *p, GridParams &g)
     g.dcf_a = p->dcf_a;
     g.dcf_b = p->dcf_b;
     memcpy(g.kb_poly, p->kb_poly, sizeof(g.kb_poly));
-    g.debug = p->debug_skip;
-    g.lds_pad = p->grid_lds_pad;
 }
 
 // Adjoint for slices [zfirst, zfirst+zcount).  d_in_z0 points at the first spoke of slice
@@ -142,8 +138,7 @@ int ensure_work(tron_plan *p, int units)
     const tron_dims &d = p->d;
     const size_t per_unit = (size_t)p->nchan * d.nxos * d.nyos * sizeof(float2);
     HIP_TRY(hipStreamSynchronize(p->stream));
-    if (p->stream2) HIP_TRY(hipStreamSynchronize(p->stream2));
-    for (float2 **b : {&p->d_grid, &p->d_grid2, &p->d_fft_tmp})
+    for (float2 **b : {&p->d_grid, &p->d_fft_tmp})
         if (*b) { HIP_TRY(hipFree(*b)); *b = nullptr; }
     p->work_units = 0;
     if (hipMalloc(reinterpret_cast<void **>(&p->d_grid), (size_t)units * per_unit) != hipSuccess)
@@ -154,56 +149,40 @@ int ensure_work(tron_plan *p, int units)
     }
     if (p->fft512 && hipMalloc(reinterpret_cast<void **>(&p->d_fft_tmp), (size_t)units * p->nchan * 256 * 512 * sizeof(float2)) != hipSuccess)
         return fail(TRON_ERR_NOMEM, "cannot allocate the FFT intermediate buffer");
-    if (p->dual && hipMalloc(reinterpret_cast<void **>(&p->d_grid2), (size_t)units * per_unit) != hipSuccess)
-        return fail(TRON_ERR_NOMEM, "cannot allocate the second Cartesian buffer");
     p->work_units = units;
     return TRON_OK;
 }
 
 // in_stride_spokes: spokes between the windows of consecutive slices in d_in_z0 (0 = prof_slide: views into the stream)
-// defer_join: leave the FFT lane running when the call returns (device-resident entry point: the caller synchronises with
-// tron_plan_sync); the next call's first gridding launches then overlap this call's last FFT passes.
+// One stream: gridding and the FFT passes of a batch follow each other on the plan's stream.  (Rounds 1-5 ran the FFT passes of
+// batch k beside the gridding of batch k + 1 on a second stream with a second work grid: 3.67 ms of kernels in 3.53 ms per step, and
+// the same bench line with the lanes serialised -- profiles/round5_bench_one_lane.json, round6_bench_one_lane.json; removed in round 6.)
 int adjoint_run_raw(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, int zcount, int combine, int in_stride_spokes,
-                    bool defer_join, float out_scale = 1.f, double *norm_partial = nullptr, int *norm_parts = nullptr)
+                    float out_scale = 1.f, double *norm_partial = nullptr, int *norm_parts = nullptr)
 {
     const tron_dims &d = p->d;
     const size_t n2 = (size_t)d.nxos * d.nxos;
     const size_t elem = p->cfg.input_half ? 4 : 8;
     const int golden = p->cfg.golden_angle;
-    // Two lanes: gridding is VALU/LDS bound and leaves HBM idle, the FFT passes are HBM bound and leave the
-    // VALUs idle.  All gridding launches go to `stream`, all FFT launches to `stream2`; chunk k's FFT waits
-    // for chunk k's gridding, and gridding of chunk k+2 waits until the FFT has released buffer k&1.
-    // (worth it only when each lane still gets full-size launches: +4.9 % at 8 coils x 256 slices, +2.9 % at 128, 0 below)
-    const bool dual = p->dual && p->fft512 && combine && zcount >= 2 * p->chunk;
+    const TrajTables &T = traj_cur(p);
     // equal batches: a short last launch would be bound by the centre tile's serial chain (e.g. 128 slices = 64 + 64, not 85 + 43)
     // (the work buffers hold 1.5 x chunk so that the batches can be evened out upwards)
     int nbatch = std::max(1, (zcount + p->chunk / 2) / p->chunk);
     if ((zcount + nbatch - 1) / nbatch > p->chunk_cap) nbatch = (zcount + p->chunk_cap - 1) / p->chunk_cap;
-    const int even = (zcount + nbatch - 1) / nbatch;
-    const int step = dual ? std::max(1, std::min(even, (zcount + 1) / 2)) : even;
+    const int step = (zcount + nbatch - 1) / nbatch;
     if (int erc = ensure_work(p, std::min(step, std::max(zcount, 1)))) return erc;
-    if (!dual)      // one lane: everything of an earlier two-lane call that may still be running on the FFT lane comes first
-        for (int b = 0; b < 2; ++b)
-            if (p->fft_pending[b]) {
-                HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_f[b], 0));
-                p->fft_pending[b] = false;
-            }
-    int lane_idx = 0;
-    for (int z0 = 0; z0 < zcount; z0 += step, ++lane_idx) {
+    hipStream_t st = p->stream;
+    for (int z0 = 0; z0 < zcount; z0 += step) {
         const int cz = std::min(step, zcount - z0);
-        const int b = dual ? (lane_idx & 1) : 0;
-        hipStream_t st = p->stream;
-        hipStream_t st_fft = dual ? p->stream2 : p->stream;
-        float2 *grid_buf = b ? p->d_grid2 : p->d_grid;
+        float2 *grid_buf = p->d_grid;
         float2 *tmp_buf = p->d_fft_tmp;
-        if (dual && p->fft_pending[b]) HIP_TRY(hipStreamWaitEvent(st, p->ev_f[b], 0));   // the FFT (of this or an earlier call) that last read buffer b
         GridParams g;
         memset(&g, 0, sizeof(g));
         fill_grid_consts(p, g);
         const int in_stride = in_stride_spokes > 0 ? in_stride_spokes : d.prof_slide;
         g.nudata = static_cast<const unsigned char *>(d_in_z0) + (size_t)z0 * in_stride * d.nro * p->nchan * elem;
         g.udata = grid_buf;
-        g.trig = p->d_trig + (golden ? (size_t)(zfirst + z0) * d.prof_slide : 0);
+        g.trig = T.d_trig + (golden ? (size_t)(zfirst + z0) * d.prof_slide : 0);
         g.in_slice_stride = (long long)in_stride * d.nro * p->nchan;
         g.trig_slice_stride = golden ? d.prof_slide : 0;
         g.nslices = cz;
@@ -213,7 +192,7 @@ int adjoint_run_raw(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, 
         g.out_p = 1;
         g.out_shift = 1;
         // the fused FFT never reads beyond the sampled disc, so the gridding kernel need not store zeros there
-        const int rzero = (p->fft512 && !p->no_disc) ? (int)floorf((float)(d.nxos / 2 - 1) + p->cfg.kernwidth) + 1 : 0;
+        const int rzero = p->fft512 ? (int)floorf((float)(d.nxos / 2 - 1) + p->cfg.kernwidth) + 1 : 0;
         g.skip_outside = rzero > 0 ? 1 : 0;
         {
             StageTimer t(p, STAGE_GRID, st);
@@ -228,6 +207,10 @@ int adjoint_run_raw(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, 
                     g.nslices = (cz + vs - 1) / vs;
                 }
                 int relief_parts = p->relief_parts;
+                // every tile but the samples |r| < inner_r0 on the arc / scatter kernel, those on the centre kernel behind it -- when this set's run
+                // tables are usable and cover the slices asked for; the binned kernel (inner tile in parts + reduce pass) otherwise
+                const bool use_arc = arc_ready(p) && p->relief_entries > 0 && vs <= 1 && (reinterpret_cast<uintptr_t>(g.nudata) & 15) == 0
+                                     && (!golden || (zfirst + z0 >= p->share_z0 && zfirst + z0 + cz <= p->share_z0 + p->share_nz));
                 if (p->relief_entries > 0) {
                     // the samples next to the k-space centre go to the inner tile's workgroups; their parts are added
                     // onto the centre tiles by the reduce pass that follows the gridding kernel on this stream
@@ -235,7 +218,7 @@ int adjoint_run_raw(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, 
                     relief_parts = small ? p->relief_parts_small : p->relief_parts;
                     const size_t need = (size_t)cz + (vs > 1 ? vs : 0);               // whole slice groups
                     const int parts_cap = std::max(p->relief_parts, p->relief_parts_small);
-                    if (p->relief_slices < need) {
+                    if (!use_arc && p->relief_slices < need) {       // (the inner tile's parts: the binned kernel's only)
                         if (p->d_relief_partial) { HIP_TRY(hipStreamSynchronize(st)); HIP_TRY(hipFree(p->d_relief_partial)); p->d_relief_partial = nullptr; }
                         const size_t want = std::max(need, (size_t)std::min(step, 64) + 8);
                         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_relief_partial),
@@ -265,22 +248,7 @@ int adjoint_run_raw(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, 
                     g.split_slots = p->d_split_slots;
                     g.partial = p->d_partial;
                 }
-                if (p->arc && p->relief_entries > 0 && vs <= 1 && (reinterpret_cast<uintptr_t>(g.nudata) & 15) == 0
-                    && (!golden || (zfirst + z0 >= p->share_z0 && zfirst + z0 + cz <= p->share_z0 + p->share_nz))) {
-                    // the inner tile's parts (binned kernel), every other tile (arc kernel), then the parts are added on
-                    GridParams gi = g;
-                    gi.tile_entries = relief_parts;
-                    gi.no_reduce = 1;
-                    if (p->centre_kernel) {
-                        // (the centre kernel adds the samples |r| < inner_r0 behind the arc kernel, below)
-                    } else if (p->inner_beside) {
-                        HIP_TRY(hipEventRecord(p->ev_inner[0], st));             // (the reduce pass that last read the parts buffer is behind this)
-                        HIP_TRY(hipStreamWaitEvent(p->stream_inner, p->ev_inner[0], 0));
-                        HIP_TRY(launch_grid_binned(gi, p->cfg.input_half, p->stream_inner));
-                        HIP_TRY(hipEventRecord(p->ev_inner[1], p->stream_inner));
-                    } else {
-                        HIP_TRY(launch_grid_binned(gi, p->cfg.input_half, st));
-                    }
+                if (use_arc) {
                     const size_t win0 = golden ? (size_t)(zfirst + z0 - p->share_z0) : 0;     // the run tables start at the plan's first slice
                     const size_t nt32 = (size_t)(d.nxos / kBinnedTile) * (d.nxos / kBinnedTile);
                     g.arc_cap = p->arc_cap;
@@ -295,14 +263,14 @@ int adjoint_run_raw(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, 
                     for (int q = 0; q < p->arc_passes; ++q) {      // (one pass unless a window holds more than kArcMaxNpe spokes)
                         GridParams ga = g;
                         const size_t tab = (size_t)q * p->arc_nwin + win0;
-                        const size_t nt_tab = p->scatter && p->scat_tile == 64 ? (size_t)(d.nxos / 64) * (d.nxos / 64) : nt32;
-                        ga.arc_hdr = p->d_arc_hdr + tab * nt_tab;
-                        ga.arc_ent = p->d_arc_ent + tab * p->arc_cap;
-                        ga.arc_win = p->d_arc_win ? p->d_arc_win + tab * nt32 * 256 : nullptr;
-                        ga.arc_off = p->d_arc_off ? p->d_arc_off + tab * p->arc_cap : nullptr;
+                        const size_t nt_tab = p->arc_ntiles;
+                        ga.arc_hdr = T.d_arc_hdr + tab * nt_tab;
+                        ga.arc_ent = T.d_arc_ent + tab * p->arc_cap;
+                        ga.arc_win = T.d_arc_win ? T.d_arc_win + tab * nt32 * 256 : nullptr;
+                        ga.arc_off = T.d_arc_off ? T.d_arc_off + tab * p->arc_cap : nullptr;
                         ga.scat_tile = p->scat_tile;
-                        ga.arc_rec = p->d_arc_rec ? p->d_arc_rec + tab * (size_t)p->arc_rec_cap * 80 : nullptr;
-                        ga.arc_rbase = p->d_arc_rbase ? p->d_arc_rbase + tab * nt_tab : nullptr;
+                        ga.arc_rec = T.d_arc_rec ? T.d_arc_rec + tab * (size_t)p->arc_rec_cap * 80 : nullptr;
+                        ga.arc_rbase = T.d_arc_rbase ? T.d_arc_rbase + tab * nt_tab : nullptr;
                         ga.arc_rec_cap = p->arc_rec_cap;
                         ga.npe = std::min(d.npe1work, (q + 1) * p->arc_pass_npe) - q * p->arc_pass_npe;
                         ga.arc_accumulate = q > 0;
@@ -313,23 +281,18 @@ int adjoint_run_raw(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, 
                         } else if (p->scatter) HIP_TRY(launch_grid_scatter(ga, p->cfg.input_half, relief_parts, st));
                         else HIP_TRY(launch_grid_arc(ga, p->cfg.input_half, relief_parts, st));
                     }
-                    if (p->centre_kernel) {
-                        const size_t woff = win0 * (size_t)d.npe1work;
-                        g.cen_order = p->d_cen_order + woff;
-                        g.cen_win = p->d_cen_win + win0 * (size_t)p->cen_nblocks;
-                        g.cen_cs = p->d_cen_cs + woff;
-                        const bool parts = cz < p->cen_parts_below && p->cen_nheavy > 0;      // small launch: the busy blocks in parts
-                        g.cen_grec = parts ? p->d_cen_grec_parts : p->d_cen_grec;
-                        g.cen_ticket = p->d_cen_ticket;
-                        g.cen_parts = p->d_cen_parts;
-                        g.cen_nblocks = p->cen_nblocks;
-                        g.cen_nheavy = parts ? p->cen_nheavy : 0;
-                        g.cen_ngroups = parts ? p->cen_nunits_parts : p->cen_ngroups;
-                        HIP_TRY(launch_grid_centre(g, p->cfg.input_half, st));
-                    } else {
-                        if (p->inner_beside) HIP_TRY(hipStreamWaitEvent(st, p->ev_inner[1], 0));
-                        HIP_TRY(launch_grid_reduce(g, st));
-                    }
+                    const size_t woff = win0 * (size_t)d.npe1work;
+                    g.cen_order = T.d_order + woff;
+                    g.cen_win = T.d_cen_win + win0 * (size_t)p->cen_nblocks;
+                    g.cen_cs = T.d_cs + woff;
+                    const bool parts = cz < p->cen_parts_below && p->cen_nheavy > 0;      // small launch: the busy blocks in parts
+                    g.cen_grec = parts ? p->d_cen_grec_parts : p->d_cen_grec;
+                    g.cen_ticket = p->d_cen_ticket;
+                    g.cen_parts = p->d_cen_parts;
+                    g.cen_nblocks = p->cen_nblocks;
+                    g.cen_nheavy = parts ? p->cen_nheavy : 0;
+                    g.cen_ngroups = parts ? p->cen_nunits_parts : p->cen_ngroups;
+                    HIP_TRY(launch_grid_centre(g, p->cfg.input_half, st));
                 } else {
                     HIP_TRY(launch_grid_binned(g, p->cfg.input_half, st));
                 }
@@ -341,30 +304,22 @@ int adjoint_run_raw(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, 
         if (rc) return rc;
         if (p->fft512 && combine) {
             // fused: pruned inverse FFT + crop + deapodise + root-sum-of-squares (tron_fft512.hip)
-            if (dual) {
-                HIP_TRY(hipEventRecord(p->ev_g[b], st));
-                HIP_TRY(hipStreamWaitEvent(st_fft, p->ev_g[b], 0));
-            }
             {
-                StageTimer t(p, STAGE_FFT, st_fft);
+                StageTimer t(p, STAGE_FFT, st);
                 HIP_TRY(launch_fft512_adjoint(grid_buf, tmp_buf, static_cast<float2 *>(d_out) + (size_t)z0 * d.nx * d.nx,
-                                              p->d_tw512, p->d_deapod, rzero, p->nchan, cz, st_fft));
-            }
-            if (dual) {
-                HIP_TRY(hipEventRecord(p->ev_f[b], st_fft));
-                p->fft_pending[b] = true;
+                                              p->d_tw512, p->d_deapod, rzero, p->nchan, cz, st));
             }
             if ((rc = stage_check(p, "fft512"))) return rc;
             continue;
         }
         if (p->fft512) {
             // fused, uncombined: pruned inverse FFT + crop + deapodise per coil image, interleaved by coil (CGNR, Walsh, nt > 1)
-            StageTimer t(p, STAGE_FFT, st_fft);
+            StageTimer t(p, STAGE_FFT, st);
             const int parts = fft512_coils_partials(cz) * p->nchan;
             if (norm_parts) *norm_parts = parts;
             HIP_TRY(launch_fft512_adjoint_coils(grid_buf, tmp_buf, static_cast<float2 *>(d_out) + (size_t)z0 * d.nx * d.nx * p->nchan,
                                                 p->d_tw512, p->d_deapod, rzero, p->nchan, cz, out_scale,
-                                                norm_partial ? norm_partial + (size_t)z0 * parts : nullptr, st_fft));
+                                                norm_partial ? norm_partial + (size_t)z0 * parts : nullptr, st));
             if ((rc = stage_check(p, "fft512 coils"))) return rc;
             continue;
         }
@@ -380,14 +335,11 @@ int adjoint_run_raw(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, 
         q.nchan = p->nchan;
         q.nslices = cz;
         q.combine = combine;
-        if (g.debug != 5) {
+        {
             StageTimer t(p, STAGE_POST);
             HIP_TRY(launch_post(q, p->stream));
         }
         if ((rc = stage_check(p, "post"))) return rc;
-    }
-    if (dual && lane_idx > 0 && !defer_join) {   // later work on the main stream (e.g. the download) waits for the FFT lane
-        HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_f[(lane_idx - 1) & 1], 0));
     }
     return TRON_OK;
 }
@@ -406,10 +358,11 @@ int combine_coils(tron_plan *p, float2 *d_out, const float2 *d_coil, int cz)
 // tail; Walsh's adaptive combination and nt > 1 (channel = coil + nc*repetition) run it uncombined into a scratch
 // buffer and combine from there.
 int adjoint_run(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, int zcount, int combine, int in_stride_spokes,
-                bool defer_join, float out_scale, double *norm_partial, int *norm_parts)
+                float out_scale, double *norm_partial, int *norm_parts)
 {
+    if (int trc = traj_turn(p)) return trc;
     if (!combine || (p->d.nt == 1 && p->cfg.coil_combine != 1))
-        return adjoint_run_raw(p, d_out, d_in_z0, zfirst, zcount, combine, in_stride_spokes, defer_join, out_scale, norm_partial, norm_parts);
+        return adjoint_run_raw(p, d_out, d_in_z0, zfirst, zcount, combine, in_stride_spokes, out_scale, norm_partial, norm_parts);
     const tron_dims &d = p->d;
     const size_t N = (size_t)p->nchan * d.nx * d.ny, elem = p->cfg.input_half ? 4 : 8;
     const int step = std::max(1, std::min(p->chunk, zcount));
@@ -424,7 +377,7 @@ int adjoint_run(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, int 
     for (int z0 = 0; z0 < zcount; z0 += step) {
         const int cz = std::min(step, zcount - z0);
         int rc = adjoint_run_raw(p, p->d_coil_tmp, static_cast<const unsigned char *>(d_in_z0) + (size_t)z0 * in_stride * d.nro * p->nchan * elem,
-                                 zfirst + z0, cz, 0, in_stride_spokes, false);
+                                 zfirst + z0, cz, 0, in_stride_spokes);
         if (rc) return rc;
         if ((rc = combine_coils(p, static_cast<float2 *>(d_out) + (size_t)z0 * d.nt * d.nx * d.ny, p->d_coil_tmp, cz))) return rc;
     }
@@ -434,10 +387,11 @@ int adjoint_run(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, int 
 int forward_run(tron_plan *p, void *d_out, const void *d_in, int nimg, const float2 *trig, int trig_img_stride,
                 const float *deapod)
 {
+    if (int trc = traj_turn(p)) return trc;
     const tron_dims &d = p->d;
     const size_t n2 = (size_t)d.nxos * d.nyos;
     const bool square = d.nx == d.ny;
-    if (!trig) trig = p->d_trig;
+    if (!trig) trig = traj_cur(p).d_trig;
     if (!deapod) deapod = p->d_deapod;
     if (int erc = ensure_work(p, std::max(1, std::min(p->chunk, nimg)))) return erc;
     for (int k0 = 0; k0 < nimg; k0 += p->chunk) {
@@ -450,7 +404,7 @@ int forward_run(tron_plan *p, void *d_out, const void *d_in, int nimg, const flo
             // fused: pad + deapodise + shift + pruned forward FFT (tron_fft512.hip)
             StageTimer t(p, STAGE_FFT);
             // samples lie within nxos/2 of the centre, their footprints (zero-weight slots included) within W + 2 more
-            const int rzero = p->no_disc ? 0 : d.nxos / 2 + (int)ceilf(p->cfg.kernwidth) + 4;
+            const int rzero = d.nxos / 2 + (int)ceilf(p->cfg.kernwidth) + 4;
             HIP_TRY(launch_fft512_forward(img, p->d_fft_tmp, p->d_grid, p->d_tw512, deapod, rzero, grid_rot, p->nchan, ck, p->stream));
         } else {
             PreParams a;
@@ -483,7 +437,6 @@ int forward_run(tron_plan *p, void *d_out, const void *d_in, int nimg, const flo
         g.in_shift = 1;
         g.in_transposed = p->fft512 ? 1 : 0;      // launch_fft512_forward stores the grid transposed
         g.in_rot = p->fft512 ? grid_rot : 0;
-        g.debug = p->debug_skip;
         g.n = d.nxos;
         g.nrows = square ? 0 : d.nyos;
         g.nrep = p->nchan;
@@ -494,8 +447,6 @@ int forward_run(tron_plan *p, void *d_out, const void *d_in, int nimg, const flo
         g.beta = p->beta;
         memcpy(g.kb_poly, p->kb_poly, sizeof(g.kb_poly));
         memcpy(g.group_end, p->dg_group_end, sizeof(g.group_end));
-        static const bool nosort = tuning_env("TRON_DEGRID_NOSORT") != nullptr;
-        g.debug_nosort = nosort ? 1 : 0;
         g.group_max = (square && !p->degrid_tile_only) ? std::min(16, ck / 4) : 0;   // runs of images only where they leave enough workgroups
         {
             StageTimer t(p, STAGE_DEGRID);
@@ -518,7 +469,9 @@ int forward_run(tron_plan *p, void *d_out, const void *d_in, int nimg, const flo
 // : coil images [z][nchan*id + c].
 int cgnr_run(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, int zcount, int combine)
 {
+    if (int trc = traj_turn(p)) return trc;
     const tron_dims &d = p->d;
+    const TrajTables &T = traj_cur(p);
     if (p->cfg.input_half) return fail(TRON_ERR_UNSUPPORTED, "CGNR needs complex64 k-space (the residual lives in fp32)");
     const size_t n = (size_t)p->nchan * d.nro * d.npe1work;          // data-space elements per slice
     const size_t N = (size_t)p->nchan * d.nx * d.ny;                 // image-space elements per slice (F2)
@@ -553,7 +506,7 @@ int cgnr_run(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, int zco
     // 512 / 256 path the FFT tail scales and leaves the partial sums; otherwise one pass over ztilde does both.
     auto residual_image = [&](int z0, int cz, int mode) -> int {
         int parts = 0;
-        int r2 = adjoint_run(p, p->d_cg_zt, p->d_cg_r, zfirst + z0, cz, 0, d.npe1work, false, unscale, p->d_cg_partial, &parts);
+        int r2 = adjoint_run(p, p->d_cg_zt, p->d_cg_r, zfirst + z0, cz, 0, d.npe1work, unscale, p->d_cg_partial, &parts);
         if (r2) return r2;
         if (parts == 0) {
             HIP_TRY(launch_cg_scale_norm2(p->d_cg_zt, N, cz, unscale, p->d_cg_partial, st));
@@ -572,7 +525,7 @@ int cgnr_run(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, int zco
         HIP_TRY(hipMemcpyAsync(p->d_cg_pt, p->d_cg_zt, cz * N * sizeof(float2), hipMemcpyDeviceToDevice, st));
         HIP_TRY(hipMemsetAsync(p->d_cg_x, 0, cz * N * sizeof(float2), st));
         // the forward operator's angles: the slice's own index range (F4); golden angles are shared with the adjoint's table
-        const float2 *trig = golden ? p->d_trig + (size_t)(zfirst + z0) * d.prof_slide : (p->d_trig_fwd ? p->d_trig_fwd : p->d_trig);
+        const float2 *trig = golden ? T.d_trig + (size_t)(zfirst + z0) * d.prof_slide : (p->d_trig_fwd ? p->d_trig_fwd : T.d_trig);
         const int trig_stride = golden ? d.prof_slide : 0;
         for (int t = 0; t < p->cfg.niter; ++t) {
             if ((rc = forward_run(p, p->d_cg_v, p->d_cg_pt, cz, trig, trig_stride, p->d_deapod_fwd))) return rc;   // v = A ptilde (:691)

@@ -13,6 +13,7 @@
 // (The pipelines themselves live in tron_pipeline.cpp, the host-buffer entry points in tron_hostio.cpp.)
 #include "tron_plan_impl.h"
 
+#include <fcntl.h>
 #include <time.h>
 #include <unistd.h>
 
@@ -49,6 +50,130 @@ extern "C" int tron_plan_create_times(const tron_plan *plan, double seconds[5])
 
 extern "C" const char *tron_version(void) { return "tronhip 0.1 (gfx950)"; }
 
+// Everything of an arc / scatter plan that follows from (p->scatter, p->scat_tile, p->relief_r0) and not from the spoke angles: the centre
+// kernel's block lists, the sizes of the run tables (TrajTables).  Called again when the first build of the tables overflows and the plan
+// takes the next formulation down (64-tiles -> 32-tiles -> arc kernel -> binned kernel).
+static int arc_setup(tron_plan *p, const std::vector<uint32_t> &band)
+{
+    const tron_config *cfg = &p->cfg;
+    const tron_dims &d = p->d;
+    int rc = TRON_OK;
+    for (void **q : {(void **)&p->d_cen_gwin, (void **)&p->d_cen_grec, (void **)&p->d_cen_grec_parts, (void **)&p->d_cen_ticket, (void **)&p->d_cen_parts,
+                     (void **)&p->d_tile_order64})
+        if (*q) { hipFree(*q); *q = nullptr; }
+    p->arc_rec_cap = 0;
+    {
+        // The sizes of the angle-dependent tables (TrajTables: built below, once everything they read is in place, and again by
+        // tron_plan_retarget) and everything the centre kernel needs that does NOT depend on the angles.
+        const size_t nwin = cfg->golden_angle ? (size_t)p->share_nz : 1;
+        const int npe = d.npe1work, nt32 = (d.nxos / kBinnedTile) * (d.nxos / kBinnedTile);
+        {   // centre kernel: the 2x2 blocks of the origin-centred 32 x 32 square that a sample |r| < inner_r0 can reach, nearest the
+            // origin (most spokes) first
+            std::vector<int> groups;
+            const float reach = (float)(p->relief_r0 - 1) + cfg->kernwidth + 1.0f;
+            auto d2 = [](int g) { const float x = 2.f * (g & 255) - 15.f, y = 2.f * (g >> 8) - 15.f; return x * x + y * y; };   // block centre
+            for (int j = 0; j < 16; ++j)
+                for (int i = 0; i < 16; ++i) {
+                    const float ax = fabsf(2.f * i - 15.f) - 0.5f, ay = fabsf(2.f * j - 15.f) - 0.5f;                           // its nearest point
+                    if (ax * ax + ay * ay <= reach * reach) groups.push_back(i | (j << 8));
+                }
+            std::stable_sort(groups.begin(), groups.end(), [&](int a, int b) { return d2(a) < d2(b); });
+            // per block: the band of its four points (src/tron.cu:498-502) as masks over |r| and the largest |r| < inner_r0
+            // inside it; a block no such sample reaches is dropped
+            std::vector<uint32_t> grec;
+            {
+                std::vector<int> kept;
+                const int n = d.nxos, h = n / 2;
+                for (int g : groups) {
+                    const int X0 = 2 * (g & 255) - 16, Y0 = 2 * (g >> 8) - 16;
+                    uint32_t bm[4];
+                    int bandhi = -1, bandlo = 1 << 20;
+                    for (int q = 0; q < 4; ++q) {
+                        const int X = X0 + (q & 1), Y = Y0 + (q >> 1);
+                        const uint32_t bnd = band[(size_t)(Y + h) * n + (X + h)];
+                        const int lo = (int)(bnd & 0xffffu), hi = std::min((int)(bnd >> 16), 31);
+                        bm[q] = 0u;
+                        if (lo <= hi) {
+                            bm[q] = (0xffffffffu >> (31 - (hi - lo))) << lo;
+                            bandhi = std::max(bandhi, hi);
+                            bandlo = std::min(bandlo, lo);
+                        }
+                    }
+                    const int rcap = std::min(p->relief_r0 - 1, bandhi);
+                    if (bandlo > rcap) continue;
+                    kept.push_back(g);
+                    const uint32_t rec[8] = {(uint32_t)g, (uint32_t)rcap, 0u, 0u, bm[0], bm[1], bm[2], bm[3]};
+                    grec.insert(grec.end(), rec, rec + 8);
+                }
+                groups.swap(kept);
+            }
+            // the angular window of every block's run of a window's sorted list (geometry only); the runs themselves are TrajTables'
+            std::vector<float> gwin(4 * groups.size());
+            build_centre_group_windows(groups.data(), (int)groups.size(), cfg->kernwidth, gwin.data());
+            if ((rc = upload(&p->d_cen_gwin, gwin.data(), gwin.size() * sizeof(float)))) return rc;
+            // A block next to the origin meets every spoke, one at the rim 50: a busy block is worked on in up to four PARTS (runs
+            // of its window, ~128 spokes each), so that no work item is much longer than the others -- the longest one is the
+            // floor under a launch (40 us for a whole window of 400 spokes, against 55 us for a launch of 32 slices).
+            // Launches of fewer than 64 slices only (cen_parts_below): 32 slices 56 -> 41 us; a launch of 128 has enough
+            // items to hide its longest ones and pays for the parts' hand-over instead (115 -> 122 us), so it takes whole blocks.
+            // (Parts by the EXPECTED share of a window's spokes, gwin[4 g + 3]: the same lists whatever the angles, so a retargeted
+            //  plan sums in the order a fresh one would.  Until round 5 the mean over the plan's windows decided.)
+            const int nblocks = (int)groups.size();
+            std::vector<uint32_t> units, whole;
+            int nheavy = 0;
+            for (int g = 0; g < nblocks; ++g) {
+                const double mean = (double)gwin[4 * (size_t)g + 3] * npe;
+                const int per_part = 200;
+                const int parts = std::max(1, std::min(4, (int)ceil(mean / per_part)));
+                const int heavy = parts > 1 ? nheavy++ : 0;
+                const uint32_t *r = &grec[8 * (size_t)g];
+                for (int q = 0; q < parts; ++q) {
+                    const uint32_t rec[8] = {r[0], r[1], (uint32_t)q | ((uint32_t)parts << 8) | ((uint32_t)heavy << 16), (uint32_t)g, r[4], r[5], r[6], r[7]};
+                    units.insert(units.end(), rec, rec + 8);
+                }
+                const uint32_t rec[8] = {r[0], r[1], 1u << 8, (uint32_t)g, r[4], r[5], r[6], r[7]};
+                whole.insert(whole.end(), rec, rec + 8);
+            }
+            p->cen_nblocks = nblocks;
+            p->cen_nheavy = nheavy;
+            p->cen_ngroups = nblocks;
+            p->cen_nunits_parts = (int)(units.size() / 8);
+            if ((rc = upload(&p->d_cen_grec, whole.data(), whole.size() * sizeof(uint32_t)))) return rc;
+            if ((rc = upload(&p->d_cen_grec_parts, units.data(), units.size() * sizeof(uint32_t)))) return rc;
+            const size_t slots = (size_t)p->chunk_cap * (size_t)(p->nchan <= 4 ? 1 : (p->nchan + 7) / 8) * (size_t)nheavy;
+            if (hipMalloc(reinterpret_cast<void **>(&p->d_cen_ticket), (8 * 16 + slots) * sizeof(unsigned)) != hipSuccess ||
+                (slots > 0 && hipMalloc(reinterpret_cast<void **>(&p->d_cen_parts), slots * 4 * 64 * sizeof(float)) != hipSuccess))
+                return (fail(TRON_ERR_NOMEM, "centre kernel work counters"));
+        }
+        // Windows of more than kArcMaxNpe spokes: the run tables are built, and the arc kernel run, once per PASS over the spokes
+        // [q sub, (q + 1) sub) of every window (each pass's list = the sorted list with the other spokes left out); the passes
+        // after the first add to the grid.  The centre kernel takes the whole window at once.
+        const int npass = (npe + kArcMaxNpe - 1) / kArcMaxNpe, sub = (npe + npass - 1) / npass;
+        p->arc_passes = npass;
+        p->arc_nwin = nwin;
+        p->arc_pass_npe = sub;
+        // a spoke crosses at most 2 * nxos / 32 + 3 tiles (+ their halos): 56 run entries per spoke bound every window
+        p->arc_cap = sub * (2 * (d.nxos / kBinnedTile) + 24);
+        p->arc_nrec = p->scatter ? 32767 : grid_arc_nrec(p->nchan, cfg->input_half);      // (scatter kernel: one batch per run)
+        // Scatter kernel: 64 x 64 tiles where the grid's centre is a corner of four of them, the channels go one per pass (two channels
+        // per pass would need 100 KB of sums) and a centre tile's run -- ~0.6 of a window's spokes -- fits the 512 run entries
+        p->scat_tile = 32;
+        if (p->scatter && p->nchan != 2 && (d.nxos / 2) % 64 == 0 && d.nxos >= 256 && sub <= 800 && p->scat_tile_max >= 64) p->scat_tile = 64;
+        if (const char *e = tuning_env("TRON_SCAT_TILE")) { if (atoi(e) == 32 || (atoi(e) == 64 && (d.nxos / 2) % 64 == 0 && p->nchan != 2 && p->scat_tile_max >= 64)) p->scat_tile = atoi(e); }
+        p->arc_ntiles = p->scatter && p->scat_tile == 64 ? (size_t)(d.nxos / 64) * (d.nxos / 64) : (size_t)nt32;
+        if (p->scatter && p->scat_tile == 64) {
+            std::vector<int> o64;
+            build_tile_order(d.nxos, 64, o64);
+            if ((rc = upload(&p->d_tile_order64, o64.data(), o64.size() * sizeof(int)))) return rc;
+        }
+        // scatter kernel's member tables: one byte per record of every run + 16 bits per group of 64 records.  A spoke holds nxos - 1
+        // radii (whatever its readout length), a record lies in 1.13 (64-tiles) to 1.27 (32-tiles) runs on average, a little more where few
+        // spokes make the corner segments count, every run ends on a partly filled group (+ slack: the kernel copies whole rounds)
+        if (p->scatter) p->arc_rec_cap = (int)(((size_t)sub * d.nxos * 3 / 2) / 64 + p->arc_ntiles + 16);
+    }
+    return rc;
+}
+
 extern "C" int tron_plan_create(tron_plan **out, const tron_config *cfg, const tron_dims *dims)
 {
     if (!out || !cfg || !dims) return fail(TRON_ERR_INVALID, "tron_plan_create: null argument");
@@ -59,13 +184,16 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
 {
     if (!out || !cfg || !dims) return fail(TRON_ERR_INVALID, "tron_plan_create: null argument");
     *out = nullptr;
-    // Test hook (TRON_TUNING=1 only): TRON_INJECT_COLD_FAULT=<path> makes the FIRST plan creation on a box fail -- the process that
+    // Test hook (TRON_TUNING=1 only): TRON_DEBUG=cold_fault=<path> makes the FIRST plan creation on a box fail -- the process that
     // finds <path> missing creates it and fails; every later one runs normally.  That is the shape of the cold-start faults of
     // DESIGN.md 4.5 (first GPU process on a fresh box), and tests/test_gpu_cold_start.py uses it to prove that such a fault is seen.
-    if (const char *mark = tuning_env("TRON_INJECT_COLD_FAULT")) {
-        if (access(mark, F_OK) != 0) {
-            if (FILE *f = fopen(mark, "w")) fclose(f);
-            return fail(TRON_ERR_HIP, "injected cold-start fault (TRON_INJECT_COLD_FAULT=%s)", mark);
+    // (O_CREAT | O_EXCL: exactly one creator fails, however many plans -- tron_recon_radial2d_multi's workers -- are created at once)
+    std::string mark;
+    if (debug_token("cold_fault", &mark) && !mark.empty()) {
+        const int fd = open(mark.c_str(), O_CREAT | O_EXCL | O_WRONLY, 0644);
+        if (fd >= 0) {
+            close(fd);
+            return fail(TRON_ERR_HIP, "injected cold-start fault (TRON_DEBUG=cold_fault=%s)", mark.c_str());
         }
     }
     const tron_dims &d = *dims;
@@ -119,6 +247,7 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
     HIP_TRY(warm_degrid_tile());
     HIP_TRY(warm_degrid_stream());
     HIP_TRY(warm_cgnr());
+    HIP_TRY(warm_traj());
     HIP_TRY(hipDeviceSynchronize());
     const double t_runtime = since();                // HIP runtime + code objects (the first plan of a process pays for both)
 
@@ -148,29 +277,22 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
     size_t auto_chunk = std::max<size_t>(1, ((size_t)2 << 30) / per_unit);   // (2 GiB: 128 slices x 8 coils; +5 % over 64-slice launches with the arc kernel)
     if (auto_chunk < 64) auto_chunk = std::max<size_t>(auto_chunk, std::min<size_t>(64, ((size_t)6 << 30) / per_unit));
     int chunk = cfg->chunk_slices > 0 ? cfg->chunk_slices : (int)std::max<size_t>(1, auto_chunk);
-    if (const char *env = tuning_env("TRON_CHUNK_SLICES")) chunk = std::max(1, atoi(env));
     p->chunk = std::max(1, std::min(chunk, std::max(units, 1)));
     p->chunk_cap = std::max(p->chunk, std::min(std::max(units, 1), p->chunk + p->chunk / 2));
     if (!cfg->adjoint) p->chunk = p->chunk_cap = std::max(1, chunk);
 
     int rc = TRON_OK;
-    double t_arc0 = 0.0, t_arc1 = 0.0;
     auto bail = [&](int code) { tron_plan_destroy(p); return code; };
     if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess)
         return bail(fail(TRON_ERR_HIP, "hipStreamCreate failed"));
 
     p->ntrig = trig_table_size(*cfg, d);
-    {
-        std::vector<float> trig(2 * p->ntrig);
-        build_trig_table(*cfg, d, trig.data(), p->ntrig);
-        if ((rc = upload(&p->d_trig, trig.data(), trig.size() * sizeof(float)))) return bail(rc);
-    }
     {   // 32x32 tiles, centre first: binned gridding and tiled degridding
         std::vector<int> order;
         build_tile_order(d.nxos, kBinnedTile, order);
         if ((rc = upload(&p->d_tile_order32, order.data(), order.size() * sizeof(int)))) return bail(rc);
         if (!cfg->adjoint || cfg->niter > 0) {      // CGNR (an adjoint plan) runs the forward operator too: its centre tiles need the short runs as well
-            static const int target = tuning_env("TRON_DEGRID_RUN") ? atoi(tuning_env("TRON_DEGRID_RUN")) : 24000;   // tuning knob: samples per run
+            const int target = 24000;                                         // samples per run of images of one tile (degrid_stream_kernel)
             build_degrid_groups(d.nxos, kBinnedTile, d.npe1work, d.nro, target, p->dg_group_end);
         }
     }
@@ -178,27 +300,16 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
         std::vector<uint32_t> band(n2);
         build_band_table(d.nxos, cfg->kernwidth, band.data());
         if ((rc = upload(&p->d_band, band.data(), band.size() * sizeof(uint32_t)))) return bail(rc);
-        std::vector<int> order;
-        build_tile_order(d.nxos, kTile, order);
         p->tiles_per_row = (d.nxos + kTile - 1) / kTile;
-        p->ntiles = (int)order.size();
-        if ((rc = upload(&p->d_tile_order, order.data(), order.size() * sizeof(int)))) return bail(rc);
+        p->ntiles = p->tiles_per_row * p->tiles_per_row;
         p->binned = p->kb_mode == TRON_KB_FAST && cfg->kernwidth <= 3.f;
         if (const char *gk = tuning_env("TRON_GRID_KERNEL")) p->binned = p->binned && strcmp(gk, "gather") != 0;
+        if (!p->binned) {                                                 // the order-preserving gather kernel's 16 x 16 tiles, centre first
+            std::vector<int> order;
+            build_tile_order(d.nxos, kTile, order);
+            if ((rc = upload(&p->d_tile_order, order.data(), order.size() * sizeof(int)))) return bail(rc);
+        }
         if (p->binned) {
-            std::vector<int> sorder, slots;
-            int target = 2500;                                            // records per workgroup and image
-            if (const char *e = tuning_env("TRON_SPLIT_TARGET")) target = std::max(64, atoi(e));
-            p->max_parts = 8;
-            build_split_tile_order(d.nxos, kBinnedTile, d.npe1work, cfg->kernwidth, target, p->max_parts, sorder, slots);
-            p->split_entries = (int)sorder.size();
-            p->nsplit_slots = (int)slots.size();
-            p->split_below = 64;                                          // launches of fewer slices use the split list
-            if (const char *e = tuning_env("TRON_SPLIT_BELOW")) p->split_below = atoi(e);
-            if (p->nsplit_slots > 0) {
-                if ((rc = upload(&p->d_tile_order32_split, sorder.data(), sorder.size() * sizeof(int)))) return bail(rc);
-                if ((rc = upload(&p->d_split_slots, slots.data(), slots.size() * sizeof(int)))) return bail(rc);
-            }
             // centre relief: the samples next to the k-space centre get workgroups of their own (tron_grid_binned.hip)
             std::vector<int> rorder, rslots;
             int r0 = 0;
@@ -220,9 +331,21 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
                     if ((rc = upload(&p->d_tile_order32_relief_small, sorder.data(), sorder.size() * sizeof(int)))) return bail(rc);
                     if ((rc = upload(&p->d_relief_slots_small, sslots.data(), sslots.size() * sizeof(int)))) return bail(rc);
                 }
+            } else {
+                // no centre relief (small grids, TRON_CENTRE_RELIEF=0): small launches split the k-space-centre tiles over spoke ranges instead
+                std::vector<int> sorder, slots;
+                const int target = 2500;                                  // records per workgroup and image
+                p->max_parts = 8;
+                build_split_tile_order(d.nxos, kBinnedTile, d.npe1work, cfg->kernwidth, target, p->max_parts, sorder, slots);
+                p->split_entries = (int)sorder.size();
+                p->nsplit_slots = (int)slots.size();
+                p->split_below = 64;                                      // launches of fewer slices use the split list
+                if (const char *e = tuning_env("TRON_SPLIT_BELOW")) p->split_below = atoi(e);
+                if (p->nsplit_slots > 0) {
+                    if ((rc = upload(&p->d_tile_order32_split, sorder.data(), sorder.size() * sizeof(int)))) return bail(rc);
+                    if ((rc = upload(&p->d_split_slots, slots.data(), slots.size() * sizeof(int)))) return bail(rc);
+                }
             }
-            t_arc0 = since();
-            t_arc1 = t_arc0;
             // arc kernel: everything but the inner tile, when the trajectory and the sample layout allow it
             p->arc = p->relief_entries > 0 && grid_arc_supported(p->nchan, d.nxos, d.nro, d.npe1work, cfg->kernwidth, cfg->input_half);
             // one or two channels: lane = sample, fixed-point sums in LDS (tron_grid_scatter.hip) on the arc kernel's tables
@@ -237,6 +360,7 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
                 p->scatter = p->scatter && strcmp(gk, "binned") != 0 && strcmp(gk, "arc") != 0;
                 p->arc = p->arc && strcmp(gk, "binned") != 0;
             }
+            p->relief_r0_binned = p->relief_r0;
             if (p->scatter) {
                 p->arc = true;
                 // The arc formulation starves next to the k-space centre (a block there meets every spoke), which is why the samples |r| < 14 have
@@ -245,248 +369,22 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
                 // (A centre tile's run holds every spoke whose line is inside tile + W at radius r0: the quadrant's 90 degrees + 2 asin(W sqrt(2) / r0) --
                 // 0.76 of a window's spokes at r0 = 5, 0.59 at 14 -- and a run has 512 entries: windows (passes) of more than 640 spokes keep 14.)
                 const int npass_ = (d.npe1work + kArcMaxNpe - 1) / kArcMaxNpe, sub_ = (d.npe1work + npass_ - 1) / npass_;
-                int r0 = sub_ <= 640 ? 5 : p->relief_r0;
-                if (const char *e = tuning_env("TRON_SCAT_R0")) r0 = std::max(3, std::min(atoi(e), p->relief_r0));
+                const int r0 = sub_ <= 640 ? 5 : p->relief_r0;
                 p->relief_r0 = std::min(p->relief_r0, r0);
             }
-            if (p->arc) {
-                // plan-time pass: every window's spokes sorted by line angle (host), clipped against every tile and dealt
-                // into batches (arc_prep_kernel); the sorted lists are scratch
-                const size_t nwin = cfg->golden_angle ? (size_t)p->share_nz : 1;
-                const size_t win_first = cfg->golden_angle ? (size_t)p->share_z0 : 0;
-                const int npe = d.npe1work, nt32 = (d.nxos / kBinnedTile) * (d.nxos / kBinnedTile);
-                std::vector<float> trig(2 * p->ntrig);
-                build_trig_table(*cfg, d, trig.data(), p->ntrig);
-                std::vector<unsigned short> order(nwin * npe);
-                std::vector<float> phi(nwin * npe);
-                build_arc_tables(trig.data() + 2 * win_first * (size_t)d.prof_slide, nwin, (size_t)d.prof_slide, npe, order.data(), phi.data());
-                {   // centre kernel: the 2x2 blocks of the origin-centred 32 x 32 square that a sample |r| < inner_r0 can reach, nearest the
-                    // origin (most spokes) first
-                    std::vector<int> groups;
-                    const float reach = (float)(p->relief_r0 - 1) + cfg->kernwidth + 1.0f;
-                    auto d2 = [](int g) { const float x = 2.f * (g & 255) - 15.f, y = 2.f * (g >> 8) - 15.f; return x * x + y * y; };   // block centre
-                    for (int j = 0; j < 16; ++j)
-                        for (int i = 0; i < 16; ++i) {
-                            const float ax = fabsf(2.f * i - 15.f) - 0.5f, ay = fabsf(2.f * j - 15.f) - 0.5f;                           // its nearest point
-                            if (ax * ax + ay * ay <= reach * reach) groups.push_back(i | (j << 8));
-                        }
-                    std::stable_sort(groups.begin(), groups.end(), [&](int a, int b) { return d2(a) < d2(b); });
-                    // per block: the band of its four points (src/tron.cu:498-502) as masks over |r| and the largest |r| < inner_r0
-                    // inside it; a block no such sample reaches is dropped
-                    std::vector<uint32_t> grec;
-                    {
-                        std::vector<int> kept;
-                        const int n = d.nxos, h = n / 2;
-                        for (int g : groups) {
-                            const int X0 = 2 * (g & 255) - 16, Y0 = 2 * (g >> 8) - 16;
-                            uint32_t bm[4];
-                            int bandhi = -1, bandlo = 1 << 20;
-                            for (int q = 0; q < 4; ++q) {
-                                const int X = X0 + (q & 1), Y = Y0 + (q >> 1);
-                                const uint32_t bnd = band[(size_t)(Y + h) * n + (X + h)];
-                                const int lo = (int)(bnd & 0xffffu), hi = std::min((int)(bnd >> 16), 31);
-                                bm[q] = 0u;
-                                if (lo <= hi) {
-                                    bm[q] = (0xffffffffu >> (31 - (hi - lo))) << lo;
-                                    bandhi = std::max(bandhi, hi);
-                                    bandlo = std::min(bandlo, lo);
-                                }
-                            }
-                            const int rcap = std::min(p->relief_r0 - 1, bandhi);
-                            if (bandlo > rcap) continue;
-                            kept.push_back(g);
-                            const uint32_t rec[8] = {(uint32_t)g, (uint32_t)rcap, 0u, 0u, bm[0], bm[1], bm[2], bm[3]};
-                            grec.insert(grec.end(), rec, rec + 8);
-                        }
-                        groups.swap(kept);
-                    }
-                    std::vector<uint32_t> wnd(nwin * groups.size());
-                    build_centre_windows(phi.data(), nwin, npe, groups.data(), (int)groups.size(), cfg->kernwidth, wnd.data());
-                    if ((rc = upload(&p->d_cen_win, wnd.data(), wnd.size() * sizeof(uint32_t)))) return bail(rc);
-                    // A block next to the origin meets every spoke, one at the rim 50: a busy block is worked on in up to four PARTS (runs
-                    // of its window, ~128 spokes each), so that no work item is much longer than the others -- the longest one is the
-                    // floor under a launch (40 us for a whole window of 400 spokes, against 55 us for a launch of 32 slices).
-                    // Launches of fewer than 64 slices only (TRON_CEN_PART_BELOW): 32 slices 56 -> 41 us; a launch of 128 has enough
-                    // items to hide its longest ones and pays for the parts' hand-over instead (115 -> 122 us), so it takes whole blocks.
-                    const int nblocks = (int)groups.size();
-                    std::vector<uint32_t> units, whole;
-                    int nheavy = 0;
-                    for (int g = 0; g < nblocks; ++g) {
-                        double mean = 0.0;
-                        for (size_t w = 0; w < nwin; ++w) mean += (double)(wnd[w * nblocks + g] >> 16);
-                        mean /= (double)nwin;
-                        static const int per_part = tuning_env("TRON_CEN_PART") ? std::max(16, atoi(tuning_env("TRON_CEN_PART"))) : 200;   // tuning knob
-                        const int parts = std::max(1, std::min(4, (int)ceil(mean / per_part)));
-                        const int heavy = parts > 1 ? nheavy++ : 0;
-                        const uint32_t *r = &grec[8 * (size_t)g];
-                        for (int q = 0; q < parts; ++q) {
-                            const uint32_t rec[8] = {r[0], r[1], (uint32_t)q | ((uint32_t)parts << 8) | ((uint32_t)heavy << 16), (uint32_t)g, r[4], r[5], r[6], r[7]};
-                            units.insert(units.end(), rec, rec + 8);
-                        }
-                        const uint32_t rec[8] = {r[0], r[1], 1u << 8, (uint32_t)g, r[4], r[5], r[6], r[7]};
-                        whole.insert(whole.end(), rec, rec + 8);
-                    }
-                    p->cen_nblocks = nblocks;
-                    p->cen_nheavy = nheavy;
-                    p->cen_ngroups = nblocks;
-                    p->cen_nunits_parts = (int)(units.size() / 8);
-                    if ((rc = upload(&p->d_cen_grec, whole.data(), whole.size() * sizeof(uint32_t)))) return bail(rc);
-                    if ((rc = upload(&p->d_cen_grec_parts, units.data(), units.size() * sizeof(uint32_t)))) return bail(rc);
-                    if (const char *e = tuning_env("TRON_CEN_PART_BELOW")) p->cen_parts_below = atoi(e);
-                    const size_t slots = (size_t)p->chunk_cap * (size_t)(p->nchan <= 4 ? 1 : (p->nchan + 7) / 8) * (size_t)nheavy;
-                    if (hipMalloc(reinterpret_cast<void **>(&p->d_cen_ticket), (8 * 16 + slots) * sizeof(unsigned)) != hipSuccess ||
-                        (slots > 0 && hipMalloc(reinterpret_cast<void **>(&p->d_cen_parts), slots * 4 * 64 * sizeof(float)) != hipSuccess))
-                        return bail(fail(TRON_ERR_NOMEM, "centre kernel work counters"));
-                }
-                std::vector<float> scs(2 * order.size());
-                for (size_t w = 0; w < nwin; ++w)
-                    for (int k = 0; k < npe; ++k) {
-                        const size_t src = (cfg->golden_angle ? (win_first + w) * (size_t)d.prof_slide : 0) + order[w * npe + k];
-                        scs[2 * (w * npe + k)] = trig[2 * src];
-                        scs[2 * (w * npe + k) + 1] = trig[2 * src + 1];
-                    }
-                // Windows of more than kArcMaxNpe spokes: the run tables are built, and the arc kernel run, once per PASS over the spokes
-                // [q sub, (q + 1) sub) of every window (each pass's list = the sorted list with the other spokes left out); the passes
-                // after the first add to the grid.  The centre kernel takes the whole window at once.
-                const int npass = (npe + kArcMaxNpe - 1) / kArcMaxNpe, sub = (npe + npass - 1) / npass;
-                p->arc_passes = npass;
-                p->arc_nwin = nwin;
-                p->arc_pass_npe = sub;
-                unsigned short *d_order = nullptr;
-                float *d_scs = nullptr;
-                // a spoke crosses at most 2 * nxos / 32 + 3 tiles (+ their halos): 56 run entries per spoke bound every window
-                p->arc_cap = sub * (2 * (d.nxos / kBinnedTile) + 24);
-                p->arc_nrec = p->scatter ? 32767 : grid_arc_nrec(p->nchan, cfg->input_half);      // (scatter kernel: one batch per run)
-                // Scatter kernel: 64 x 64 tiles where the grid's centre is a corner of four of them, the channels go one per pass (two channels
-                // per pass would need 100 KB of sums) and a centre tile's run -- ~0.6 of a window's spokes -- fits the 512 run entries
-                p->scat_tile = 32;
-                if (p->scatter && p->nchan != 2 && (d.nxos / 2) % 64 == 0 && d.nxos >= 256 && sub <= 800) p->scat_tile = 64;
-                if (const char *e = tuning_env("TRON_SCAT_TILE")) { if (atoi(e) == 32 || (atoi(e) == 64 && (d.nxos / 2) % 64 == 0 && p->nchan != 2)) p->scat_tile = atoi(e); }
-                const size_t nt_tab = p->scatter && p->scat_tile == 64 ? (size_t)(d.nxos / 64) * (d.nxos / 64) : (size_t)nt32;
-                if (p->scatter && p->scat_tile == 64) {
-                    std::vector<int> o64;
-                    build_tile_order(d.nxos, 64, o64);
-                    if ((rc = upload(&p->d_tile_order64, o64.data(), o64.size() * sizeof(int)))) return bail(rc);
-                }
-                rc = upload(&d_order, order.data(), order.size() * sizeof(unsigned short));
-                if (!rc) rc = upload(&d_scs, scs.data(), scs.size() * sizeof(float));
-                p->d_cen_order = d_order;                       // the sorted lists stay: centre kernel
-                p->d_cen_cs = reinterpret_cast<float2 *>(d_scs);
-                const size_t ntab = nwin * (size_t)npass;       // tables [pass][window]
-                if (!rc && (hipMalloc(reinterpret_cast<void **>(&p->d_arc_hdr), ntab * nt_tab * sizeof(int4)) != hipSuccess ||
-                            hipMalloc(reinterpret_cast<void **>(&p->d_arc_ent), ntab * p->arc_cap * sizeof(uint4)) != hipSuccess ||
-                            (p->scatter ? hipMalloc(reinterpret_cast<void **>(&p->d_arc_off), ntab * p->arc_cap * sizeof(uint32_t))        // (scatter kernel: offsets, no thread windows)
-                                        : hipMalloc(reinterpret_cast<void **>(&p->d_arc_win), ntab * nt32 * 256 * sizeof(uint32_t))) != hipSuccess))
-                    rc = fail(TRON_ERR_NOMEM, "cannot allocate the arc kernel's run tables");
-                if (!rc && p->scatter) {
-                    // one byte per record of every run (its member; arc_prep_kernel) + 16 bits per 64 records: a sample lies in 1.13 (64-tiles) to
-                    // 1.27 (32-tiles) runs on average, a little more where few spokes make the corner segments count; runs are padded to 64
-                    // groups of 64 records per window: a spoke holds nxos - 1 radii (whatever its readout length), a record lies in 1.13-1.27
-                    // runs on average, every run ends on a partly filled group (+ slack: the kernel copies whole rounds)
-                    p->arc_rec_cap = (int)(((size_t)sub * d.nxos * 3 / 2) / 64 + nt_tab + 16);
-                    if (hipMalloc(reinterpret_cast<void **>(&p->d_arc_rec), (ntab * (size_t)p->arc_rec_cap + 16) * 80) != hipSuccess ||
-                        hipMalloc(reinterpret_cast<void **>(&p->d_arc_rbase), ntab * nt_tab * sizeof(int)) != hipSuccess)
-                        rc = fail(TRON_ERR_NOMEM, "cannot allocate the scatter kernel's record tables");
-                }
-                if (rc) return bail(rc);
-                unsigned int zero = 0;
-                if ((rc = upload(&p->d_errflag, &zero, sizeof(zero)))) return bail(rc);
-                hipError_t he = hipSuccess;
-                for (int q = 0; q < npass && he == hipSuccess && !rc; ++q) {
-                    const int lo = q * sub, hi = std::min(npe, lo + sub), nq = hi - lo;
-                    std::vector<unsigned short> order_q;
-                    std::vector<float> phi_q, scs_q;
-                    const unsigned short *ho = order.data();
-                    const float *hp = phi.data(), *hs = scs.data();
-                    if (npass > 1) {
-                        order_q.resize(nwin * nq); phi_q.resize(nwin * nq); scs_q.resize(2 * nwin * nq);
-                        for (size_t w = 0; w < nwin; ++w) {
-                            size_t o = w * nq;
-                            for (int k = 0; k < npe; ++k) {
-                                const unsigned short pe = order[w * npe + k];
-                                if (pe < lo || pe >= hi) continue;
-                                order_q[o] = pe; phi_q[o] = phi[w * npe + k];
-                                scs_q[2 * o] = scs[2 * (w * npe + k)]; scs_q[2 * o + 1] = scs[2 * (w * npe + k) + 1];
-                                ++o;
-                            }
-                        }
-                        ho = order_q.data(); hp = phi_q.data(); hs = scs_q.data();
-                    }
-                    unsigned short *dq_order = nullptr;
-                    float *dq_phi = nullptr, *dq_scs = nullptr;
-                    int *d_alloc = nullptr;
-                    auto drop = [&]() { hipFree(d_alloc); hipFree(dq_phi); if (npass > 1) { hipFree(dq_order); hipFree(dq_scs); } };
-                    if (npass > 1) {
-                        rc = upload(&dq_order, ho, nwin * nq * sizeof(unsigned short));
-                        if (!rc) rc = upload(&dq_scs, hs, 2 * nwin * nq * sizeof(float));
-                    } else {
-                        dq_order = d_order; dq_scs = d_scs;
-                    }
-                    if (!rc) rc = upload(&dq_phi, hp, nwin * nq * sizeof(float));
-                    if (!rc && hipMalloc(reinterpret_cast<void **>(&d_alloc), 2 * nwin * sizeof(int)) != hipSuccess) rc = fail(TRON_ERR_NOMEM, "arc tables");
-                    if (rc) { drop(); break; }
-                    // ON THE PLAN'S STREAM: a memset of device memory on the null stream returns before it has run, and a non-blocking stream
-                    // does not wait for it -- arc_prep_kernel then handed out run-table space from whatever the allocation held (round 3's
-                    // `hipMemset`: tables that overlapped, or an overflow flag and a silent fall-back to the binned kernel; one first process
-                    // in three on a fresh box, most runs with eight plans being created at once)
-                    if (hipMemsetAsync(d_alloc, 0, 2 * nwin * sizeof(int), p->stream) != hipSuccess) { drop(); rc = fail(TRON_ERR_HIP, "hipMemsetAsync failed"); break; }
-                    ArcPrepParams ap;
-                    ap.order = dq_order; ap.phi = dq_phi; ap.cs = reinterpret_cast<const float2 *>(dq_scs);
-                    ap.hdr = p->d_arc_hdr + (size_t)q * nwin * nt_tab; ap.ent = p->d_arc_ent + (size_t)q * nwin * p->arc_cap;
-                    ap.win = p->d_arc_win ? p->d_arc_win + (size_t)q * nwin * nt32 * 256 : nullptr; ap.band = p->d_band; ap.alloc = d_alloc; ap.errflag = p->d_errflag;
-                    ap.off = p->d_arc_off ? p->d_arc_off + (size_t)q * nwin * p->arc_cap : nullptr;
-                    ap.tile = p->scatter ? p->scat_tile : 0;
-                    ap.rec = p->d_arc_rec ? p->d_arc_rec + (size_t)q * nwin * p->arc_rec_cap * 80 : nullptr;
-                    ap.rbase = p->d_arc_rbase ? p->d_arc_rbase + (size_t)q * nwin * nt_tab : nullptr;
-                    ap.ralloc = d_alloc + nwin;
-                    ap.rec_cap = p->arc_rec_cap;
-                    ap.nxos = d.nxos; ap.nro = d.nro; ap.npe = nq; ap.ntiles = (int)nt_tab; ap.inner_r0 = p->relief_r0; ap.nrec = p->arc_nrec;
-                    ap.cap = p->arc_cap; ap.W = cfg->kernwidth; ap.flat = p->scatter ? 1 : 0;
-                    he = launch_arc_prep(ap, (int)nwin, p->stream);
-                    if (he == hipSuccess) he = hipStreamSynchronize(p->stream);
-                    drop();
-                }
-                if (rc) return bail(rc);
-                unsigned int flag = 0;
-                if (he == hipSuccess) he = hipMemcpy(&flag, p->d_errflag, sizeof(flag), hipMemcpyDeviceToHost);
-                if (he != hipSuccess) return bail(fail(TRON_ERR_HIP, "arc_prep_kernel failed: %s", hipGetErrorString(he)));
-                if (flag) {   // a trajectory the arc kernel's tables cannot hold: the binned kernel takes all tiles
-                    hipMemsetAsync(p->d_errflag, 0, sizeof(flag), p->stream);
-                    hipStreamSynchronize(p->stream);
-                    hipFree(p->d_arc_hdr); hipFree(p->d_arc_ent); hipFree(p->d_arc_win); hipFree(p->d_arc_off);
-                    hipFree(p->d_arc_rec); hipFree(p->d_arc_rbase);
-                    p->d_arc_hdr = nullptr; p->d_arc_ent = nullptr; p->d_arc_win = nullptr; p->d_arc_off = nullptr;
-                    p->d_arc_rec = nullptr; p->d_arc_rbase = nullptr;
-                    hipFree(p->d_cen_order); hipFree(p->d_cen_cs);
-                    p->d_cen_order = nullptr; p->d_cen_cs = nullptr;
-                    p->arc = false;
-                    p->scatter = false;
-                    // never silent: this is a 2x slower kernel the caller did not ask for (the shapes that go to the binned kernel by design are
-                    // listed in README.md; tron_plan_grid_kernel_name tells which one a plan runs)
-                    fprintf(stderr, "tronhip: arc tables overflowed (flag %u): falling back to the binned gridding kernel\n", flag);
-                }
-            }
+            if (p->arc && (rc = arc_setup(p, band))) return bail(rc);
             if (p->arc) {
                 std::vector<float> lut(6 * (size_t)kArcLutEntries);
                 p->lut_entries = build_kb_pair_lut(cfg->kernwidth, kArcLutEntries, lut.data(), &p->lut_scale, &p->lut_bias, &p->lut_err);
                 if (p->lut_entries <= 0) return bail(fail(TRON_ERR_UNSUPPORTED, "no Kaiser-Bessel pair table for width %g", (double)cfg->kernwidth));
                 if ((rc = upload(&p->d_kb_lut, lut.data(), lut.size() * sizeof(float)))) return bail(rc);
-                p->scat_wsum = (float)(4.0 * kb_peak(cfg->kernwidth) * kb_peak(cfg->kernwidth));
+                // what ONE spoke can add to one grid point, in units of the largest weighted sample: the window products along a line at unit
+                // spacing sum to at most 1.65 K(0)^2 for every direction and offset at W = 2 (axis 1.61, diagonal 1.65, 2 : 1 1.64; less for
+                // narrower windows) -- 1.75 with margin.  (4 K(0)^2 until round 5: one to two bits of the fixed-point sums given away)
+                p->scat_wsum = (float)(1.75 * kb_peak(cfg->kernwidth) * kb_peak(cfg->kernwidth));
                 p->arc_zper = 0;                                    // 0: by launch size (tron_pipeline.cpp)
-                if (const char *e = tuning_env("TRON_CENTRE_KERNEL")) p->centre_kernel = strcmp(e, "binned") != 0;
-                // the inner tile's workgroups are few and slow (every spoke passes the k-space centre): on a stream of their own,
-                // most urgent, they run beside the arc kernel instead of in front of it
-                if (const char *e = tuning_env("TRON_ARC_INNER_STREAM")) p->inner_beside = atoi(e) != 0;
-                int lo = 0, hi = 0;
-                hipDeviceGetStreamPriorityRange(&lo, &hi);
-                if (hipStreamCreateWithPriority(&p->stream_inner, hipStreamNonBlocking, hi) != hipSuccess ||
-                    hipEventCreateWithFlags(&p->ev_inner[0], hipEventDisableTiming) != hipSuccess ||
-                    hipEventCreateWithFlags(&p->ev_inner[1], hipEventDisableTiming) != hipSuccess)
-                    return bail(fail(TRON_ERR_HIP, "cannot create the inner-tile stream"));
-                if (const char *e = tuning_env("TRON_ARC_ZPER")) p->arc_zper = std::max(0, atoi(e));
             }
         }
-        if (p->binned) t_arc1 = since();
         std::vector<float> dea((size_t)d.nx * d.nx);
         build_deapod_table(d.nx, cfg->kernwidth, cfg->gridos, dea.data());        // src/tron.cu:635
         if ((rc = upload(&p->d_deapod, dea.data(), dea.size() * sizeof(float)))) return bail(rc);
@@ -512,7 +410,7 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
     }
     unsigned int zero = 0;
     if (!p->d_errflag && (rc = upload(&p->d_errflag, &zero, sizeof(zero)))) return bail(rc);
-    p->poison = tuning_env("TRON_POISON_GRID") != nullptr;   // tests: NaN-fill the work grid so a read of a never-written point shows up
+    p->poison = debug_token("poison");                       // tests (TRON_DEBUG=poison): NaN-fill the work grid so a read of a never-written point shows up
     if (d.nxos == 512 && d.nx == 256 && d.nyos == 512 && d.ny == 256) {
         p->fft512 = true;
         if (const char *ff = tuning_env("TRON_FFT")) p->fft512 = strcmp(ff, "rocfft") != 0;
@@ -524,48 +422,37 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
             tw[2 * k + 1] = (float)sin(2.0 * M_PI * k / 512.0);
         }
         if ((rc = upload(&p->d_tw512, tw.data(), tw.size() * sizeof(float)))) return bail(rc);
-        // Two lanes (gridding on `stream`, FFT passes on `stream2`, two Cartesian buffers): round 1 measured +2 % and left
-        // it off; with the round-2 FFT passes it is +4.9 % at 8 coils x 256 slices (+2.7 % at 6 coils, +2 % at 4, 0 at 1),
-        // so adjoint plans with at least two full batches and more than one channel have it on.  TRON_DUAL_STREAM=0/1 overrides.
-        p->dual = cfg->adjoint && p->nchan > 1 && p->share_nz >= 2 * p->chunk;
-        if (const char *ds = tuning_env("TRON_DUAL_STREAM")) p->dual = d.nz > 1 && atoi(ds) != 0;
-        if (p->dual) {
-            // TRON_CU_SPLIT=k (tuning knob): give the FFT lane every k-th CU of every XCD and the gridding lane the rest, so the two overlap
-            // in space instead of queueing behind each other.  Bit i of a stream's CU mask is CU i / 8 of XCD i % 8, and an XCD
-            // whose bits are all clear runs on all of its CUs (tools/probe/cumask.hip): the mask is built per XCD.  Measured, round 4:
-            // no split 67.6 k slices/s, k = 3: 54.0 k -- both lanes' kernels scale with the CUs they get.
-            int split = 0;
-            if (const char *cs = tuning_env("TRON_CU_SPLIT")) split = atoi(cs);
-            if (split >= 2) {
-                uint32_t mask_fft[8], mask_grid[8];
-                for (int w = 0; w < 8; ++w) { mask_fft[w] = 0; mask_grid[w] = 0; }
-                for (int bit = 0; bit < 256; ++bit) {
-                    if ((bit / 8) % split == 0) mask_fft[bit / 32] |= 1u << (bit % 32);
-                    else mask_grid[bit / 32] |= 1u << (bit % 32);
-                }
-                hipStream_t masked = nullptr;
-                if (hipExtStreamCreateWithCUMask(&p->stream2, 8, mask_fft) != hipSuccess ||
-                    hipExtStreamCreateWithCUMask(&masked, 8, mask_grid) != hipSuccess)
-                    return bail(fail(TRON_ERR_HIP, "cannot create CU-masked streams"));
-                hipStreamDestroy(p->stream);
-                p->stream = masked;
-            } else {
-                // the FFT lane's workgroups are short and light: at a higher stream priority they slip into every slot the
-                // gridding lane frees instead of queueing behind its backlog (TRON_FFT_PRIO: 0 = same priority)
-                int lo = 0, hi = 0, prio = 0;
-                hipDeviceGetStreamPriorityRange(&lo, &hi);          // lo = least urgent (numerically greatest), hi = most urgent
-                const char *fp = tuning_env("TRON_FFT_PRIO");
-                const int want = fp ? atoi(fp) : -1;                // -1: most urgent, +1: least urgent
-                prio = want < 0 ? hi : (want > 0 ? lo : 0);
-                if (hipStreamCreateWithPriority(&p->stream2, hipStreamNonBlocking, prio) != hipSuccess)
-                    return bail(fail(TRON_ERR_HIP, "cannot create the FFT lane"));
-            }
-            for (int i = 0; i < 2; ++i)
-                if (hipEventCreateWithFlags(&p->ev_g[i], hipEventDisableTiming) != hipSuccess ||
-                    hipEventCreateWithFlags(&p->ev_f[i], hipEventDisableTiming) != hipSuccess)
-                    return bail(fail(TRON_ERR_HIP, "cannot create pipeline events"));
-        }
     }
+    // The angle-dependent tables of the plan's own skip_angles: the build tron_plan_retarget repeats for later ones (tron_traj.cpp), here on
+    // the plan's stream and waited for.  Run tables that overflow (more spokes through a tile than a run holds, ...) send the plan to the
+    // next formulation down -- 64-tiles -> 32-tiles -> arc kernel -> binned kernel -- instead of straight to the binned one (round 5).
+    const double t_arc0 = since();
+    for (;;) {
+        TrajTables &T = p->traj[0];
+        if ((rc = traj_alloc(p, T)) || (rc = traj_build(p, T, cfg->skip_angles, p->stream)) || (rc = traj_finish(p, T))) return bail(rc);
+        if (T.ok || !p->arc) break;
+        // never silent: a slower kernel than the shape would normally get (tron_plan_grid_kernel_name tells which one a plan runs)
+        const bool can_arc = grid_arc_supported(p->nchan, d.nxos, d.nro, d.npe1work, cfg->kernwidth, cfg->input_half);
+        const unsigned flag = *T.h_flag;
+        if (p->scatter && p->scat_tile == 64) {
+            p->scat_tile_max = 32;
+            fprintf(stderr, "tronhip: the scatter kernel's run tables overflowed on 64 x 64 tiles (flag %u): trying 32 x 32 tiles\n", flag);
+        } else if (p->scatter && can_arc) {
+            p->scatter = false;
+            p->relief_r0 = p->relief_r0_binned;
+            fprintf(stderr, "tronhip: the scatter kernel's run tables overflowed (flag %u): trying the arc kernel\n", flag);
+        } else {
+            p->arc = p->scatter = false;                      // the binned kernel takes every tile; later retargets rebuild the (cos, sin) table only
+            p->relief_r0 = p->relief_r0_binned;
+            fprintf(stderr, "tronhip: run tables overflowed (flag %u): falling back to the binned gridding kernel\n", flag);
+            break;
+        }
+        traj_free(T);
+        std::vector<uint32_t> band(n2);
+        build_band_table(d.nxos, cfg->kernwidth, band.data());
+        if ((rc = arc_setup(p, band))) return bail(rc);
+    }
+    const double t_arc1 = since();
     const double t_tables = since();
     // adjoint: the whole batch now (an out-of-memory plan fails here, not mid-run); forward: on first use, sized by the call
     if (cfg->adjoint && (rc = ensure_work(p, p->chunk_cap))) return bail(rc);
@@ -586,16 +473,13 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
                since(), t_runtime, t_tables - t_runtime, t_arc1 - t_arc0, t_work - t_tables);
     if (cfg->verbose) printf("tronhip: of the start-up, the HIP runtime itself %.3f s, loading the code objects %.3f s\n", t_hipinit, t_runtime - t_hipinit);
     }
-    if (const char *se = tuning_env("TRON_SYNC_EACH")) p->sync_each = atoi(se) != 0;
-    p->debug_skip = 0;
-    if (const char *dbg = tuning_env("TRON_DEBUG_SKIP")) p->debug_skip = atoi(dbg);
-    p->degrid_simple = tuning_env("TRON_DEGRID_SIMPLE") != nullptr;
-    p->degrid_tile_only = tuning_env("TRON_DEGRID_TILE") != nullptr;      // tuning knob: never the streaming degridding kernel
+    p->sync_each = debug_token("sync");                      // TRON_DEBUG=sync: synchronise after every stage and name the failing one
+    if (const char *dk = tuning_env("TRON_DEGRID_KERNEL")) {     // simple: the thread-per-sample audit kernel; tile: never the streaming kernel
+        p->degrid_simple = strcmp(dk, "simple") == 0;
+        p->degrid_tile_only = strcmp(dk, "tile") == 0;
+    }
     if (const char *sp = tuning_env("TRON_SLICES_PER_PASS")) p->slices_per_pass = atoi(sp) != 0;
-    if (const char *lp = tuning_env("TRON_GRID_LDS_PAD")) p->grid_lds_pad = atoi(lp);
-    p->no_disc = tuning_env("TRON_NO_DISC") != nullptr;
     p->pin_host = cfg->pin_host != 0;
-    if (const char *ph = tuning_env("TRON_PIN_HOST")) p->pin_host = atoi(ph) != 0;
     *out = p;
     return TRON_OK;
 }
@@ -605,7 +489,7 @@ extern "C" int tron_plan_destroy(tron_plan *p)
     if (!p) return TRON_OK;
     hipSetDevice(p->cfg.device);
     if (p->stream) hipStreamSynchronize(p->stream);
-    if (p->stream2) hipStreamSynchronize(p->stream2);
+    if (p->stream_build) hipStreamSynchronize(p->stream_build);
     for (int s = 0; s < STAGE_COUNT; ++s)
         for (auto &pr : p->ev[s]) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     for (auto &kv : p->fft) {
@@ -613,7 +497,8 @@ extern "C" int tron_plan_destroy(tron_plan *p)
         if (kv.second.plan) rocfft_plan_destroy(kv.second.plan);
         if (kv.second.work) hipFree(kv.second.work);
     }
-    hipFree(p->d_trig);
+    traj_free(p->traj[0]);
+    traj_free(p->traj[1]);
     hipFree(p->d_band);
     hipFree(p->d_tile_order);
     hipFree(p->d_tile_order32);
@@ -622,13 +507,8 @@ extern "C" int tron_plan_destroy(tron_plan *p)
     hipFree(p->d_trig_fwd);
     hipFree(p->d_cg_r); hipFree(p->d_cg_v); hipFree(p->d_cg_zt); hipFree(p->d_cg_pt); hipFree(p->d_cg_x);
     hipFree(p->d_cg_partial); hipFree(p->d_cg_num); hipFree(p->d_cg_coef);
-    hipFree(p->d_arc_hdr);
-    hipFree(p->d_arc_ent);
-    hipFree(p->d_arc_win);
     hipFree(p->d_kb_lut);
-    hipFree(p->d_cen_order);
-    hipFree(p->d_cen_win);
-    hipFree(p->d_cen_cs);
+    hipFree(p->d_cen_gwin);
     hipFree(p->d_cen_grec);
     hipFree(p->d_cen_grec_parts);
     hipFree(p->d_cen_ticket);
@@ -638,9 +518,6 @@ extern "C" int tron_plan_destroy(tron_plan *p)
     hipFree(p->d_partial);
     hipFree(p->d_tile_order32_relief);
     hipFree(p->d_tile_order64);
-    hipFree(p->d_arc_off);
-    hipFree(p->d_arc_rec);
-    hipFree(p->d_arc_rbase);
     hipFree(p->d_relief_slots);
     hipFree(p->d_tile_order32_relief_small);
     hipFree(p->d_relief_slots_small);
@@ -653,18 +530,10 @@ extern "C" int tron_plan_destroy(tron_plan *p)
     hipFree(p->d_trig_tmp);
     hipFree(p->d_tw512);
     hipFree(p->d_fft_tmp);
-    hipFree(p->d_grid2);
-    for (int i = 0; i < 2; ++i) {
-        if (p->ev_g[i]) hipEventDestroy(p->ev_g[i]);
-        if (p->ev_f[i]) hipEventDestroy(p->ev_f[i]);
-    }
     for (hipEvent_t e : p->ev_pipe) hipEventDestroy(e);
     if (p->stream_up) hipStreamDestroy(p->stream_up);
     if (p->stream_down) hipStreamDestroy(p->stream_down);
-    if (p->stream2) hipStreamDestroy(p->stream2);
-    if (p->stream_inner) { hipStreamSynchronize(p->stream_inner); hipStreamDestroy(p->stream_inner); }
-    for (int i = 0; i < 2; ++i)
-        if (p->ev_inner[i]) hipEventDestroy(p->ev_inner[i]);
+    if (p->stream_build) hipStreamDestroy(p->stream_build);
     if (p->stream) hipStreamDestroy(p->stream);
     delete p;
     return TRON_OK;
@@ -675,8 +544,8 @@ extern "C" const char *tron_plan_grid_kernel_name(const tron_plan *p)
     if (!p || !p->cfg.adjoint) return "";
     // linear angles with few channels: several slices share one pass of the binned kernel (slice groups, tron_pipeline.cpp), whatever tables the plan holds
     if (p->binned && !p->cfg.golden_angle && p->nchan <= 4 && p->slices_per_pass && p->d.nz > 1) return "grid_binned_kernel (linear-angle slice groups)";
-    if (p->scatter) return p->centre_kernel ? "grid_scatter_kernel (+ grid_centre_kernel for |r| < inner_r0)" : "grid_scatter_kernel (+ grid_binned_kernel on the inner tile, grid_reduce_parts_kernel)";
-    if (p->arc) return p->centre_kernel ? "grid_arc_kernel (+ grid_centre_kernel for |r| < inner_r0)" : "grid_arc_kernel (+ grid_binned_kernel on the inner tile, grid_reduce_parts_kernel)";
+    if (arc_ready(p) && p->scatter) return "grid_scatter_kernel (+ grid_centre_kernel for |r| < inner_r0)";
+    if (arc_ready(p)) return "grid_arc_kernel (+ grid_centre_kernel for |r| < inner_r0)";
     if (p->binned) return p->relief_entries > 0 ? "grid_binned_kernel (+ grid_reduce_parts_kernel)" : "grid_binned_kernel";
     return "grid_tile_kernel";
 }
@@ -705,8 +574,6 @@ extern "C" int tron_plan_sync(tron_plan *p)
 {
     if (!p) return fail(TRON_ERR_INVALID, "tron_plan_sync: null plan");
     HIP_TRY(hipStreamSynchronize(p->stream));
-    if (p->stream2) HIP_TRY(hipStreamSynchronize(p->stream2));
-    p->fft_pending[0] = p->fft_pending[1] = false;
     return check_errflag(p);
 }
 
@@ -724,7 +591,7 @@ extern "C" int tron_nufft_adj_radial2d(tron_plan *p, void *d_out, const void *d_
     HIP_TRY(hipSetDevice(p->cfg.device));
     const size_t elem = p->cfg.input_half ? 4 : 8;
     const unsigned char *in = static_cast<const unsigned char *>(d_in) + (size_t)zfirst * d.prof_slide * d.nro * p->nchan * elem;
-    return adjoint_run(p, d_out, in, zfirst, zcount, combine, 0, true);   // asynchronous: the FFT lane is joined by tron_plan_sync / the next call
+    return adjoint_run(p, d_out, in, zfirst, zcount, combine, 0);   // asynchronous: tron_plan_sync waits for it
 }
 
 extern "C" int tron_cgnr_radial2d(tron_plan *p, void *d_out, const void *d_in, int zfirst, int zcount, int combine)
@@ -799,12 +666,13 @@ extern "C" int tron_degridradial2d(tron_plan *p, void *d_nudata, const void *d_u
     if (!p || !d_udata || !d_nudata) return fail(TRON_ERR_INVALID, "tron_degridradial2d: null argument");
     if (p->cfg.adjoint) return fail(TRON_ERR_INVALID, "plan was created for the adjoint direction");
     HIP_TRY(hipSetDevice(p->cfg.device));
+    if (int trc = traj_turn(p)) return trc;
     const tron_dims &d = p->d;
     DegridParams g;
     memset(&g, 0, sizeof(g));
     g.udata = static_cast<const float2 *>(d_udata);
     g.nudata = static_cast<float2 *>(d_nudata);
-    g.trig = p->d_trig;
+    g.trig = traj_cur(p).d_trig;
     g.tile_order = p->d_tile_order32;
     g.in_z = 0;
     g.in_c = 1;                           // udata[nrep*(i*n+j) + c], src/tron.cu:571-573
@@ -826,20 +694,6 @@ extern "C" int tron_degridradial2d(tron_plan *p, void *d_nudata, const void *d_u
         HIP_TRY(launch_degrid_tile(g, p->kb_mode, p->stream));
     else
         HIP_TRY(launch_degrid(g, p->kb_mode, p->stream));
-    return TRON_OK;
-}
-
-// Gridding and FFT launches of consecutive batches overlap on two streams when the plan has a second lane; enable = 0
-// serialises them on one stream (each kernel then runs alone: what a per-kernel duration should be measured on),
-// enable = 1 restores the plan's default.  Returns TRON_OK; *had_two_lanes (optional) tells whether the plan has the lane.
-extern "C" int tron_plan_two_lanes(tron_plan *p, int enable, int *had_two_lanes)
-{
-    if (!p) return fail(TRON_ERR_INVALID, "null plan");
-    HIP_TRY(hipStreamSynchronize(p->stream));
-    if (p->stream2) HIP_TRY(hipStreamSynchronize(p->stream2));
-    p->fft_pending[0] = p->fft_pending[1] = false;
-    if (had_two_lanes) *had_two_lanes = p->stream2 != nullptr && p->d_grid2 != nullptr;
-    p->dual = enable != 0 && p->stream2 != nullptr && p->d_grid2 != nullptr;
     return TRON_OK;
 }
 

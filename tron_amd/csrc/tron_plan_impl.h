@@ -54,6 +54,37 @@ struct FftPlan {
 
 }  // namespace tron
 
+// Everything that depends on the spoke ANGLES (src/tron.cu:509-511, 555-559: a function of skip_angles): the (cos, sin) table, the
+// angle-sorted spoke lists, the centre kernel's block windows and the arc / scatter kernels' run tables.  A plan holds two sets:
+// `cur` is the one launches read, tron_plan_retarget builds the other on a stream of its own while the launches already queued
+// run on (tron_traj.cpp, tron_traj_dev.hip).
+struct TrajTables {
+    bool allocated = false;
+    bool ok = true;                       // run tables usable (false: they overflowed -- the binned kernel takes every tile of this set)
+    int skip_angles = 0;
+    float *h_trig = nullptr;              // pinned host: (cos, sin) by libm, as the reference computes them
+    float2 *d_trig = nullptr;
+    unsigned short *d_order = nullptr;    // [window][npe] window-relative spoke index, ascending line angle (mod pi); kept: centre kernel
+    float *d_phi = nullptr;               // [window][npe] that line angle
+    float2 *d_cs = nullptr;               // [window][npe] (cos, sin) of that spoke
+    unsigned short *d_order_q = nullptr;  // windows of more than kArcMaxNpe spokes: the same lists per pass, [pass][window][spokes of the pass]
+    float *d_phi_q = nullptr;
+    float2 *d_cs_q = nullptr;
+    uint32_t *d_cen_win = nullptr;        // [window][block] the block's run of the sorted list (centre kernel)
+    int4 *d_arc_hdr = nullptr;
+    uint4 *d_arc_ent = nullptr;
+    uint32_t *d_arc_win = nullptr;
+    uint32_t *d_arc_off = nullptr;        // scatter kernel: record offset of every run entry
+    unsigned char *d_arc_rec = nullptr;   //                 per group of 64 records of every run: 80 bytes (arc_prep_kernel)
+    int *d_arc_rbase = nullptr;           //                 [window][tile] first record of the run
+    int *d_alloc = nullptr;               // [pass][2][window] arc_prep_kernel's allocation counters
+    unsigned int *d_flag = nullptr;       // arc_prep_kernel's overflow flags of this set
+    unsigned int *h_flag = nullptr;       // ... copied here (pinned) behind the build
+    hipEvent_t ev_built = nullptr;        // the build of this set (on the stream it was queued on)
+    hipEvent_t ev_released = nullptr;     // recorded on the plan's stream when the plan turned away from this set: its last reader
+    bool released = false;
+};
+
 struct tron_plan {
     tron_config cfg;
     tron_dims d;
@@ -62,12 +93,11 @@ struct tron_plan {
     int kb_mode = TRON_KB_EXACT;
     int chunk = 1;                 // slices (adjoint) or images (forward) per batch
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;  // FFT lane of the adjoint pipeline (gridding stays on `stream`)
-    hipEvent_t ev_g[2] = {nullptr, nullptr}, ev_f[2] = {nullptr, nullptr};   // grid done / buffer free, per buffer
-    bool dual = false;
-    bool fft_pending[2] = {false, false};   // two-lane pipeline: an FFT launch that reads work buffer b may still be in flight (ev_f[b])
+    hipStream_t stream_build = nullptr;   // tron_plan_retarget: the next table set is built here, beside the launches on `stream`
+    TrajTables traj[2];
+    int cur = 0;                   // the set launches read
+    bool retarget_pending = false; // traj[1 - cur] is being built: the next launch waits for it and turns to it
     // device tables
-    float2 *d_trig = nullptr;
     size_t ntrig = 0;
     uint32_t *d_band = nullptr;
     int *d_tile_order = nullptr;
@@ -92,35 +122,26 @@ struct tron_plan {
     bool scatter = false;                 // ... gridded by grid_scatter_kernel (one or two channels, tron_grid_scatter.hip): same tables, one batch per run
     float scat_wsum = 0;
     int scat_tile = 32;                   // ... on 32 x 32 or 64 x 64 tiles (its run tables are made for one of them)
-    uint32_t *d_arc_off = nullptr;        // scatter kernel: record offset of every run entry
-    unsigned char *d_arc_rec = nullptr;   //                 per group of 64 records of every run: 80 bytes (arc_prep_kernel)
-    int *d_arc_rbase = nullptr;           //                 [window][tile] first record of the run
-    int arc_rec_cap = 0;
+    int scat_tile_max = 64;               // ... 32 once 64-tile tables have overflowed (tron_plan_create's retry)
+    int relief_r0_binned = 0;             // the binned kernel's own inner radius (scatter plans lower relief_r0: restored when they fall back)
+    int arc_rec_cap = 0;                  // scatter kernel: groups of 64 records per window its member tables hold
     int *d_tile_order64 = nullptr;        // 64-tiles, centre first
-    int4 *d_arc_hdr = nullptr;
-    uint4 *d_arc_ent = nullptr;
-    uint32_t *d_arc_win = nullptr;
     float2 *d_kb_lut = nullptr;
-    // ... and the k-space centre's kernel (tron_grid_centre.hip): the sorted spoke lists, the block groups
-    unsigned short *d_cen_order = nullptr;
-    uint32_t *d_cen_win = nullptr;
-    float2 *d_cen_cs = nullptr;
+    // ... and the k-space centre's kernel (tron_grid_centre.hip): the block groups (the sorted spoke lists are TrajTables')
+    float4 *d_cen_gwin = nullptr;         // per block: the angular window of its run (lo, hi, all | wrap << 1), tron_traj_dev.hip
     uint4 *d_cen_grec = nullptr;
     unsigned *d_cen_ticket = nullptr;
     float *d_cen_parts = nullptr;
     uint4 *d_cen_grec_parts = nullptr;          // the work units with the busy blocks in parts (launches of fewer than cen_parts_below slices)
     int cen_nblocks = 0, cen_nheavy = 0, cen_nunits_parts = 0, cen_parts_below = 64;
     int cen_ngroups = 0;
-    bool centre_kernel = true;            // TRON_CENTRE_KERNEL=binned (A/B): the inner tile on the binned kernel + grid_reduce_parts_kernel, as in round 3
-    int arc_cap = 0, arc_nrec = 0, arc_zper = 1;
+    int arc_cap = 0, arc_nrec = 0, arc_zper = 0;
     int arc_passes = 1, arc_pass_npe = 0;       // windows of more than kArcMaxNpe spokes: passes over arc_pass_npe spokes each (tron_plan.cpp)
     size_t arc_nwin = 0;                        // windows the run tables hold (per pass)
+    size_t arc_ntiles = 0;                      // tiles per window of the run tables (32-tiles; 64-tiles for the scatter kernel's large tiles)
     float lut_scale = 0;
     int lut_entries = 0, lut_bias = 0;
     double lut_err = 0;
-    hipStream_t stream_inner = nullptr;   // the inner tile's parts (binned kernel) run beside the arc kernel
-    hipEvent_t ev_inner[2] = {nullptr, nullptr};
-    bool inner_beside = true;             // TRON_ARC_INNER_STREAM=0 (A/B): the inner tile's launch in front of the arc kernel, same stream
     float *d_deapod = nullptr;
     unsigned int *d_errflag = nullptr;
     int ntiles = 0, tiles_per_row = 0;
@@ -130,7 +151,6 @@ struct tron_plan {
     float kb_poly[tron::kKbPolyTerms];
     // work buffers
     float2 *d_grid = nullptr;      // chunk * nchan * nxos^2
-    float2 *d_grid2 = nullptr;     // second Cartesian buffer (dual-stream pipeline)
     void *d_stage_in = nullptr;    // host-API staging
     size_t stage_in_bytes = 0;
     void *d_stage_out = nullptr;
@@ -155,16 +175,15 @@ struct tron_plan {
     float2 *d_fft_tmp = nullptr;   // chunk * nchan * 256 * 512
     std::map<std::pair<int, int>, tron::FftPlan> fft;   // (batch, direction) -> plan
     // timing
-    int grid_lds_pad = 0;          // TRON_GRID_LDS_PAD (two-lane experiments): LDS request of the binned gridding kernel
     bool slices_per_pass = true;   // TRON_SLICES_PER_PASS=0 turns the linear-angle slice grouping off (A/B, tests)
-    bool poison = false;           // TRON_POISON_GRID (tests): NaN-fill the work grid
+    bool poison = false;           // TRON_DEBUG=poison (tests): NaN-fill the work grid
     double create_s[5] = {0, 0, 0, 0, 0};   // tron_plan_create_times
-    int debug_skip = 0;            // environment knobs, read once at plan creation (never on the launch path)
-    bool degrid_simple = false, degrid_tile_only = false, no_disc = false;
+    double retarget_s[2] = {0, 0};          // the last tron_plan_retarget: host seconds of the call, of which the (cos, sin) table
+    bool degrid_simple = false, degrid_tile_only = false;    // environment knobs, read once at plan creation (never on the launch path)
     const char *last_degrid_kernel = "";   // tron_plan_degrid_kernel_name
     bool pin_host = false;         // hipHostRegister the caller's buffers in tron_recon_radial2d[_range]
     bool timing = false;
-    bool sync_each = false;        // TRON_SYNC_EACH=1: synchronise after every launch and name the failing stage
+    bool sync_each = false;        // TRON_DEBUG=sync: synchronise after every launch and name the failing stage
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[tron::STAGE_COUNT];
     double ms_acc[tron::STAGE_COUNT] = {0, 0, 0, 0, 0};
     uint64_t launches[tron::STAGE_COUNT] = {0, 0, 0, 0, 0};
@@ -205,6 +224,17 @@ int upload(T **dptr, const void *host, size_t bytes)
 // batch sizes, work buffers and the arc kernel's run tables are sized for that block
 int plan_create_share(tron_plan **out, const tron_config *cfg, const tron_dims *dims, int z0, int zcount);
 
+// tron_traj.cpp: the angle-dependent tables (TrajTables).  traj_build queues the whole build of set T for `skip_angles` on `st`
+// (host: the (cos, sin) table by libm on a few threads; device: sort by line angle, centre windows, run tables) and records
+// T.ev_built; traj_finish waits for it and reads the overflow flags into T.ok.
+int traj_alloc(tron_plan *p, TrajTables &T);
+int traj_build(tron_plan *p, TrajTables &T, int skip_angles, hipStream_t st);
+int traj_finish(tron_plan *p, TrajTables &T);
+void traj_free(TrajTables &T);
+int traj_turn(tron_plan *p);       // a pending retarget: wait for the other set and make it current (every launch path calls this first)
+inline const TrajTables &traj_cur(const tron_plan *p) { return p->traj[p->cur]; }
+inline bool arc_ready(const tron_plan *p) { return p->arc && p->traj[p->cur].ok; }
+
 // tron_pipeline.cpp
 int drain_timers(tron_plan *p);
 int get_fft(tron_plan *p, int batch, int inverse, FftPlan **out);
@@ -218,7 +248,7 @@ int combine_coils(tron_plan *p, float2 *d_out, const float2 *d_coil, int cz);
 // out_scale / norm_partial: uncombined output only (combine = 0): the images times out_scale and, on the fused 512 / 256 path,
 // fft512_coils_partials(batch) * nchan partial sums of |image|^2 per slice (CGNR); norm_partial_done tells whether they were written
 int adjoint_run(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, int zcount, int combine, int in_stride_spokes = 0,
-                bool defer_join = false, float out_scale = 1.f, double *norm_partial = nullptr, int *norm_parts = nullptr);
+                float out_scale = 1.f, double *norm_partial = nullptr, int *norm_parts = nullptr);
 int forward_run(tron_plan *p, void *d_out, const void *d_in, int nimg, const float2 *trig = nullptr, int trig_img_stride = 0,
                 const float *deapod = nullptr);
 int cgnr_run(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, int zcount, int combine);

@@ -55,7 +55,7 @@ EXPORTS = [
     "tron_config_default", "tron_derive_dims", "tron_plan_create", "tron_plan_destroy",
     "tron_recon_radial2d", "tron_recon_radial2d_range", "tron_recon_radial2d_block", "tron_recon_radial2d_multi", "tron_nufft_adj_radial2d", "tron_cgnr_radial2d", "tron_nufft_radial2d",
     "tron_precompensate", "tron_gridradial2d", "tron_degridradial2d", "tron_plan_sync",
-    "tron_plan_timing", "tron_plan_timing_get", "tron_plan_timing_reset", "tron_plan_two_lanes", "tron_plan_grid_kernel_name", "tron_plan_degrid_kernel_name", "tron_plan_create_times", "tron_plan_shader_clock",
+    "tron_plan_timing", "tron_plan_timing_get", "tron_plan_timing_reset", "tron_plan_retarget", "tron_plan_retarget_times", "tron_plan_grid_kernel_name", "tron_plan_degrid_kernel_name", "tron_plan_create_times", "tron_plan_shader_clock",
     "tron_host_trig_table", "tron_host_band_table", "tron_host_deapod_table", "tron_host_numa_cpulist",
     "tron_device_count", "tron_device_malloc", "tron_device_free", "tron_memcpy_h2d", "tron_memcpy_d2h",
     "tron_last_error", "tron_version",
@@ -100,7 +100,8 @@ def load():
     sig("tron_gridradial2d", i, [p, p, p, i])
     sig("tron_degridradial2d", i, [p, p, p])
     sig("tron_plan_sync", i, [p])
-    sig("tron_plan_two_lanes", i, [p, i, ctypes.POINTER(i)])
+    sig("tron_plan_retarget", i, [p, i])
+    sig("tron_plan_retarget_times", i, [p, ctypes.POINTER(ctypes.c_double)])
     sig("tron_plan_create_times", i, [p, ctypes.POINTER(ctypes.c_double)])
     sig("tron_plan_shader_clock", i, [p, ctypes.POINTER(ctypes.c_double)])
     sig("tron_plan_grid_kernel_name", ctypes.c_char_p, [p])
@@ -300,11 +301,17 @@ class Plan:
         check(load().tron_plan_shader_clock(self._h, ctypes.byref(mhz)))
         return mhz.value
 
-    def two_lanes(self, enable=True) -> bool:
-        """Serialise (False) or restore (True) the gridding || FFT overlap; returns whether the plan has a second lane."""
-        had = ctypes.c_int(0)
-        check(load().tron_plan_two_lanes(self._h, int(enable), ctypes.byref(had)))
-        return bool(had.value)
+    def retarget(self, skip_angles: int):
+        """Later calls use spoke angles starting at index `skip_angles` (= tron_plan_retarget: the new tables are built on the
+        device beside the work already queued; results equal those of a plan created with this skip_angles)."""
+        check(load().tron_plan_retarget(self._h, int(skip_angles)))
+        self.cfg.skip_angles = int(skip_angles)
+
+    def retarget_times(self) -> dict:
+        """Host seconds of the last retarget() call, of which the (cos, sin) table."""
+        t = (ctypes.c_double * 2)()
+        check(load().tron_plan_retarget_times(self._h, t))
+        return dict(call=t[0], trig=t[1])
 
     def timing(self, enable=True):
         check(load().tron_plan_timing(self._h, int(enable)))

@@ -126,8 +126,8 @@ def main(argv=None):
         dist.init_process_group("gloo", rank=rank, world_size=world)     # host-side gather only
     from . import lib, ra
     opts, args = getopt.getopt(argv, "3aB:d:g:Ghi:k:o:r:s:T:u:v")      # the reference's flags, src/tron.cu:822
-    # same default as the tron binary (tron_main.cpp): fast Kaiser-Bessel unless TRON_KB_MODE=exact
-    kw = dict(device=local_rank, kb_mode=lib.KB_EXACT if os.environ.get("TRON_KB_MODE") == "exact" else lib.KB_FAST)
+    # same default as the tron binary (tron_main.cpp): fast Kaiser-Bessel unless TRON_OPTIONS holds kb=exact
+    kw = dict(device=local_rank, kb_mode=lib.KB_EXACT if "kb=exact" in os.environ.get("TRON_OPTIONS", "").split(",") else lib.KB_FAST)
     for o, v in opts:
         if o == "-a": kw["adjoint"] = 1
         elif o == "-G": kw["golden_angle"] = 1
