@@ -384,6 +384,7 @@ def main():
     torch.cuda.set_device(local_rank)
     torch.zeros(1, device="cuda")
     from tron_amd import launch
+    bound_cpus = launch.bind_near_gpu(local_rank) if world > 1 and not share else []    # one rank per GPU: run on that GPU's socket
     group = launch.HostGroup(rank, world)      # gloo on the host: barrier + max of wall times, nothing on the data path
 
     import ctypes

@@ -238,6 +238,8 @@ int tron_host_numa_cpulist(const char *sysroot, const char *pci_bus_id, int *cpu
 /* Small device-memory helpers so a host language without HIP bindings can drive the
    device-resident entry points. */
 int tron_device_count(int *count);
+/* PCI bus id of a device ("0000:c1:00.0", at least 16 bytes): the key of its NUMA node in sysfs, see tron_host_numa_cpulist. */
+int tron_device_pci_bus_id(int device, char *buf, int len);
 int tron_device_malloc(void **d_ptr, size_t bytes);
 int tron_device_free(void *d_ptr);
 int tron_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes);

@@ -71,6 +71,27 @@ def test_multi_device_workers_in_one_process(tmp_path):
     assert open(a, "rb").read() == open(b, "rb").read()
 
 
+def test_multi_device_workers_on_distinct_devices_share_one_registration():
+    """More than one GPU in the box (skipped otherwise; the driver's 8-GPU node is the first place this can run): the workers of
+    tron_recon_radial2d_multi sit on DISTINCT device ordinals and copy from / to the caller's buffers, which the entry point registers
+    ONCE with hipHostRegisterPortable from whichever device is current -- visible to every device, or the workers' copies fault.  Large
+    enough that the registration is taken (>= 8 MiB moved per worker).  The bytes of one plan on device 0."""
+    ndev = lib.device_count()
+    if ndev < 2:
+        pytest.skip("needs at least two GPUs")
+    nz = 4 * ndev
+    data = synth.kspace(8, 256, 120 * nz, seed=1250)
+    flags = dict(golden_angle=1, data_undersamp=(120 + 0.5) / 256, prof_slide=120)
+    single, dims = lib.recon(data, adjoint=True, **flags)
+    assert dims.nz == nz
+    multi, _ = lib.recon_multi(data, adjoint=True, devices=list(range(ndev)), **flags)
+    assert np.array_equal(multi, single)
+    multi, _ = lib.recon_multi(data, adjoint=True, devices=list(range(ndev - 1, -1, -1)), **flags)     # any order of ordinals
+    assert np.array_equal(multi, single)
+    for dev in range(ndev):
+        assert len(lib.device_pci_bus_id(dev)) >= 7
+
+
 def test_centre_relief_and_split_tiles_are_deterministic_and_agree_with_the_plain_kernel(oracle, monkeypatch):
     """The k-space-centre tiles' corner blocks see every spoke.  Grids whose centre is a tile corner take the samples
     |r| < 14 out of those tiles and grid them with workgroups of their own (the origin-centred inner tile, dealt over

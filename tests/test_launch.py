@@ -111,3 +111,51 @@ def test_spawn_ranks_retries_on_a_taken_port(tmp_path, monkeypatch):
 def test_spawn_ranks_has_a_finite_default_timeout():
     import inspect
     assert inspect.signature(launch.spawn_ranks).parameters["timeout"].default == launch.DEFAULT_TIMEOUT_S < 3600
+
+
+@pytest.mark.timeout(120)
+def test_ranks_bind_to_the_cpus_of_their_gpus_numa_node(tmp_path):
+    """launch.bind_near_gpu: a rank that feeds its GPU from host buffers stays on that GPU's socket (PCI bus id -> sysfs numa_node ->
+    cpulist -> sched_setaffinity), here against a fake sysfs tree with two "GPUs" on two nodes that split this machine's CPUs; an
+    unknown node or a node none of whose CPUs this process may use leaves the process where it is.  (In a child: affinity is
+    inherited by everything pytest starts later.)"""
+    cpus = sorted(os.sched_getaffinity(0))
+    if len(cpus) < 2:
+        pytest.skip("needs two CPUs")
+    half = len(cpus) // 2
+    nodes = {"0000:01:00.0": (0, cpus[:half]), "0000:c1:00.0": (1, cpus[half:])}
+    for bus, (node, cl) in nodes.items():
+        dev = tmp_path / "bus" / "pci" / "devices" / bus
+        dev.mkdir(parents=True)
+        (dev / "numa_node").write_text(f"{node}\n")
+        nd = tmp_path / "devices" / "system" / "node" / f"node{node}"
+        nd.mkdir(parents=True)
+        (nd / "cpulist").write_text(",".join(str(c) for c in cl) + "\n")
+    dev = tmp_path / "bus" / "pci" / "devices" / "0000:e1:00.0"            # a GPU whose node is unknown (-1: single-node hosts, VMs)
+    dev.mkdir(parents=True)
+    (dev / "numa_node").write_text("-1\n")
+    dev = tmp_path / "bus" / "pci" / "devices" / "0000:f1:00.0"            # ... and one on a node whose CPUs this process may not use
+    dev.mkdir(parents=True)
+    (dev / "numa_node").write_text("7\n")
+    nd = tmp_path / "devices" / "system" / "node" / "node7"
+    nd.mkdir(parents=True)
+    (nd / "cpulist").write_text("100000-100003\n")
+    child = _child(tmp_path, """
+        import json
+        from tron_amd import launch
+        root = sys.argv[1]
+        before = sorted(os.sched_getaffinity(0))
+        res = {}
+        for bus in ("0000:e1:00.0", "0000:f1:00.0"):
+            res[bus] = [launch.bind_near_gpu(0, sysroot=root, bus_id=bus), sorted(os.sched_getaffinity(0)) == before]
+        for bus in ("0000:C1:00.0", "0000:01:00.0"):                        # HIP reports upper-case hex
+            os.sched_setaffinity(0, before)
+            res[bus] = [launch.bind_near_gpu(0, sysroot=root, bus_id=bus), sorted(os.sched_getaffinity(0))]
+        print(json.dumps(res))
+    """)
+    r = subprocess.run([sys.executable, child, str(tmp_path)], capture_output=True, text=True, timeout=100)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    assert res["0000:e1:00.0"] == [[], True] and res["0000:f1:00.0"] == [[], True]
+    assert res["0000:C1:00.0"] == [cpus[half:], cpus[half:]]
+    assert res["0000:01:00.0"] == [cpus[:half], cpus[:half]]

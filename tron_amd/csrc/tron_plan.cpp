@@ -732,6 +732,15 @@ extern "C" int tron_device_count(int *count)
     return TRON_OK;
 }
 
+// PCI bus id of a HIP device ("0000:c1:00.0"): what sysfs keys its NUMA node by (tron_host_numa_cpulist); one-rank-per-GPU launchers
+// bind each rank to its GPU's socket with it (tron_amd/launch.py: bind_near_gpu).
+extern "C" int tron_device_pci_bus_id(int device, char *buf, int len)
+{
+    if (!buf || len < 16) return fail(TRON_ERR_INVALID, "tron_device_pci_bus_id: buffer of at least 16 bytes needed");
+    HIP_TRY(hipDeviceGetPCIBusId(buf, len, device));
+    return TRON_OK;
+}
+
 extern "C" int tron_device_malloc(void **d_ptr, size_t bytes)
 {
     if (!d_ptr) return fail(TRON_ERR_INVALID, "null argument");

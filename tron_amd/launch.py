@@ -32,6 +32,22 @@ def rank_env(rank: int, world: int, port: int, base=None) -> dict:
     return env
 
 
+def bind_near_gpu(local_rank: int, sysroot: str = "/sys", bus_id: str | None = None):
+    """Binds the calling process (and every thread it starts later) to the CPUs of the NUMA node its GPU hangs off: a rank feeds its
+    GPU from host buffers (python -m tron_amd.shard, the host-buffer entry points), and on a two-socket 8-GPU node half the ranks would
+    otherwise run across the socket link.  sysfs: <sysroot>/bus/pci/devices/<bus id>/numa_node -> .../node<N>/cpulist (parsed by
+    tron_host_numa_cpulist, as for the in-process workers of tron_recon_radial2d_multi).  Best effort: returns the CPUs bound to, or []
+    when the node is unknown (single-node hosts, VMs) or none of its CPUs is available to this process -- the process then stays put.
+    `bus_id` is looked up through HIP (tron_device_pci_bus_id) unless given, so call it in the rank, not in the spawning parent."""
+    from tron_amd import lib
+    if bus_id is None:
+        bus_id = lib.device_pci_bus_id(local_rank)
+    cpus = sorted(set(lib.numa_cpulist(sysroot, bus_id)) & os.sched_getaffinity(0))
+    if cpus:
+        os.sched_setaffinity(0, cpus)
+    return cpus
+
+
 DEFAULT_TIMEOUT_S = 1800.0   # a run that has not finished by then is ended (gloo's own rendezvous timeout is 30 minutes too)
 
 

@@ -57,7 +57,7 @@ EXPORTS = [
     "tron_precompensate", "tron_gridradial2d", "tron_degridradial2d", "tron_plan_sync",
     "tron_plan_timing", "tron_plan_timing_get", "tron_plan_timing_reset", "tron_plan_retarget", "tron_plan_retarget_times", "tron_plan_grid_kernel_name", "tron_plan_degrid_kernel_name", "tron_plan_create_times", "tron_plan_shader_clock",
     "tron_host_trig_table", "tron_host_band_table", "tron_host_deapod_table", "tron_host_numa_cpulist",
-    "tron_device_count", "tron_device_malloc", "tron_device_free", "tron_memcpy_h2d", "tron_memcpy_d2h",
+    "tron_device_count", "tron_device_pci_bus_id", "tron_device_malloc", "tron_device_free", "tron_memcpy_h2d", "tron_memcpy_d2h",
     "tron_last_error", "tron_version",
     "ra_read", "ra_write", "ra_free", "ra_query", "ra_reshape", "ra_convert", "ra_squash", "ra_diff", "ra_read_header", "ra_data_offset", "ra_write_header", "ra_read_range", "ra_write_range",
     "ra_float_to_half_bits", "ra_half_to_float_bits", "ra_double_to_half_bits", "ra_half_to_double_bits",
@@ -114,6 +114,7 @@ def load():
     sig("tron_host_band_table", i, [i, f, p])
     sig("tron_host_deapod_table", i, [i, f, f, p])
     sig("tron_device_count", i, [ctypes.POINTER(i)])
+    sig("tron_device_pci_bus_id", i, [i, ctypes.c_char_p, i])
     sig("tron_device_malloc", i, [ctypes.POINTER(p), sz])
     sig("tron_device_free", i, [p])
     sig("tron_memcpy_h2d", i, [p, p, sz])
@@ -154,6 +155,21 @@ def device_count() -> int:
     n = ctypes.c_int(0)
     rc = load().tron_device_count(ctypes.byref(n))
     return n.value if rc == TRON_OK else 0
+
+
+def device_pci_bus_id(device: int) -> str:
+    buf = ctypes.create_string_buffer(64)
+    check(load().tron_device_pci_bus_id(int(device), buf, 64))
+    return buf.value.decode()
+
+
+def numa_cpulist(sysroot: str, bus_id: str, max_cpus: int = 4096):
+    """CPUs of the NUMA node a PCI function hangs off, from a sysfs tree (= tron_host_numa_cpulist); [] when the node is unknown."""
+    cpus = (ctypes.c_int * max_cpus)()
+    n = load().tron_host_numa_cpulist(sysroot.encode(), bus_id.encode(), cpus, max_cpus)
+    if n < 0:
+        raise ValueError(f"malformed cpulist under {sysroot} for {bus_id}")
+    return [cpus[k] for k in range(n)]
 
 
 class DeviceBuffer:

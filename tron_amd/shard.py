@@ -124,7 +124,12 @@ def main(argv=None):
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)     # host-side gather only
-    from . import lib, ra
+    from . import launch, lib, ra
+    if world > 1:
+        try:
+            launch.bind_near_gpu(local_rank)         # this rank reads its spokes from the file and feeds its GPU: stay on that GPU's socket
+        except Exception:                            # (no GPU here -- the CPU tests -- or no NUMA information: stay put)
+            pass
     opts, args = getopt.getopt(argv, "3aB:d:g:Ghi:k:o:r:s:T:u:v")      # the reference's flags, src/tron.cu:822
     # same default as the tron binary (tron_main.cpp): fast Kaiser-Bessel unless TRON_OPTIONS holds kb=exact
     kw = dict(device=local_rank, kb_mode=lib.KB_EXACT if "kb=exact" in os.environ.get("TRON_OPTIONS", "").split(",") else lib.KB_FAST)
