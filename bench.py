@@ -520,6 +520,12 @@ def main():
     stages = {}
     if rank == 0:
         reps = max(2, min(args.steps, 5))
+        # (the oracle checks above left the GPU idle for seconds and the chip's clock takes tens of milliseconds of load to settle,
+        #  a quarter of a second of untimed steps first, so that the kernels are clocked as in the timed region)
+        t_w = time.perf_counter()
+        while time.perf_counter() - t_w < 0.25:
+            step()
+        fence()
         plan.timing(True)
         plan.timing_reset()
         for _ in range(reps):

@@ -85,6 +85,7 @@ struct ScatLds {
     unsigned long long acc[NC][G::kPitch * G::kStride];          // (re << 32) + im, fixed point
     unsigned dmax_bits[2];                                        // largest |d| dcf of the rounds so far, by round parity
     unsigned pad[2];
+    unsigned smax[kScatMaxSpokes];                               // per run entry (spoke segment): its largest |d| dcf so far, float bits (round 6)
     // a wave's next round of the member table (arc_prep_kernel: 80 bytes per group of 64 records), copied by LDS-DMA a round ahead
     unsigned char recb[G::kWaves][ScatCfg<NC, TILE>::R * 80];
 };
@@ -234,6 +235,7 @@ grid_scatter_kernel(const GridParams p)
         constexpr int N4 = NC * kScatPitch * kScatStride / 2;
         for (int i = tid; i < N4; i += kScatThreads) a4[i] = make_uint4(0u, 0u, 0u, 0u);
         if (tid < 2) L.dmax_bits[tid] = 0u;
+        for (int i = tid; i < kScatMaxSpokes; i += kScatThreads) L.smax[i] = 0u;
     }
 
     for (int iz = 0; iz < zper; ++iz) {
@@ -351,12 +353,16 @@ grid_scatter_kernel(const GridParams p)
                 if (meta[q] >> 31) {
                     const float uf = (float)((meta[q] >> 9) & 1023u);
                     const float sdc = fabsf(fmaf(dcf_a, RS ? arc_sample_of(uf, rs_nro, rs_inv) : uf, dcf_b));
+                    float mq = 0.f;
 #pragma unroll
                     for (int c = 0; c < NC; ++c)
-                        if (c < ncb) mxv = fmaxf(mxv, fmaxf(fabsf(dreg[q][c].x), fabsf(dreg[q][c].y)) * sdc);
+                        if (c < ncb) mq = fmaxf(mq, fmaxf(fabsf(dreg[q][c].x), fabsf(dreg[q][c].y)) * sdc);
+                    if (!(mq < 3.0e38f)) mq = 3.0e38f;          // inf / NaN in the data: garbage either way; keep the scale finite
+                    // ... and the largest of the record's SPOKE SEGMENT (an integer maximum over float bits: exact in any order)
+                    atomicMax(&L.smax[meta[q] & 511u], __float_as_uint(mq));
+                    mxv = fmaxf(mxv, mq);
                 }
             }
-            if (!(mxv < 3.0e38f)) mxv = 3.0e38f;                // inf / NaN in the data: garbage either way; keep the scale finite
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) mxv = fmaxf(mxv, __shfl_xor(mxv, o));
             const int slot = (r0 / R) & 1;                      // (two slots, never cleared inside a slice: a fast wave's next round cannot disturb this one)
@@ -365,10 +371,25 @@ grid_scatter_kernel(const GridParams p)
             __syncthreads();
             SPROF_MARK(5);
             const float new_max = __uint_as_float(L.dmax_bits[slot]);
-            // S = 2^e: every sum of the tile stays inside 32 bits: max (|d| dcf) * (spokes that can reach one point) * (1.75 K(0)^2 per spoke, GridParams::scat_wsum) * S < 2^31
-            if (new_max > run_max || !have_scale) {
-                int e_new = 0;
-                const float bound = new_max * (float)max(mwin, 1) * p.scat_wsum;
+            // S = 2^e, the largest with  bound * S < 2^31,  bound = what the |re| or |im| sum of ONE point can reach:
+            //   one spoke adds at most (its largest |d| dcf in the tile) x (the window products along a line: <= 1.65 K(0)^2, scat_wsum = 1.75 K(0)^2),
+            //   so a point's sum stays below  scat_wsum x min( M x the tile's largest |d| dcf,  the SUM over the tile's spoke segments of each one's
+            //   largest |d| dcf )  -- M = the most spokes whose line can pass one of the tile's 2x2 blocks (arc_prep_kernel: the run header).
+            // Until round 5 only the first term stood, and ONE large sample (a spike 300 x its neighbourhood in a 640-spoke window: 1.8e-5 relative
+            // L2 against the oracle, tests/test_gpu_scatter.py) set the step of the whole tile; the second term charges a spike to its own spoke.
+            // Deterministic: the per-segment maxima are integer maxima, their sum is taken by every wave in the same fixed order.
+            float ssum = 0.f;
+            {
+                const int ns_run = hdr.x;
+#pragma unroll
+                for (int k = 0; k < kScatMaxSpokes / 64; ++k)
+                    if (k * 64 < ns_run) ssum += __uint_as_float(L.smax[k * 64 + lane]);      // (entries beyond the run are zero)
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) ssum += __shfl_xor(ssum, o);                   // xor butterfly: the same bits in every lane and wave
+            }
+            {
+                const float bound = fminf(new_max * (float)max(mwin, 1), ssum) * p.scat_wsum;
+                int e_new = have_scale ? e2 : 0;
                 if (bound > 0.f) {
                     const int ex = (int)((__float_as_uint(bound) >> 23) & 255u) - 127;      // bound < 2^(ex + 1)
                     e_new = min(max(30 - ex, -120), 120);
@@ -387,7 +408,9 @@ grid_scatter_kernel(const GridParams p)
                     }
                     __syncthreads();
                 }
-                if (new_max > 0.f || !have_scale) e2 = e_new;
+                // (the bound never falls from round to round -- both maxima and their sum only grow -- so the scale never has to grow; before the
+                //  first non-zero sample every sum is zero and any scale will do)
+                if (!(have_scale && run_max > 0.f) || e_new < e2) e2 = e_new;
                 have_scale = true;
                 run_max = new_max;
                 S = __uint_as_float((unsigned)(e2 + 127) << 23);
@@ -442,6 +465,12 @@ grid_scatter_kernel(const GridParams p)
                     const float um = fmaxf(uf - W, 0.0f), up = uf + W;
                     const float bandA = um * um, bandB = up * up;
                     const float bandC = 0.5f * (bandA + bandB), bandD = 0.5f * (bandB - bandA);
+                    // Two points per instruction (round 6; a compare + select per point before: 4 instructions and 3 hazard cycles per outer point
+                    // where this is 2.5): s = X^2 + Y^2 - C for a pair of columns, mask = clamp(D^2 + qd - s^2, 0, 1) as ONE packed fma with the
+                    // clamp modifier.  W = 2 and u >= 3 (this kernel's plans): C = u^2 + 4, D = 4 u and s are integers, so a point inside its band
+                    // has s^2 <= D^2 and the fma's exact value is >= 1, one outside has |s| >= D + 1 and the value is <= -2 D: a single rounding
+                    // of the exact value cannot move either across (0, 1), whatever the magnitudes (D^2 + 1 < 2^24 up to nxos = 2048).
+                    const float d2p1 = fmaf(bandD, bandD, 1.0f);
                     float xc[4], y2[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -449,6 +478,12 @@ grid_scatter_kernel(const GridParams p)
                         xc[j] = xj * xj - bandC;
                         y2[j] = yj * yj;
                     }
+                    auto mask2 = [&](const float xa, const float xb, const float yy, const float w) -> v2f {      // (in band ? w : 0) for two columns of one row
+                        const v2f sv = (v2f){xa, xb} + (v2f){yy, yy};
+                        v2f m;
+                        asm("v_pk_fma_f32 %0, %1, %1, %2 neg_lo:[1,0,0] neg_hi:[1,0,0] clamp" : "=v"(m) : "v"(sv), "v"((v2f){d2p1, d2p1}));
+                        return m * (v2f){w, w};
+                    };
                     // density compensation (src/tron.cu:412: |ro - nro/2| = u, or u's sample) and the fixed-point scale, once per sample
                     const float sdc = fmaf(dcf_a, RS ? arc_sample_of(uf, rs_nro, rs_inv) : uf, dcf_b) * S;
                     v2f a[4][NC];
@@ -459,13 +494,20 @@ grid_scatter_kernel(const GridParams p)
                         for (int j = 0; j < 4; ++j) a[j][c] = ds * (v2f){wx[j], wx[j]};
                     }
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < 4; ++i) {
+                        // row i's four weights: the inner columns of the inner rows lie within sqrt(2) < W of the sample and pass always
+                        float wrow[4];
+                        const v2f outer = mask2(xc[0], xc[3], y2[i], wy[i]);
+                        wrow[0] = outer.x; wrow[3] = outer.y;
+                        if (i == 1 || i == 2) {
+                            wrow[1] = wy[i]; wrow[2] = wy[i];
+                        } else {
+                            const v2f inner = mask2(xc[1], xc[2], y2[i], wy[i]);
+                            wrow[1] = inner.x; wrow[2] = inner.y;
+                        }
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            float wyb2 = wy[i];
-                            if (!((i == 1 || i == 2) && (j == 1 || j == 2))) {
-                                wyb2 = fabsf(xc[j] + y2[i]) <= bandD ? wy[i] : 0.0f;      // outside the point's band: weight zero (adding 0 costs less than a branch)
-                            }
+                            const float wyb2 = wrow[j];                                    // zero outside the point's band (adding 0 costs less than a branch)
 #pragma unroll
                             for (int c = 0; c < NC; ++c)
                                 if (c < ncb) {
@@ -476,6 +518,7 @@ grid_scatter_kernel(const GridParams p)
                                     __hip_atomic_fetch_add(&L.acc[c][base + i * kScatStride + j], ((unsigned long long)hi << 32) | lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                                 }
                         }
+                    }
                 }
             }
             SPROF_MARK(6);                                      // scatter
@@ -526,6 +569,7 @@ grid_scatter_kernel(const GridParams p)
                 for (int k = tid; k < kRing; k += kScatThreads) L.acc[c][halo_index(k)] = 0ull;
             }
             if (tid < 2) L.dmax_bits[tid] = 0u;
+            for (int i = tid; i < hdr.x; i += kScatThreads) L.smax[i] = 0u;
             if (more) table_to_lds(hdr_next.x);                 // (every wave is past the scatter: the old table is done with)
         }
         SPROF_MARK(8);                                          // store, next slice's table
@@ -601,7 +645,7 @@ bool grid_scatter_supported(int nchan, int nxos, int nro, int npe, float W, int 
 hipError_t launch_grid_scatter(const GridParams &p, int half_in, int first_plain, hipStream_t s)
 {
     const int nc = p.nchan - p.coil0;
-    if (p.out_p != 1 || p.inner_r0 <= 0 || !p.arc_hdr || !p.arc_ent || !p.arc_off || !p.arc_rec || !p.arc_rbase || (p.scat_tile != 32 && p.scat_tile != 64) || (p.nxos / 2) % p.scat_tile != 0 || !p.kb_lut || p.lut_entries > kArcLutEntries || p.npe > kArcMaxNpe || !(p.scat_wsum > 0.f) || (int)p.lut_scale != kScatLutS
+    if (p.out_p != 1 || p.inner_r0 < 3 || !p.arc_hdr || !p.arc_ent || !p.arc_off || !p.arc_rec || !p.arc_rbase || (p.scat_tile != 32 && p.scat_tile != 64) || (p.nxos / 2) % p.scat_tile != 0 || !p.kb_lut || p.lut_entries > kArcLutEntries || p.npe > kArcMaxNpe || !(p.scat_wsum > 0.f) || (int)p.lut_scale != kScatLutS
         || !grid_scatter_supported(nc, p.nxos, p.nro, p.npe, p.W, half_in) || (reinterpret_cast<uintptr_t>(p.nudata) & (half_in ? 3 : 7)) != 0
         || (nc == 2 && (reinterpret_cast<uintptr_t>(p.nudata) & (half_in ? 7 : 15)) != 0))
         return hipErrorInvalidValue;

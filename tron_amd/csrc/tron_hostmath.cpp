@@ -146,16 +146,25 @@ static void for_rows(int n, size_t work_per_row, F body)
 void build_band_table(int nxos, float kernwidth, uint32_t *band)
 {
     const int h = nxos / 2;
-    for_rows(nxos, (size_t)nxos, [&](int yy) {
-        for (int xx = 0; xx < nxos; ++xx) {
-            int X = xx - h, Y = yy - h;
-            float R = hypotf((float)X, (float)Y);
+    // hypotf(+-X, +-Y) is one value (IEEE: the signs do not enter), so only the quadrant |X|, |Y| <= h is evaluated -- a quarter of the
+    // libm calls -- and every point looks its (|X|, |Y|) up; the argument ORDER is kept as the reference's (X first), never swapped.
+    const int q = h + 1;
+    std::vector<uint32_t> quad((size_t)q * q);
+    for_rows(q, (size_t)q * 4, [&](int ay) {
+        for (int ax = 0; ax < q; ++ax) {
+            float R = hypotf((float)ax, (float)ay);
             int Rhi = fminf(floorf(R + kernwidth), nxos / 2 - 1);
             int Rlo = fmaxf(ceilf(R - kernwidth), 0);
             if (Rhi < 0) { Rhi = 0; Rlo = 1; }                // nxos < 2: empty band
-            band[(size_t)yy * nxos + xx] = (uint32_t)Rlo | ((uint32_t)Rhi << 16);
+            quad[(size_t)ay * q + ax] = (uint32_t)Rlo | ((uint32_t)Rhi << 16);
         }
     });
+    for (int yy = 0; yy < nxos; ++yy) {
+        const int ay = yy < h ? h - yy : yy - h;
+        uint32_t *row = band + (size_t)yy * nxos;
+        const uint32_t *qr = quad.data() + (size_t)ay * q;
+        for (int xx = 0; xx < nxos; ++xx) row[xx] = qr[xx < h ? h - xx : xx - h];
+    }
 }
 
 // grid_scatter_kernel tests the band as (u - W)^2 <= X^2 + Y^2 <= (u + W)^2 (u - W clamped at 0) instead of reading this table.  For integer u
@@ -211,12 +220,18 @@ static float kb_hat(float u, float kernwidth)
 // x coordinate of :395); the kernel's "/= w" is a multiplication by 1.0f/w (float2math.h:23).
 void build_deapod_table(int n, float kernwidth, float sigma, float *inv_weight)
 {
-    for_rows(n, (size_t)n * 4, [&](int row) {
+    // the second factor depends on the column alone (y = id % n - ...): n evaluations instead of n^2; the first keeps the reference's
+    // fractional x = id / float(n) - ... (Q7), one evaluation per pixel
+    const float scale = 1.f / n / sigma;
+    std::vector<float> hy(n);
+    for (int col = 0; col < n; ++col) {
+        float y = float(col) - (n + 1) / 2;
+        hy[col] = kb_hat(y * scale, kernwidth);
+    }
+    for_rows(n, (size_t)n * 8, [&](int row) {
         for (size_t id = (size_t)row * n; id < (size_t)(row + 1) * n; ++id) {
             float x = id / float(n) - (n + 1) / 2;
-            float y = float(id % n) - (n + 1) / 2;
-            float scale = 1.f / n / sigma;
-            float wgt = kb_hat(x * scale, kernwidth) * kb_hat(y * scale, kernwidth);
+            float wgt = kb_hat(x * scale, kernwidth) * hy[id % n];
             inv_weight[id] = 1.0f / (wgt > 0.f ? wgt : 1.f);
         }
     });

@@ -98,9 +98,10 @@ int main(int argc, char *argv[])
     }
     const char *infile = argv[optind];
     const char *outfile = optind + 1 < argc ? argv[optind + 1] : "img_tron.ra";   // src/tron.cu:877
+    int pin_opt = -1;                                                          // TRON_OPTIONS pin=0|1 (default: see the streamed path below)
     // What the reference's getopt string has no letter for (its flags are kept exactly, src/tron.cu:813): TRON_OPTIONS, a comma-separated
     // list -- kb=exact|fast (Kaiser-Bessel mode, default fast), gpus=N (one worker per GPU, as -g all), combine=walsh|sos, patch=N
-    // (Walsh patch half-width), cgnr_consistent=1.  They become tron_config fields; the library itself reads no such variable.
+    // (Walsh patch half-width), cgnr_consistent=1, pin=0|1 (register the host buffers for the copies).  They become tron_config fields; the library itself reads no such variable.
     if (const char *opts = getenv("TRON_OPTIONS")) {
         std::string all(opts);
         size_t pos = 0;
@@ -113,13 +114,14 @@ int main(int argc, char *argv[])
             else if (key == "cgnr_consistent") cfg.cgnr_consistent = atoi(val.c_str()) != 0;
             else if (key == "combine") cfg.coil_combine = val == "walsh" ? 1 : 0;
             else if (key == "patch") cfg.walsh_patch = atoi(val.c_str());
+            else if (key == "pin") pin_opt = atoi(val.c_str()) != 0 ? 1 : 0;
             else if (key == "gpus") {
                 if (atoi(val.c_str()) > 1 && gpu_list.empty()) {
                     multi_gpu = true;
                     for (int g = 0; g < atoi(val.c_str()); ++g) gpu_list.push_back(g);
                 }
             } else if (!key.empty()) {
-                fprintf(stderr, "tron: TRON_OPTIONS: unknown option '%s' (kb, gpus, combine, patch, cgnr_consistent)\n", key.c_str());
+                fprintf(stderr, "tron: TRON_OPTIONS: unknown option '%s' (kb, gpus, combine, patch, cgnr_consistent, pin)\n", key.c_str());
                 return 1;
             }
             pos = end + 1;
@@ -233,10 +235,28 @@ int main(int argc, char *argv[])
     out.size = dims.out_bytes;
     out.dims = static_cast<uint64_t *>(malloc(5 * sizeof(uint64_t)));
     out.data = static_cast<uint8_t *>(calloc(dims.out_bytes ? dims.out_bytes : 1, 1));
+    // the streamed path (below): blocks of slices; the plan's batches, work buffers and staging are sized for ONE block, and the
+    // copies go from / to pageable memory -- registering every block's 40 + 30 MB for a copy of 1 ms each cost more than it
+    // returned (whole-body shape, round 6: profiles/round6_wholebody_cli.log; TRON_OPTIONS pin=1 brings it back)
+    const bool will_stream = !multi_gpu && cfg.adjoint && dims.nz > 1 && !same_file;
+    const int nblocks = std::max(1, std::min(16, dims.nz / 48));
+    if (will_stream) {
+        if (cfg.chunk_slices <= 0) cfg.chunk_slices = (dims.nz + nblocks - 1) / nblocks;
+        cfg.pin_host = pin_opt == 1 ? 1 : 0;
+    } else if (pin_opt >= 0) {
+        cfg.pin_host = pin_opt;
+    }
+    // the output's pages are touched by a helper while the GPU comes up (calloc hands out untouched pages: the first download would
+    // fault them in one by one, 120 k of them for the whole-body volume)
+    std::thread toucher([&]() {
+        if (!out.data) return;
+        for (uint64_t o = 0; o < dims.out_bytes; o += 4096) reinterpret_cast<volatile uint8_t *>(out.data)[o] = 0;
+    });
     tron_plan *plan = nullptr;
     int rc = TRON_OK;
     if (!(out.dims && out.data)) rc = TRON_ERR_NOMEM;
     else if (!multi_gpu) rc = tron_plan_create(&plan, &cfg, &dims);        // multi-GPU: every worker creates its own plan
+    toucher.join();
     clock_gettime(CLOCK_MONOTONIC, &tp);
     const double plan_s = (tp.tv_sec - t0.tv_sec) + 1e-9 * (tp.tv_nsec - t0.tv_nsec);
     if (!out.dims || !out.data) {
@@ -265,14 +285,13 @@ int main(int argc, char *argv[])
     double write_s = 0.0;
     bool streamed = false;
     int wrc = 0;
-    if (rc == TRON_OK && !multi_gpu && cfg.adjoint && dims.nz > 1 && !same_file) {
+    if (rc == TRON_OK && will_stream) {
         // ---- streamed: blocks of slices, each started when its spokes have been read, each written when it is done ----
         streamed = true;
         const uint64_t out_off = ra_data_offset(&out);
         wrc = ra_write_header(&out, outfile);
         const size_t spoke_bytes = (size_t)dims.nro * dims.nc * dims.nt * (cfg.input_half ? 4 : 8);
         const size_t img_bytes = (size_t)dims.nt * dims.nx * dims.ny * sizeof(tron_float2);
-        const int nblocks = std::max(1, std::min(16, dims.nz / 48));
         std::atomic<int> blocks_done(0);
         std::atomic<bool> stop(false);
         std::thread writer([&]() {

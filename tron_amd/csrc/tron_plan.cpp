@@ -282,7 +282,15 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
     if (!cfg->adjoint) p->chunk = p->chunk_cap = std::max(1, chunk);
 
     int rc = TRON_OK;
-    auto bail = [&](int code) { tron_plan_destroy(p); return code; };
+    // The deapodisation table (65 k libm sinhf / sinf at the metric shape, 260 k for a forward plan: the longest host table by far) is
+    // filled by a helper thread while this one builds and uploads everything else; joined where it is uploaded.
+    std::vector<float> dea(cfg->adjoint ? (size_t)d.nx * d.nx : n2);
+    std::thread dea_thread([&]() {
+        if (cfg->adjoint) build_deapod_table(d.nx, cfg->kernwidth, cfg->gridos, dea.data());                          // src/tron.cu:635
+        else if (d.nxos == d.nyos) build_deapod_table(d.nxos, cfg->kernwidth, 1.f, dea.data());                     // src/tron.cu:643
+        else build_deapod_table_rect(d.nyos, d.nxos, cfg->kernwidth, 1.f, dea.data());
+    });
+    auto bail = [&](int code) { if (dea_thread.joinable()) dea_thread.join(); tron_plan_destroy(p); return code; };
     if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess)
         return bail(fail(TRON_ERR_HIP, "hipStreamCreate failed"));
 
@@ -385,8 +393,7 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
                 p->arc_zper = 0;                                    // 0: by launch size (tron_pipeline.cpp)
             }
         }
-        std::vector<float> dea((size_t)d.nx * d.nx);
-        build_deapod_table(d.nx, cfg->kernwidth, cfg->gridos, dea.data());        // src/tron.cu:635
+        dea_thread.join();
         if ((rc = upload(&p->d_deapod, dea.data(), dea.size() * sizeof(float)))) return bail(rc);
         if (cfg->niter > 0) {
             // CGNR applies the forward operator too (src/tron.cu:691): its deapodisation table and, for linear angles,
@@ -403,9 +410,7 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
             }
         }
     } else {
-        std::vector<float> dea(n2);
-        if (d.nxos == d.nyos) build_deapod_table(d.nxos, cfg->kernwidth, 1.f, dea.data());             // src/tron.cu:643
-        else build_deapod_table_rect(d.nyos, d.nxos, cfg->kernwidth, 1.f, dea.data());
+        dea_thread.join();
         if ((rc = upload(&p->d_deapod, dea.data(), dea.size() * sizeof(float)))) return bail(rc);
     }
     unsigned int zero = 0;
