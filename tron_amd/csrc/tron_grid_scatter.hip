@@ -85,7 +85,7 @@ struct ScatLds {
     unsigned long long acc[NC][G::kPitch * G::kStride];          // (re << 32) + im, fixed point
     unsigned dmax_bits[2];                                        // largest |d| dcf of the rounds so far, by round parity
     unsigned pad[2];
-    unsigned smax[kScatMaxSpokes];                               // per run entry (spoke segment): its largest |d| dcf so far, float bits (round 6)
+    float psum[2][G::kWaves];                                    // every wave's sum of |d| dcf over its records of a round, by round parity (round 6)
     // a wave's next round of the member table (arc_prep_kernel: 80 bytes per group of 64 records), copied by LDS-DMA a round ahead
     unsigned char recb[G::kWaves][ScatCfg<NC, TILE>::R * 80];
 };
@@ -235,7 +235,6 @@ grid_scatter_kernel(const GridParams p)
         constexpr int N4 = NC * kScatPitch * kScatStride / 2;
         for (int i = tid; i < N4; i += kScatThreads) a4[i] = make_uint4(0u, 0u, 0u, 0u);
         if (tid < 2) L.dmax_bits[tid] = 0u;
-        for (int i = tid; i < kScatMaxSpokes; i += kScatThreads) L.smax[i] = 0u;
     }
 
     for (int iz = 0; iz < zper; ++iz) {
@@ -301,6 +300,7 @@ grid_scatter_kernel(const GridParams p)
         const int pbeg = wave * quota, pend = min(total, pbeg + quota);
         SPROF_MARK(2);                                          // first member of the wave's quarter
         float run_max = 0.f;                                    // largest weighted sample of the rounds so far (workgroup-uniform)
+        float run_sum = 0.f;                                    // ... and the sum of all of them
         int e2 = 0;
         bool have_scale = false;
         float S = 1.0f, invS = 1.0f;
@@ -347,7 +347,7 @@ grid_scatter_kernel(const GridParams p)
             }
             SPROF_MARK(9);                                      // entries, loads issued
             // ---- largest density-compensated |re|, |im| ----
-            float mxv = 0.f;
+            float mxv = 0.f, msum = 0.f;
 #pragma unroll
             for (int q = 0; q < R; ++q) {
                 if (meta[q] >> 31) {
@@ -358,37 +358,38 @@ grid_scatter_kernel(const GridParams p)
                     for (int c = 0; c < NC; ++c)
                         if (c < ncb) mq = fmaxf(mq, fmaxf(fabsf(dreg[q][c].x), fabsf(dreg[q][c].y)) * sdc);
                     if (!(mq < 3.0e38f)) mq = 3.0e38f;          // inf / NaN in the data: garbage either way; keep the scale finite
-                    // ... and the largest of the record's SPOKE SEGMENT (an integer maximum over float bits: exact in any order)
-                    atomicMax(&L.smax[meta[q] & 511u], __float_as_uint(mq));
                     mxv = fmaxf(mxv, mq);
+                    msum += mq;                                 // (in q order: the same sum every run)
                 }
             }
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) mxv = fmaxf(mxv, __shfl_xor(mxv, o));
+            for (int o = 32; o > 0; o >>= 1) {
+                mxv = fmaxf(mxv, __shfl_xor(mxv, o));
+                msum += __shfl_xor(msum, o);                    // xor butterfly of a commutative operation: the same bits in every lane
+            }
             const int slot = (r0 / R) & 1;                      // (two slots, never cleared inside a slice: a fast wave's next round cannot disturb this one)
-            if (lane == 0) atomicMax(&L.dmax_bits[slot], __float_as_uint(fmaxf(mxv, run_max)));
+            if (lane == 0) {
+                atomicMax(&L.dmax_bits[slot], __float_as_uint(fmaxf(mxv, run_max)));
+                L.psum[slot][wave] = fminf(msum, 3.0e38f);
+            }
             SPROF_MARK(4);                                      // front: walk, loads, maximum
             __syncthreads();
             SPROF_MARK(5);
             const float new_max = __uint_as_float(L.dmax_bits[slot]);
-            // S = 2^e, the largest with  bound * S < 2^31,  bound = what the |re| or |im| sum of ONE point can reach:
-            //   one spoke adds at most (its largest |d| dcf in the tile) x (the window products along a line: <= 1.65 K(0)^2, scat_wsum = 1.75 K(0)^2),
-            //   so a point's sum stays below  scat_wsum x min( M x the tile's largest |d| dcf,  the SUM over the tile's spoke segments of each one's
-            //   largest |d| dcf )  -- M = the most spokes whose line can pass one of the tile's 2x2 blocks (arc_prep_kernel: the run header).
-            // Until round 5 only the first term stood, and ONE large sample (a spike 300 x its neighbourhood in a 640-spoke window: 1.8e-5 relative
-            // L2 against the oracle, tests/test_gpu_scatter.py) set the step of the whole tile; the second term charges a spike to its own spoke.
-            // Deterministic: the per-segment maxima are integer maxima, their sum is taken by every wave in the same fixed order.
-            float ssum = 0.f;
-            {
-                const int ns_run = hdr.x;
+            // S = 2^e, the largest with  bound * S < 2^31,  bound = what the |re| or |im| sum of ONE point can reach, the smaller of
+            //   (a) M x the tile's largest |d| dcf x 1.75 K(0)^2: M = the most spokes whose line can pass one of the tile's 2x2 blocks (arc_prep_kernel:
+            //       the run header), and one spoke adds at most its largest sample times the window products along a line (<= 1.65 K(0)^2);
+            //   (b) K(0)^2 x the SUM of |d| dcf over every record of the tile so far: a sample adds at most K(0)^2 of itself to a point.
+            // Until round 5 only (a) stood, and ONE large sample (a spike 300 x its neighbourhood in a 640-spoke window: 1.8e-5 relative L2 against
+            // the oracle, tests/test_gpu_scatter.py) set the step of the whole tile; (b) charges a spike as one sample, and data that falls off
+            // with the radius as the sum it is.  On flat data (a) is the smaller one, as before.  Deterministic: every wave's sum is taken in a
+            // fixed order, the waves' sums are added in wave order by everybody.
+            float rsum = 0.f;
 #pragma unroll
-                for (int k = 0; k < kScatMaxSpokes / 64; ++k)
-                    if (k * 64 < ns_run) ssum += __uint_as_float(L.smax[k * 64 + lane]);      // (entries beyond the run are zero)
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) ssum += __shfl_xor(ssum, o);                   // xor butterfly: the same bits in every lane and wave
-            }
+            for (int ww = 0; ww < kWaves; ++ww) rsum += L.psum[slot][ww];
+            run_sum = fminf(run_sum + rsum, 3.0e38f);
             {
-                const float bound = fminf(new_max * (float)max(mwin, 1), ssum) * p.scat_wsum;
+                const float bound = fminf(new_max * (float)max(mwin, 1) * p.scat_wsum, run_sum * p.scat_wmax);
                 int e_new = have_scale ? e2 : 0;
                 if (bound > 0.f) {
                     const int ex = (int)((__float_as_uint(bound) >> 23) & 255u) - 127;      // bound < 2^(ex + 1)
@@ -569,7 +570,6 @@ grid_scatter_kernel(const GridParams p)
                 for (int k = tid; k < kRing; k += kScatThreads) L.acc[c][halo_index(k)] = 0ull;
             }
             if (tid < 2) L.dmax_bits[tid] = 0u;
-            for (int i = tid; i < hdr.x; i += kScatThreads) L.smax[i] = 0u;
             if (more) table_to_lds(hdr_next.x);                 // (every wave is past the scatter: the old table is done with)
         }
         SPROF_MARK(8);                                          // store, next slice's table
@@ -645,7 +645,7 @@ bool grid_scatter_supported(int nchan, int nxos, int nro, int npe, float W, int 
 hipError_t launch_grid_scatter(const GridParams &p, int half_in, int first_plain, hipStream_t s)
 {
     const int nc = p.nchan - p.coil0;
-    if (p.out_p != 1 || p.inner_r0 < 3 || !p.arc_hdr || !p.arc_ent || !p.arc_off || !p.arc_rec || !p.arc_rbase || (p.scat_tile != 32 && p.scat_tile != 64) || (p.nxos / 2) % p.scat_tile != 0 || !p.kb_lut || p.lut_entries > kArcLutEntries || p.npe > kArcMaxNpe || !(p.scat_wsum > 0.f) || (int)p.lut_scale != kScatLutS
+    if (p.out_p != 1 || p.inner_r0 < 3 || !p.arc_hdr || !p.arc_ent || !p.arc_off || !p.arc_rec || !p.arc_rbase || (p.scat_tile != 32 && p.scat_tile != 64) || (p.nxos / 2) % p.scat_tile != 0 || !p.kb_lut || p.lut_entries > kArcLutEntries || p.npe > kArcMaxNpe || !(p.scat_wsum > 0.f) || !(p.scat_wmax > 0.f) || (int)p.lut_scale != kScatLutS
         || !grid_scatter_supported(nc, p.nxos, p.nro, p.npe, p.W, half_in) || (reinterpret_cast<uintptr_t>(p.nudata) & (half_in ? 3 : 7)) != 0
         || (nc == 2 && (reinterpret_cast<uintptr_t>(p.nudata) & (half_in ? 7 : 15)) != 0))
         return hipErrorInvalidValue;

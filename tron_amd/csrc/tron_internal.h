@@ -87,7 +87,8 @@ struct GridParams {
     int lut_entries, lut_bias;
     float lut_scale;
     int arc_zper;                      // consecutive slices one workgroup grids in turn (the table stays in LDS)
-    float scat_wsum;                   // scatter kernel: bound of the window products one spoke adds to one grid point, 4 K(0)^2 (its fixed-point scale)
+    float scat_wsum;                   // scatter kernel: bound of the window products one spoke adds to one grid point, 1.75 K(0)^2 (its fixed-point scale)
+    float scat_wmax;                   //                 ... and of what one SAMPLE adds: K(0)^2 (with a margin of 1e-5)
     // centre kernel (tron_grid_centre.hip): the angle-sorted spoke lists of the arc kernel's plan, kept
     const unsigned short *cen_order;   // [window][npe] window-relative spoke index, ascending line angle (mod pi)
     const uint32_t *cen_win;           // [window][cen_ngroups] the block's run of that list: first entry | entries << 16 (circular)

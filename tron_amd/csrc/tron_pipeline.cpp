@@ -275,6 +275,7 @@ int adjoint_run_raw(tron_plan *p, void *d_out, const void *d_in_z0, int zfirst, 
                         ga.npe = std::min(d.npe1work, (q + 1) * p->arc_pass_npe) - q * p->arc_pass_npe;
                         ga.arc_accumulate = q > 0;
                         ga.scat_wsum = p->scat_wsum;
+                        ga.scat_wmax = p->scat_wmax;
                         if (p->scatter && p->scat_tile == 64) {
                             ga.tile_order = p->d_tile_order64;          // (its own list of 64-tiles; no inner-tile entries in front)
                             HIP_TRY(launch_grid_scatter(ga, p->cfg.input_half, 0, st));

@@ -390,6 +390,7 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
                 // spacing sum to at most 1.65 K(0)^2 for every direction and offset at W = 2 (axis 1.61, diagonal 1.65, 2 : 1 1.64; less for
                 // narrower windows) -- 1.75 with margin.  (4 K(0)^2 until round 5: one to two bits of the fixed-point sums given away)
                 p->scat_wsum = (float)(1.75 * kb_peak(cfg->kernwidth) * kb_peak(cfg->kernwidth));
+                p->scat_wmax = (float)(1.00001 * kb_peak(cfg->kernwidth) * kb_peak(cfg->kernwidth));
                 p->arc_zper = 0;                                    // 0: by launch size (tron_pipeline.cpp)
             }
         }

@@ -120,7 +120,7 @@ struct tron_plan {
     // arc gridding kernel (tron_grid_arc.hip): per (window, tile) run tables built at plan creation, Kaiser-Bessel table
     bool arc = false;
     bool scatter = false;                 // ... gridded by grid_scatter_kernel (one or two channels, tron_grid_scatter.hip): same tables, one batch per run
-    float scat_wsum = 0;
+    float scat_wsum = 0, scat_wmax = 0;
     int scat_tile = 32;                   // ... on 32 x 32 or 64 x 64 tiles (its run tables are made for one of them)
     int scat_tile_max = 64;               // ... 32 once 64-tile tables have overflowed (tron_plan_create's retry)
     int relief_r0_binned = 0;             // the binned kernel's own inner radius (scatter plans lower relief_r0: restored when they fall back)
