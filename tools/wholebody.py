@@ -13,9 +13,13 @@ inp, out = os.path.join(tmp, "wb_in.ra"), os.path.join(tmp, "wb_out.ra")
 t0 = time.perf_counter()
 ra.write(inp, synth.kspace(6, 512, 20271, seed=synth.SEED_BASE + 3))
 print(f"wrote {inp}: {os.path.getsize(inp)} B in {time.perf_counter()-t0:.1f} s")
+extra = os.environ.get("WB_OPTIONS", "")           # e.g. WB_OPTIONS=pin=1: appended to TRON_OPTIONS
+pause = float(os.environ.get("WB_PAUSE", "2"))     # seconds between runs: a process that starts while the previous one's GPU context is
+                                                   # still being torn down pays 0.15 s more for its own (the HIP runtime line of -v)
 for mode in ("fast", "exact"):
-    env = dict(os.environ, TRON_OPTIONS=f"kb={mode}")
-    for rep in range(2):
+    env = dict(os.environ, TRON_OPTIONS=f"kb={mode}" + ("," + extra if extra else ""))
+    for rep in range(3 if mode == "fast" else 1):
+        time.sleep(pause)
         t0 = time.perf_counter()
         r = subprocess.run([os.path.join(ROOT, "tron_amd/bin/tron"), "-v", "-u", "0.4", "-d", "21", "-a", "-G", inp, out], capture_output=True, text=True, env=env)
         dt = time.perf_counter() - t0

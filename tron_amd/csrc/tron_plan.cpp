@@ -282,6 +282,9 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
     if (!cfg->adjoint) p->chunk = p->chunk_cap = std::max(1, chunk);
 
     int rc = TRON_OK;
+    std::vector<std::pair<const char *, double>> laps;      // -v: where the table time goes
+    auto lap = [&](const char *what) { laps.emplace_back(what, since()); };
+    lap("start");
     // The deapodisation table (65 k libm sinhf / sinf at the metric shape, 260 k for a forward plan: the longest host table by far) is
     // filled by a helper thread while this one builds and uploads everything else; joined where it is uploaded.
     std::vector<float> dea(cfg->adjoint ? (size_t)d.nx * d.nx : n2);
@@ -293,6 +296,7 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
     auto bail = [&](int code) { if (dea_thread.joinable()) dea_thread.join(); tron_plan_destroy(p); return code; };
     if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess)
         return bail(fail(TRON_ERR_HIP, "hipStreamCreate failed"));
+    lap("stream");
 
     p->ntrig = trig_table_size(*cfg, d);
     {   // 32x32 tiles, centre first: binned gridding and tiled degridding
@@ -304,10 +308,13 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
             build_degrid_groups(d.nxos, kBinnedTile, d.npe1work, d.nro, target, p->dg_group_end);
         }
     }
+    lap("tile order");
     if (cfg->adjoint) {
         std::vector<uint32_t> band(n2);
         build_band_table(d.nxos, cfg->kernwidth, band.data());
+        lap("band table");
         if ((rc = upload(&p->d_band, band.data(), band.size() * sizeof(uint32_t)))) return bail(rc);
+        lap("band upload");
         p->tiles_per_row = (d.nxos + kTile - 1) / kTile;
         p->ntiles = p->tiles_per_row * p->tiles_per_row;
         p->binned = p->kb_mode == TRON_KB_FAST && cfg->kernwidth <= 3.f;
@@ -368,6 +375,7 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
                 p->scatter = p->scatter && strcmp(gk, "binned") != 0 && strcmp(gk, "arc") != 0;
                 p->arc = p->arc && strcmp(gk, "binned") != 0;
             }
+            lap("relief orders");
             p->relief_r0_binned = p->relief_r0;
             if (p->scatter) {
                 p->arc = true;
@@ -380,7 +388,9 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
                 const int r0 = sub_ <= 640 ? 5 : p->relief_r0;
                 p->relief_r0 = std::min(p->relief_r0, r0);
             }
+            lap("kernel choice");
             if (p->arc && (rc = arc_setup(p, band))) return bail(rc);
+            lap("centre tables");
             if (p->arc) {
                 std::vector<float> lut(6 * (size_t)kArcLutEntries);
                 p->lut_entries = build_kb_pair_lut(cfg->kernwidth, kArcLutEntries, lut.data(), &p->lut_scale, &p->lut_bias, &p->lut_err);
@@ -394,7 +404,9 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
                 p->arc_zper = 0;                                    // 0: by launch size (tron_pipeline.cpp)
             }
         }
+        lap("pair table");
         dea_thread.join();
+        lap("deapod join");
         if ((rc = upload(&p->d_deapod, dea.data(), dea.size() * sizeof(float)))) return bail(rc);
         if (cfg->niter > 0) {
             // CGNR applies the forward operator too (src/tron.cu:691): its deapodisation table and, for linear angles,
@@ -432,6 +444,7 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
     // The angle-dependent tables of the plan's own skip_angles: the build tron_plan_retarget repeats for later ones (tron_traj.cpp), here on
     // the plan's stream and waited for.  Run tables that overflow (more spokes through a tile than a run holds, ...) send the plan to the
     // next formulation down -- 64-tiles -> 32-tiles -> arc kernel -> binned kernel -- instead of straight to the binned one (round 5).
+    lap("fft tables");
     const double t_arc0 = since();
     for (;;) {
         TrajTables &T = p->traj[0];
@@ -478,6 +491,9 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
         printf("tronhip: plan %.3f s = HIP runtime + code objects %.3f, tables %.3f (of which the arc kernel's run tables %.3f), work buffers %.3f\n",
                since(), t_runtime, t_tables - t_runtime, t_arc1 - t_arc0, t_work - t_tables);
     if (cfg->verbose) printf("tronhip: of the start-up, the HIP runtime itself %.3f s, loading the code objects %.3f s\n", t_hipinit, t_runtime - t_hipinit);
+        printf("tronhip: tables (ms):");
+        for (size_t i = 1; i < laps.size(); ++i) printf(" %s %.2f", laps[i].first, 1e3 * (laps[i].second - laps[i - 1].second));
+        printf(" | trajectory tables %.2f\n", 1e3 * (t_arc1 - t_arc0));
     }
     p->sync_each = debug_token("sync");                      // TRON_DEBUG=sync: synchronise after every stage and name the failing one
     if (const char *dk = tuning_env("TRON_DEGRID_KERNEL")) {     // simple: the thread-per-sample audit kernel; tile: never the streaming kernel
