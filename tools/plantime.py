@@ -10,7 +10,7 @@ nz = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 npe = int(sys.argv[3]) if len(sys.argv) > 3 else 402
 us = 0.7852 if npe == 402 else (npe + 0.5) / 512
 for rep in range(4):
-    cfg = lib.default_config(adjoint=1, golden_angle=1, data_undersamp=us, prof_slide=npe, verbose=1 if rep else 0)
+    cfg = lib.default_config(adjoint=1, golden_angle=1, data_undersamp=us, prof_slide=npe, verbose=1)
     dims = lib.derive_dims(cfg, (nc, 1, 512, npe * nz, 1))
     t0 = time.perf_counter()
     plan = lib.Plan(cfg, dims)
