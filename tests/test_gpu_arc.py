@@ -83,6 +83,7 @@ CASES = [
     (4, 256, 90, 2, dict(golden_angle=0, gridos=2.5)),            # 320^2 grid, linear angles
     (1, 256, 100, 2, dict(golden_angle=1, gridos=1.5)),           # one coil
     # more than 1 024 spokes per window: the arc kernel runs in passes over <= 1 024 spokes, the later ones adding to the grid
+    (8, 256, 900, 2, dict(golden_angle=1)),                       # two passes of 450 (813 .. 1 024 spokes: the binned kernel until round 6)
     (2, 256, 1300, 2, dict(golden_angle=1)),                      # two passes of 650
     (8, 128, 2100, 2, dict(golden_angle=1, prof_slide=700)),      # three passes of 700, sliding windows
     (4, 256, 1030, 1, dict(golden_angle=0)),                      # two passes of 515, linear angles

@@ -920,7 +920,7 @@ bool grid_arc_supported(int nchan, int nxos, int nro, int npe, float W, int half
     const bool coils = half_in ? (nchan >= 4 && (nchan & 1) == 0) : (nchan == 1 || (nchan & 1) == 0);
     // widths without a Kaiser-Bessel pair table (W <= 1, W 2^k no integer; build_kb_pair_lut) stay on the binned kernel
     // nro != nxos (any -o but 2): the truncating resample of src/tron.cu:517, where its float form is exact (it is for every size tried)
-    return nchan >= 1 && coils && (nro == nxos || (nro >= 2 && arc_resample_exact(nxos, nro))) && nxos <= 2048 && npe <= kArcMaxPasses * kArcMaxNpe && W <= 3.0f && kb_pair_lut_scale(W, kArcLutEntries) > 0
+    return nchan >= 1 && coils && (nro == nxos || (nro >= 2 && arc_resample_exact(nxos, nro))) && nxos <= 2048 && npe <= kArcMaxWindow && W <= 3.0f && kb_pair_lut_scale(W, kArcLutEntries) > 0
            && (nxos / 2) % kArcTile == 0 && nxos >= 4 * kArcTile && (long long)nro * npe * nchan < (1ll << 28);
 }
 

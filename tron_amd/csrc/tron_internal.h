@@ -149,7 +149,11 @@ hipError_t launch_grid_arc(const GridParams &p, int half_in, int first_plain, hi
 hipError_t launch_grid_centre(const GridParams &p, int half_in, hipStream_t s);
 hipError_t warm_grid_centre();
 constexpr int kArcMaxNpe = 1024;       // spokes of one window the arc kernel's run tables hold (arc_prep_kernel: thread = spoke, four per thread)
-constexpr int kArcMaxPasses = 4;       // windows of more spokes are gridded in passes of <= kArcMaxNpe, the later ones adding to the grid
+constexpr int kArcPassNpe = 812;       // ... but a window of more than this many is gridded in PASSES of at most this many, the later ones adding to the grid: a centre
+                                       // tile's run holds 0.63 of a pass's spokes (its quadrant of directions + 2 asin(W sqrt(2) / 14)) and has 512 entries.  (Until round 6
+                                       // passes began at 1 025 spokes, and windows of 813 .. 1 024 overflowed their run tables: binned kernel.)
+constexpr int kArcMaxWindow = 4096;    // most spokes of one window the arc / scatter kernels take (grid_arc_supported)
+constexpr int kArcMaxPasses = 6;       // windows of more spokes are gridded in passes of <= kArcMaxNpe, the later ones adding to the grid
 bool grid_arc_supported(int nchan, int nxos, int nro, int npe, float W, int half_in);
 int grid_arc_nrec(int nchan, int half_in);
 constexpr int kArcLutEntries = 400;    // Kaiser-Bessel pair-table entries held in LDS (build_kb_pair_lut: (2 W + 1) s + 4 of them, s a power of two, W > 1)

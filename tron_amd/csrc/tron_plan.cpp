@@ -148,7 +148,7 @@ static int arc_setup(tron_plan *p, const std::vector<uint32_t> &band)
         // Windows of more than kArcMaxNpe spokes: the run tables are built, and the arc kernel run, once per PASS over the spokes
         // [q sub, (q + 1) sub) of every window (each pass's list = the sorted list with the other spokes left out); the passes
         // after the first add to the grid.  The centre kernel takes the whole window at once.
-        const int npass = (npe + kArcMaxNpe - 1) / kArcMaxNpe, sub = (npe + npass - 1) / npass;
+        const int npass = (npe + kArcPassNpe - 1) / kArcPassNpe, sub = (npe + npass - 1) / npass;
         p->arc_passes = npass;
         p->arc_nwin = nwin;
         p->arc_pass_npe = sub;
@@ -249,9 +249,22 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
     HIP_TRY(warm_cgnr());
     HIP_TRY(warm_traj());
     HIP_TRY(hipDeviceSynchronize());
-    const double t_runtime = since();                // HIP runtime + code objects (the first plan of a process pays for both)
-
     tron_plan *p = new tron_plan();
+    p->cfg = *cfg;
+    {   // The plan's stream and its first host-to-device copy, still on the runtime's account: the FIRST hipStreamCreate of a process takes
+        // 8 ms and its first hipMemcpy 7.7 ms (the copy engines' staging buffers), 0.2 + 0.07 ms ever after (profiles/round6_plan_time_breakdown.log;
+        // until round 6 they were booked as "tables", 15 of the 18 ms a process's first plan showed there).
+        const unsigned int zero0 = 0;
+        hipError_t e0 = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
+        if (e0 == hipSuccess) e0 = hipMalloc(reinterpret_cast<void **>(&p->d_errflag), sizeof(zero0));
+        if (e0 == hipSuccess) e0 = hipMemcpy(p->d_errflag, &zero0, sizeof(zero0), hipMemcpyHostToDevice);
+        if (e0 != hipSuccess) {
+            tron_plan_destroy(p);
+            return fail(TRON_ERR_HIP, "cannot create the plan's stream: %s", hipGetErrorString(e0));
+        }
+    }
+    const double t_runtime = since();                // HIP runtime + code objects + first stream and copy (the first plan of a process pays for all of them)
+
     p->cfg = *cfg;
     p->d = d;
     p->share_z0 = share_z0;
@@ -294,9 +307,6 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
         else build_deapod_table_rect(d.nyos, d.nxos, cfg->kernwidth, 1.f, dea.data());
     });
     auto bail = [&](int code) { if (dea_thread.joinable()) dea_thread.join(); tron_plan_destroy(p); return code; };
-    if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess)
-        return bail(fail(TRON_ERR_HIP, "hipStreamCreate failed"));
-    lap("stream");
 
     p->ntrig = trig_table_size(*cfg, d);
     {   // 32x32 tiles, centre first: binned gridding and tiled degridding
@@ -384,7 +394,7 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
                 // tile must still hold one side of a spoke only: more than W sqrt(2) = 2.83): 9 of a spoke's samples instead of 27.
                 // (A centre tile's run holds every spoke whose line is inside tile + W at radius r0: the quadrant's 90 degrees + 2 asin(W sqrt(2) / r0) --
                 // 0.76 of a window's spokes at r0 = 5, 0.59 at 14 -- and a run has 512 entries: windows (passes) of more than 640 spokes keep 14.)
-                const int npass_ = (d.npe1work + kArcMaxNpe - 1) / kArcMaxNpe, sub_ = (d.npe1work + npass_ - 1) / npass_;
+                const int npass_ = (d.npe1work + kArcPassNpe - 1) / kArcPassNpe, sub_ = (d.npe1work + npass_ - 1) / npass_;
                 const int r0 = sub_ <= 640 ? 5 : p->relief_r0;
                 p->relief_r0 = std::min(p->relief_r0, r0);
             }

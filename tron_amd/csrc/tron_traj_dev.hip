@@ -13,7 +13,7 @@
 namespace tron {
 
 constexpr int kTrajThreads = 256;
-constexpr int kTrajMaxNpe = kArcMaxNpe * kArcMaxPasses;     // 4 096 spokes per window
+constexpr int kTrajMaxNpe = kArcMaxWindow;                  // 4 096 spokes per window
 
 // grid = windows, block = 256.  Rank of spoke k = how many spokes of the window come before it in (line angle, acquisition index)
 // order: the stable sort of build_arc_tables (rounds 3-5, host) as a counting rank -- npe^2 comparisons of LDS broadcasts, 160 k for
