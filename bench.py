@@ -525,7 +525,7 @@ def main():
         t_w = time.perf_counter()
         while time.perf_counter() - t_w < 0.25:
             step()
-        fence()
+        plan.sync()                              # (rank 0 only here: no barrier)
         plan.timing(True)
         plan.timing_reset()
         for _ in range(reps):
@@ -601,7 +601,8 @@ def main():
                        "kb_mode_note": ("fast = tabulated Kaiser-Bessel weights (arc and centre kernels: quadratic pieces, the reference's exact support) + their own summation order: within 1e-5 of the reference arithmetic (measured on the "
                                         "line: parity_rel_l2_vs_oracle), NOT bit-identical; --kb exact is the bit-identical gather, ~2.7x slower"
                                         if args.kb == "fast" else "exact = the reference's expression tree and summation order, bit-identical interpolation"),
-                       "parallelism": f"slices sharded over {world} GPU(s), one process each, no collective on the data path (gloo barrier only)",
+                       "parallelism": f"slices sharded over {world} GPU(s), one process each, no collective on the data path (gloo barrier only)"
+                                      + (f"; rank 0 bound to the {len(bound_cpus)} CPUs of its GPU's NUMA node" if bound_cpus else ""),
                        **({"ranks_share_one_gpu": True} if share and ndev < world else {})},
             "algorithmic_gbps_per_gpu": round(alg_gbps, 1), "algorithmic_frac_of_peak": round(alg_gbps / HBM_PEAK_GBPS, 4),
             "copy_ceiling_guide_gbps": 6290.0,      # MI355X_MICROARCH.md: float4 copy, 79 % of the 8 TB/s spec (round 5's own torch copy probe read 5.0 TB/s and is gone)

@@ -6,7 +6,7 @@
 export TRON_TUNING=1   # the library reads TRON_* switches only under TRON_TUNING=1
 R=$GRAFT_REPO_ROOT; key=$1; shift; out=$R/gpurun_out/traffic/$key; mkdir -p $out; cd /tmp; export TMPDIR=/tmp TRON_BENCH_NO_BURN_IN=1   # (no burn-in child under the profiler)
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace -d $out/$c --output-format csv -- python3 $R/bench.py --steps 6 --warmup 2 --sustain 0 --cpu-slices 0 --no-irt --no-check "$@" > $out/$c.log 2> $out/$c.err
+  rocprofv3 --pmc $c --kernel-trace -d $out/$c --output-format csv -- python3 $R/bench.py --steps 6 --warmup 2 --sustain 0 --cpu-slices 0 --no-irt --no-check --no-fresh --no-one-coil "$@" > $out/$c.log 2> $out/$c.err
 done
 CMD="bench.py --steps 6 --warmup 2 $*" OUT=$out KEY=$key python3 - <<'PY'
 import csv, glob, collections, json, os, sys

@@ -34,7 +34,7 @@ static int adjoint_block(tron_plan *p, tron_float2 *h_out_block, const void *h_i
     const unsigned char *src = reinterpret_cast<const unsigned char *>(h_in_block);
     tron_float2 *dst = h_out_block;
     // Pinning the caller's buffers makes the copies truly asynchronous (and the two directions concurrent): the default
-    // (cfg.pin_host = 1, as the reference pins its output, src/tron.cu:967; TRON_PIN_HOST=0 under TRON_TUNING=1 turns it off).
+    // (cfg.pin_host = 1, as the reference pins its output, src/tron.cu:967; the `tron` binary's streamed blocks turn it off, tron_main.cpp).
     // It costs a page walk of the whole range per call, so calls that move less than kPinThreshold bytes skip it:
     // pageable copies are staged by the runtime at the same PCIe rate and still overlap the kernels of the previous chunk.
     constexpr size_t kPinThreshold = (size_t)8 << 20;

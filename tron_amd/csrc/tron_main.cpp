@@ -5,11 +5,11 @@
 //   tron [-3aGhv] [-B blocks] [-d prof_slide] [-g gpu] [-i niter] [-k width] [-o gridos]
 //        [-r nro] [-s skip_angles] [-T threads] [-u data_undersamp] <infile.ra> [outfile.ra]
 //
-// Extensions, via the environment so the flag set stays the reference's:
-//   TRON_KB_MODE=fast|exact    Kaiser-Bessel evaluation.  fast (default): polynomial window + binned gridding,
-//                              within 1e-5 relative L2 of the reference arithmetic (measured ~1e-7);
-//                              exact: the reference's expression tree and summation order, bit for bit
-//   TRON_CHUNK_SLICES=n        slices per device batch
+// Extensions, via ONE environment variable so the flag set stays the reference's:
+//   TRON_OPTIONS=kb=fast|exact,gpus=N,combine=walsh|sos,patch=N,cgnr_consistent=1,pin=0|1
+//     kb     Kaiser-Bessel evaluation.  fast (default): tabulated / polynomial window, each kernel's own summation order, within 1e-5
+//            relative L2 of the reference arithmetic (measured ~1e-7); exact: the reference's expression tree and summation order, bit for bit
+//     gpus   one worker thread + plan per GPU (as -g all / -g 0,1,...)
 // A complex-half input (eltype 4, elbyte 4) is accepted for -a and gridded from half storage.
 #include <stdio.h>
 #include <stdlib.h>
@@ -54,7 +54,7 @@ int main(int argc, char *argv[])
 {
     tron_config cfg;
     tron_config_default(&cfg);
-    bool multi_gpu = false;              // -g all | -g 0,1,... | TRON_GPUS=n: one worker thread + plan per device
+    bool multi_gpu = false;              // -g all | -g 0,1,... | TRON_OPTIONS gpus=n: one worker thread + plan per device
     std::vector<int> gpu_list;
     int c;
     opterr = 0;

@@ -458,7 +458,7 @@ int forward_run(tron_plan *p, void *d_out, const void *d_in, int nimg, const flo
             else if (!p->degrid_simple)
                 HIP_TRY(launch_degrid_tile(g, p->kb_mode, p->stream));  // every width the plan accepts (W <= 4), square or not
             else
-                HIP_TRY(launch_degrid(g, p->kb_mode, p->stream));       // TRON_DEGRID_SIMPLE=1: the thread-per-sample audit kernel
+                HIP_TRY(launch_degrid(g, p->kb_mode, p->stream));       // TRON_DEGRID_KERNEL=simple: the thread-per-sample audit kernel
         }
     }
     return TRON_OK;

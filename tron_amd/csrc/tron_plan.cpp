@@ -251,13 +251,23 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
     HIP_TRY(hipDeviceSynchronize());
     tron_plan *p = new tron_plan();
     p->cfg = *cfg;
-    {   // The plan's stream and its first host-to-device copy, still on the runtime's account: the FIRST hipStreamCreate of a process takes
-        // 8 ms and its first hipMemcpy 7.7 ms (the copy engines' staging buffers), 0.2 + 0.07 ms ever after (profiles/round6_plan_time_breakdown.log;
-        // until round 6 they were booked as "tables", 15 of the 18 ms a process's first plan showed there).
+    {   // The plan's stream and the process's first host-to-device copies, still on the runtime's account: the FIRST hipStreamCreate of a process
+        // takes 8 ms and its first copy of a megabyte from pageable memory 7.4-7.7 ms (the copy path's staging buffers), 0.2 + 0.07 ms ever after
+        // (profiles/round6_plan_time_breakdown.log; until round 6 they were booked as "tables", 15 of the 18 ms a process's first plan showed there).
         const unsigned int zero0 = 0;
         hipError_t e0 = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
         if (e0 == hipSuccess) e0 = hipMalloc(reinterpret_cast<void **>(&p->d_errflag), sizeof(zero0));
         if (e0 == hipSuccess) e0 = hipMemcpy(p->d_errflag, &zero0, sizeof(zero0), hipMemcpyHostToDevice);
+        static std::once_flag first_copy;                     // (the staging path of copies from pageable memory comes up at the first LARGE one: 7.4 ms, once per process)
+        std::call_once(first_copy, [&]() {
+            void *scratch = nullptr;
+            std::vector<unsigned char> host((size_t)1 << 20, 0);
+            if (e0 == hipSuccess && hipMalloc(&scratch, host.size()) == hipSuccess) {
+                (void)hipMemcpy(scratch, host.data(), host.size(), hipMemcpyHostToDevice);
+                (void)hipFree(scratch);
+            }
+            (void)hipGetLastError();
+        });
         if (e0 != hipSuccess) {
             tron_plan_destroy(p);
             return fail(TRON_ERR_HIP, "cannot create the plan's stream: %s", hipGetErrorString(e0));
