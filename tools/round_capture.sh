@@ -26,7 +26,7 @@ t forward_nc8 --forward
 t nc1_npe402_nz256_linear --linear --coils 1
 t nc8_npe402_nz256_exact --kb exact
 b default
-NI="--cpu-slices 0 --no-irt"
+NI="--cpu-slices 0 --no-irt --no-one-coil"
 b nc6 $NI --coils 6
 b nc4 $NI --coils 4
 b nc2 $NI --coils 2
@@ -67,9 +67,9 @@ if [ -f tron_amd/lib/libtronhip_cprof.so ]; then
 fi
 python tools/hostbench.py 8 256 > $out/hostbench.log 2>&1; python tools/hostbench.py 8 256 --half >> $out/hostbench.log 2>&1
 python tools/wholebody.py /tmp > $out/wholebody_cli.log 2>&1
+python tools/plantime.py 8 256 402 > $out/plan_time.log 2>&1; python tools/plantime.py 1 256 402 >> $out/plan_time.log 2>&1
 python tools/fwdbench.py 8 64 fast > $out/fwdbench.log 2>&1
 for n in 8 6 4 2 1; do python tools/gridbench.py $n 128 fast 5 2>&1 | tail -1; done > $out/gridbench.log
-timeout 120 tools/probe/cumask_main > $out/cu_mask_probe.txt 2>&1
 TRON_GRID_KERNEL=binned python tools/gridbench.py 8 128 fast 5 2>&1 | tail -1 >> $out/gridbench.log
 bash tools/ktrace.sh $tag tools/gridbench.py 8 128 fast 3 > $out/ktrace.log 2>&1
 WARM=20 python tools/gridbench.py 8 128 fast 20 2>&1 | tail -1 > $out/gridbench_warm.log
