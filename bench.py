@@ -384,7 +384,12 @@ def main():
     torch.cuda.set_device(local_rank)
     torch.zeros(1, device="cuda")
     from tron_amd import launch
-    bound_cpus = launch.bind_near_gpu(local_rank) if world > 1 and not share else []    # one rank per GPU: run on that GPU's socket
+    bound_cpus = []
+    if world > 1 and not share:                  # one rank per GPU: run on that GPU's socket (best effort: a box without NUMA information stays put)
+        try:
+            bound_cpus = launch.bind_near_gpu(local_rank)
+        except Exception as e:
+            sys.stderr.write(f"bench.py: rank {rank}: no NUMA binding ({e})\n")
     group = launch.HostGroup(rank, world)      # gloo on the host: barrier + max of wall times, nothing on the data path
 
     import ctypes
