@@ -407,6 +407,11 @@ def test_c_client_matches_the_tron_binary(tmp_path):
     tron = os.path.join(root, "tron_amd", "bin", "tron")
     assert subprocess.run([tron, "-a", "-G", inp, o2]).returncode == 0
     assert open(o1, "rb").read() == open(o2, "rb").read()
+    # a later batch of a continuing acquisition on ONE plan (tron_plan_retarget in the client) = the binary's -s (src/tron.cu:629-630)
+    assert subprocess.run([exe, "-a", "-s", "4020", inp, o1]).returncode == 0
+    assert subprocess.run([tron, "-a", "-G", "-s", "4020", inp, o2]).returncode == 0
+    assert open(o1, "rb").read() == open(o2, "rb").read()
+    assert subprocess.run([tron, "-a", "-G", inp, o2]).returncode == 0
     # the multi-GPU entry point (every visible device) and CGNR through the same client
     assert subprocess.run([exe, "-a", "-m", inp, o1]).returncode == 0
     assert open(o1, "rb").read() == open(o2, "rb").read()
