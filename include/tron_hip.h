@@ -208,9 +208,10 @@ const char *tron_plan_degrid_kernel_name(const tron_plan *plan);
 int tron_plan_shader_clock(tron_plan *plan, double *mhz);
 
 /* Wall-clock seconds tron_plan_create spent on this plan (the reference's one published time, src/RUNME4:219, clocks tron_init
-   too: src/tron.cu:973-978): [0] total, [1] HIP runtime + code objects (the first plan of a process pays for both),
-   [2] host tables and their upload, [3] of [2]: the arc / centre gridding kernels' run tables (host sort by line angle +
-   arc_prep_kernel), [4] device work buffers. */
+   too: src/tron.cu:973-978): [0] total, [1] HIP runtime + code objects + the process's first stream and first large copy (the first
+   plan of a process pays for all of them), [2] tables and their upload, [3] of [2]: the angle-dependent tables -- the (cos, sin) list
+   (host libm) and, built on the device, the sorted spoke lists, centre windows and run tables: what tron_plan_retarget rebuilds --,
+   [4] device work buffers. */
 int tron_plan_create_times(const tron_plan *plan, double seconds[5]);
 
 /* Per-stage device timing with hipEvents on the plan's stream (off by default; costs one
