@@ -206,3 +206,23 @@ def test_retarget_linear_angles_is_a_no_op():
 def test_retarget_rejects_a_null_plan():
     assert lib.load().tron_plan_retarget(None, 1) == lib.TRON_ERR_INVALID
     assert lib.load().tron_plan_retarget_times(None, (ctypes.c_double * 2)()) == lib.TRON_ERR_INVALID
+
+
+def test_retarget_under_cgnr_walsh_and_repetitions(oracle):
+    """The pipelines that sit on top of the adjoint / forward pair read the plan's current angle tables too: CGNR (the forward operator
+    inside the iteration uses the slice's own golden angles, F4), Walsh combination and nt > 1 (the uncombined fused tail).  A retargeted
+    plan against a fresh one bit for bit, CGNR also against the oracle's restatement at the new angle index."""
+    nro, npe, nz, skip = 256, 100, 2, 2468
+    us = (npe + 0.5) / nro
+    for nc, nt, extra in ((4, 1, dict(niter=2)), (4, 1, dict(coil_combine=1, walsh_patch=1)), (2, 3, dict())):
+        data = synth.kspace(nc, nro, npe * nz, seed=9760 + nc + nt, nt=nt)
+        fl = dict(golden_angle=1, prof_slide=npe, data_undersamp=us, **extra)
+        plan, dims = _plan(data, **fl)
+        with plan:
+            plan.retarget(skip)
+            got = plan.recon(_flat(data))
+        want, _ = _fresh(data, skip, **fl)
+        assert np.array_equal(got, want), (nc, nt, extra)
+        if extra.get("niter"):
+            ref, _ = oracle.recon_cgnr(data, 2, golden=1, prof_slide=npe, data_undersamp=us, skip_angles=skip)
+            assert rel_l2(got, _flat(ref)) <= TOL
