@@ -78,8 +78,10 @@ typedef struct tron_config {
     int   input_half;      /* adjoint only: k-space is complex-half (2 x IEEE binary16 per sample) */
     int   chunk_slices;    /* slices per internal batch; 0 = choose from the grid size */
     int   pin_host;        /* tron_recon_radial2d[_range]: hipHostRegister the caller's buffers for the call (the
-                              reference pins its output with cudaMallocHost, src/tron.cu:967); default 1; a buffer that
-                              cannot be registered (already pinned by the caller, ...) is copied as pageable memory */
+                              reference pins its output with cudaMallocHost, src/tron.cu:967); default 1.  Only a buffer
+                              of >= 32 MiB above the program break (a mapping of its own, not the brk heap) is registered;
+                              any other, and one that cannot be registered (already pinned by the caller, ...), is copied
+                              as pageable memory */
     int   cgnr_consistent; /* CGNR with linear angles: 0 = each operator keeps the reference's own convention (grid
                               src/tron.cu:509, degrid :555 -- not a matched pair), 1 = the forward operator
                               inside the iteration uses the gridding convention.  Golden angle: no effect */

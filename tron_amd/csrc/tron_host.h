@@ -17,7 +17,7 @@ int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 // Tuning / debugging switches of the library are read from the environment ONLY when TRON_TUNING=1 is set
 // as well: a library caller's behaviour does not depend on stray TRON_* variables.
 const char *tuning_env(const char *name);
-bool debug_token(const char *name, std::string *value = nullptr);   // a token of TRON_DEBUG (`sync`, `poison`, `cold_fault=<path>`)
+bool debug_token(const char *name, std::string *value = nullptr);   // a token of TRON_DEBUG (`sync`, `poison`, `pin_any`, `cold_fault=<path>`)
 
 float grid_spoke_angle(int pe, int npe, int skip, int golden);
 float degrid_spoke_angle(int pe, int npe, int skip, int golden);

@@ -5,8 +5,55 @@
 
 #include <pthread.h>
 #include <sched.h>
+#include <unistd.h>
 
 using namespace tron;
+
+// Registration of the caller's two buffers for a call (hipHostRegister maps whole pages of user memory for the GPU's copy engines).
+// WHICH memory may be registered is the point of this struct.  Rounds 2-5 registered any buffer of a call that moved >= 8 MiB; round 6
+// found (tests/test_gpu_retarget.py, then tools/probe/hostreg_heap.py) that a copy FROM a registered buffer that lives on the brk heap
+// ends about every third process with "Memory access fault by GPU ... on address <page inside the registered range>" once the heap has been
+// worked (earlier buffers registered, unregistered and freed there; glibc's dynamic mmap threshold grows to 32 MiB after the first large
+// free, and 10 MB arrays then come from the heap): 13 of 36 processes with the heap buffer, 0 of 36 with the same bytes in a mapping of
+// their own (MALLOC_MMAP_THRESHOLD_ fixed), 0 of 24 with pageable copies.  The driver's user-pointer mapping follows the heap's one
+// growing and shrinking VMA badly; a mapping of its own it follows well.  So a buffer is registered only when
+//   * it is at least kPinMinBytes = 32 MiB (glibc's largest dynamic mmap threshold: a malloc'd block of that size is always a mapping
+//     of its own; below it the page walk of a registration costs what the pinned copy saves anyway), and
+//   * it lies above the program break (never static data, never the brk heap, whatever the allocator),
+// and everything else is copied as pageable memory (staged by the runtime at 0.89 of the pinned rate).
+// Page-rounded ranges, and ONE registration of their union when the two buffers touch or overlap.
+struct HostPins {
+    static constexpr size_t kPinMinBytes = (size_t)32 << 20;
+    void *base[2] = {nullptr, nullptr};
+    int n = 0;
+    static bool eligible(const void *ptr, size_t bytes)
+    {
+        return bytes >= kPinMinBytes && reinterpret_cast<uintptr_t>(ptr) >= reinterpret_cast<uintptr_t>(sbrk(0));
+    }
+    void pin(const void *a, size_t abytes, const void *b, size_t bbytes, unsigned flags)
+    {
+        // TRON_DEBUG=pin_any: the rule of rounds 2-5 (both buffers of a call that moves >= 8 MiB): tools/probe/hostreg_heap.py shows the fault with it
+        static const bool any_dbg = debug_token("pin_any");
+        const bool any = any_dbg && abytes + bbytes >= ((size_t)8 << 20);
+        const uintptr_t pg = 4096;
+        uintptr_t a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+        if (any || eligible(a, abytes)) { a0 = reinterpret_cast<uintptr_t>(a) & ~(pg - 1); a1 = (reinterpret_cast<uintptr_t>(a) + abytes + pg - 1) & ~(pg - 1); }
+        if (any || eligible(b, bbytes)) { b0 = reinterpret_cast<uintptr_t>(b) & ~(pg - 1); b1 = (reinterpret_cast<uintptr_t>(b) + bbytes + pg - 1) & ~(pg - 1); }
+        if (a1 > a0 && b1 > b0 && a1 >= b0 && b1 >= a0) {      // neighbours or overlapping: one range
+            a0 = std::min(a0, b0); a1 = std::max(a1, b1);
+            b0 = b1 = 0;
+        }
+        for (auto r : {std::make_pair(a0, a1), std::make_pair(b0, b1)})
+            if (r.second > r.first && hipHostRegister(reinterpret_cast<void *>(r.first), r.second - r.first, flags) == hipSuccess)
+                base[n++] = reinterpret_cast<void *>(r.first);
+        (void)hipGetLastError();                               // (a range that cannot be registered -- already pinned by the caller, ... -- is copied as pageable memory)
+    }
+    void unpin()
+    {
+        for (int i = 0; i < n; ++i) hipHostUnregister(base[i]);
+        n = 0;
+    }
+};
 
 // Adjoint of slices [zfirst, zfirst+zcount) from host memory: h_in_block points at the first spoke of slice zfirst's
 // window, h_out_block at that slice's image.
@@ -35,15 +82,10 @@ static int adjoint_block(tron_plan *p, tron_float2 *h_out_block, const void *h_i
     tron_float2 *dst = h_out_block;
     // Pinning the caller's buffers makes the copies truly asynchronous (and the two directions concurrent): the default
     // (cfg.pin_host = 1, as the reference pins its output, src/tron.cu:967; the `tron` binary's streamed blocks turn it off, tron_main.cpp).
-    // It costs a page walk of the whole range per call, so calls that move less than kPinThreshold bytes skip it:
-    // pageable copies are staged by the runtime at the same PCIe rate and still overlap the kernels of the previous chunk.
-    constexpr size_t kPinThreshold = (size_t)8 << 20;
-    bool pinned_in = false, pinned_out = false;
-    if (p->pin_host && in_bytes + out_bytes >= kPinThreshold) {
-        pinned_in = hipHostRegister(const_cast<unsigned char *>(src), in_bytes, hipHostRegisterDefault) == hipSuccess;
-        pinned_out = hipHostRegister(dst, out_bytes, hipHostRegisterDefault) == hipSuccess;
-        (void)hipGetLastError();
-    }
+    // It costs a page walk of the whole range per call and is safe only for some memory: HostPins (above) decides per buffer; what
+    // it leaves is copied as pageable memory, staged by the runtime at 0.89 of the rate and still overlapping the previous chunk's kernels.
+    HostPins pins;
+    if (p->pin_host) pins.pin(src, in_bytes, dst, out_bytes, hipHostRegisterDefault);
     const int step = std::max(1, std::min(p->chunk, zcount));
     const int nchunks = (zcount + step - 1) / step;
     while ((int)p->ev_pipe.size() < 2 * nchunks) {
@@ -78,8 +120,7 @@ static int adjoint_block(tron_plan *p, tron_float2 *h_out_block, const void *h_i
                                 (size_t)cz * img_elems * sizeof(float2), hipMemcpyDeviceToHost, p->stream_down);
     }
     hipError_t s1 = hipStreamSynchronize(p->stream_up), s2 = hipStreamSynchronize(p->stream), s3 = hipStreamSynchronize(p->stream_down);
-    if (pinned_in) hipHostUnregister(const_cast<unsigned char *>(src));
-    if (pinned_out) hipHostUnregister(dst);
+    pins.unpin();
     if (rc != TRON_OK) return rc;
     for (hipError_t e : {he, s1, s2, s3})
         if (e != hipSuccess) return fail(TRON_ERR_HIP, "host-buffer pipeline failed: %s", hipGetErrorString(e));
@@ -181,13 +222,11 @@ extern "C" int tron_recon_radial2d_multi(const tron_config *cfg, const tron_dims
     std::vector<std::string> msgs(workers);
     // the workers' slice blocks share spokes (windows overlap) and pages: pin both buffers ONCE -- hipHostRegisterPortable makes
     // the registration visible to every device's context, whichever device is current here
-    bool pinned_in = false, pinned_out = false;
+    HostPins pins;
     const size_t in_bytes = (size_t)dims->in_elems * (cfg->input_half ? 4 : 8);
     if (cfg->pin_host && workers > 1) {
         HIP_TRY(hipSetDevice(devs[0]));
-        pinned_in = hipHostRegister(const_cast<tron_float2 *>(h_in), in_bytes, hipHostRegisterPortable) == hipSuccess;
-        pinned_out = hipHostRegister(h_out, (size_t)dims->out_bytes, hipHostRegisterPortable) == hipSuccess;
-        (void)hipGetLastError();
+        pins.pin(h_in, in_bytes, h_out, (size_t)dims->out_bytes, hipHostRegisterPortable);
     }
     auto work = [&](int g) {
         tron_config c = *cfg;
@@ -210,8 +249,7 @@ extern "C" int tron_recon_radial2d_multi(const tron_config *cfg, const tron_dims
         for (int g = 0; g < workers; ++g) th.emplace_back(work, g);
         for (auto &t : th) t.join();
     }
-    if (pinned_in) hipHostUnregister(const_cast<tron_float2 *>(h_in));
-    if (pinned_out) hipHostUnregister(h_out);
+    pins.unpin();
     for (int g = 0; g < workers; ++g)
         if (rcs[g] != TRON_OK) return fail(rcs[g], "device worker %d (HIP device %d): %s", g, devs[g], msgs[g].c_str());
     return TRON_OK;
