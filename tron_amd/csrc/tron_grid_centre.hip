@@ -123,6 +123,7 @@ grid_centre_kernel(const GridParams p)
     const float We = p.W + 1e-3f;
     const float dcf_a = p.apply_dcf ? p.dcf_a : 0.0f, dcf_b = p.apply_dcf ? p.dcf_b : 1.0f;
     const float2 *lut = lds.lut + p.lut_bias;                   // entry of table position 0
+    const float lut_lo = -(float)p.lut_bias;                    // the table's first position (pieces that far out are zero)
     const unsigned nchan8 = (unsigned)p.nchan * (HALF ? 4u : 8u);
     const float rs_nro = (float)p.nro, rs_inv = 1.0f / (float)p.nxos;
     CPROF_MARK(0);                                              // table
@@ -175,7 +176,7 @@ grid_centre_kernel(const GridParams p)
     // scalar register by hand; seven vector registers less over the item)
     auto uni = [](float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); };
     const float X0f = uni((float)X0), Y0f = uni((float)Y0);
-    const v2f p0v = {X0f, Y0f};
+    const v2f p0v = {X0f, Y0f}, p1v = {X0f + 1.0f, Y0f + 1.0f};
     const float xlo = uni(X0f - We), xhi = uni(X0f + 1.0f + We), ylo = uni(Y0f - We), yhi = uni(Y0f + 1.0f + We);
     const float rcap_f = uni((float)rcap);
     const unsigned char *in = reinterpret_cast<const unsigned char *>(p.nudata) + (size_t)z * (size_t)p.in_slice_stride * (HALF ? 4 : 8);   // (scalar)
@@ -254,16 +255,23 @@ grid_centre_kernel(const GridParams p)
             off = (unsigned)(p.nro * (int)(rec.w & 0xffffu) + p.nro / 2 + (ri < 0 ? -(int)sf : (int)sf)) * nchan8;
             // (kx, ky) = r (cos, sin) and the distances to the block's first column / row, op for op src/tron.cu:514-516
             const v2f kxy = (v2f){rf, rf} * (v2f){__uint_as_float(rec.x), __uint_as_float(rec.y)};
-            const v2f tp = (kxy - p0v) * lscale2;
-            const v2f tt = {__builtin_truncf(tp.x), __builtin_truncf(tp.y)};
-            const v2f fv = tp - tt;
-            const float2 *lx = lut + (int)tt.x, *ly = lut + (int)tt.y;
-            const float2 x0c = lx[0], x1c = lx[kArcLutEntries], x2c = lx[2 * kArcLutEntries];
-            const float2 y0c = ly[0], y1c = ly[kArcLutEntries], y2c = ly[2 * kArcLutEntries];
+            // The distance to EACH of the block's two columns / rows by the reference's own subtraction, k - X (src/tron.cu:516), and a table
+            // position of its own: the second one derived from the first (one lookup of the pair table, rounds 4-6) is k - X0 rounded
+            // at the magnitude of a number up to 3 where the reference rounds k - (X0 + 1) at one up to 2 -- k = 0.99999988 (the r = 1
+            // sample of a spoke 5e-4 rad off an axis: one slice in three has such a spoke), X0 = -2: k - X0 rounds to 3, "its" k - X1 = 2
+            // lies outside the window, the reference's 1.99999988 inside, and the window jumps by 6e-4 of its peak there: 1.1e-5 relative
+            // L2 on k-space whose energy sits at the centre (tests/test_gpu_headline.py, found in round 6).
+            const v2f tpa = (kxy - p0v) * lscale2, tpb = (kxy - p1v) * lscale2;
+            const v2f tta = {__builtin_truncf(tpa.x), __builtin_truncf(tpa.y)};
+            const v2f ttb = {fmaxf(__builtin_truncf(tpb.x), lut_lo), fmaxf(__builtin_truncf(tpb.y), lut_lo)};     // (the far side of the second column: below the table, zero)
+            const v2f fa = tpa - tta, fb = tpb - ttb;
+            const float2 *lxa = lut + (int)tta.x, *lya = lut + (int)tta.y, *lxb = lut + (int)ttb.x, *lyb = lut + (int)ttb.y;
+            const float2 x0c = {lxa[0].x, lxb[0].x}, x1c = {lxa[kArcLutEntries].x, lxb[kArcLutEntries].x}, x2c = {lxa[2 * kArcLutEntries].x, lxb[2 * kArcLutEntries].x};
+            const float2 y0c = {lya[0].x, lyb[0].x}, y1c = {lya[kArcLutEntries].x, lyb[kArcLutEntries].x}, y2c = {lya[2 * kArcLutEntries].x, lyb[2 * kArcLutEntries].x};
             const int ar = ri < 0 ? -ri : ri;
             // src/tron.cu:412 (|ro - nro/2|); r = 0 is visited by both loops of the reference where the band starts at 0
             const float sdc = fmaf(dcf_a, sf, dcf_b) * (ri == 0 ? 2.0f : 1.0f);
-            const v2f fxv = {fv.x, fv.x}, fyv = {fv.y, fv.y}, sdcv = {sdc, sdc};
+            const v2f fxv = {fa.x, fb.x}, fyv = {fa.y, fb.y}, sdcv = {sdc, sdc};
             const v2f wx = __builtin_elementwise_fma(fxv, __builtin_elementwise_fma(fxv, (v2f){x2c.x, x2c.y}, (v2f){x1c.x, x1c.y}), (v2f){x0c.x, x0c.y});
             const v2f wy = __builtin_elementwise_fma(fyv, __builtin_elementwise_fma(fyv, (v2f){y2c.x, y2c.y}, (v2f){y1c.x, y1c.y}), (v2f){y0c.x, y0c.y}) * sdcv;
             const v2f w01 = wx * (v2f){wy.x, wy.x}, w23 = wx * (v2f){wy.y, wy.y};    // src/tron.cu:516
