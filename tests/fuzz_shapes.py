@@ -12,8 +12,9 @@ from oracle import pyoracle
 def rel(a, b):
     return float(np.linalg.norm((a - b).ravel()) / max(np.linalg.norm(b.ravel()), 1e-30))
 
-def run(n, seed, verbose=True):
-    """Returns (worst error, list of failing case descriptions)."""
+def run(n, seed, verbose=True, scan=False):
+    """Returns (worst error, list of failing case descriptions).  scan: k-space under a scanner's envelope (synth.scan_envelope) and smooth
+    images instead of flat random fields -- the samples next to the origin carry the result, and an error in one of them shows."""
     rng = np.random.default_rng(seed)
     worst = 0.0
     failures = []
@@ -33,13 +34,13 @@ def run(n, seed, verbose=True):
             npe1 = npe_w + (nz - 1) * slide
             us = (npe_w + 0.5) / nro
             flags = dict(golden_angle=golden, data_undersamp=us, prof_slide=slide, kernwidth=W, gridos=gridos, skip_angles=skip)
-            data = synth.kspace(nc, nro, npe1, seed=1000 + it)
+            data = (synth.kspace_scan if scan else synth.kspace)(nc, nro, npe1, seed=1000 + it)
             half = bool(rng.integers(0, 5) == 0)             # complex-half storage (config 5)
             if half:
                 h16 = np.asfortranarray(data).reshape(-1, order="F").view(np.float32).astype(np.float16)
                 data = h16.astype(np.float32).view(np.complex64).reshape(data.shape, order="F")   # what the oracle sees
                 gpu_in, flags = h16.reshape((2,) + data.shape, order="F"), dict(flags, input_half=1)
-            desc = ("half " if half else "") + f"adj nc={nc} nro={nro} npe={npe_w} nz={nz} slide={slide} W={W} os={gridos} G={golden} skip={skip}"
+            desc = ("scan " if scan else "") + ("half " if half else "") + f"adj nc={nc} nro={nro} npe={npe_w} nz={nz} slide={slide} W={W} os={gridos} G={golden} skip={skip}"
             small = nro <= 128 and npe_w * nz <= 1500
         else:
             nx = int(rng.choice([8, 12, 16, 24, 32, 50, 64, 256]))
@@ -48,6 +49,9 @@ def run(n, seed, verbose=True):
             us = (npe + 0.5) / nro
             flags = dict(golden_angle=golden, data_undersamp=us, kernwidth=W, gridos=gridos, skip_angles=skip)
             data = synth.image(nc, nx, seed=2000 + it)
+            if scan:
+                g = np.exp(-0.5 * ((np.arange(nx) - nx // 2) / (0.2 * nx)) ** 2).astype(np.float32)
+                data = np.asfortranarray((data * (g[:, None] * g[None, :])[None, None, :, :, None]).astype(np.complex64))
             desc = f"fwd nc={nc} nx={nx} nro={nro} npe={npe} W={W} os={gridos} G={golden} skip={skip}"
             small = nx <= 64
         try:

@@ -29,6 +29,20 @@ def kspace(nc, nro, npe1, seed=SEED_BASE, nt=1, npe2=1):
     return flat.reshape((nc, nt, nro, npe1, npe2), order="F")
 
 
+def scan_envelope(nro):
+    """Magnitude of k-space as it comes off a scanner, along the readout: 1 at the centre sample, falling as 1 / (1 + (r / 2)^2) to a
+    noise floor of 1e-4 -- what the flat random field above hides: the samples next to the origin carry nearly all of the energy, so an
+    error in any one of them shows in the image (round 6: the centre kernel's window edge, tests/test_gpu_arc.py)."""
+    r = np.abs(np.arange(nro) - nro // 2).astype(np.float32)
+    return (1.0 / (1.0 + (r / 2.0) ** 2) + 1e-4).astype(np.float32)
+
+
+def kspace_scan(nc, nro, npe1, seed=SEED_BASE, nt=1, npe2=1):
+    """kspace() under scan_envelope()."""
+    d = kspace(nc, nro, npe1, seed=seed, nt=nt, npe2=npe2)
+    return np.asfortranarray((d * scan_envelope(nro)[None, None, :, None, None]).astype(np.complex64))
+
+
 def image(nc, nx, seed=SEED_BASE + 1, nz=1):
     flat = uniform_c64(nc * nx * nx * nz, seed)
     return flat.reshape((nc, 1, nx, nx, nz), order="F")

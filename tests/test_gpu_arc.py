@@ -188,16 +188,14 @@ def test_empty_runs_between_the_slices_of_one_workgroup(oracle, nc, nro, npe, nz
 @pytest.mark.parametrize("nc", [1, 2, 8])
 def test_k_space_whose_energy_sits_at_the_centre_and_a_spoke_next_to_an_axis(oracle, nc):
     """Round 6: the window jumps by 6e-4 of its peak at |k - X| = W, and which side a sample is on is the reference's own fp32
-    subtraction, k - X (src/tron.cu:516).  The centre kernel took the distance to a block's second column from the first (k - X0) - 1:
-    the r = 1 sample of a spoke 5e-4 rad off an axis (k = 0.99999988: spoke 305 of a golden-angle run, one slice in three has one)
-    then lies outside where the reference has it inside, and on k-space whose energy sits at the centre -- every scan -- a slice came out
-    at 1.1e-5 to 1.9e-5 of the oracle (flat random data hides it: 4e-7).  Every slice must hold the north_star's 1e-5."""
+    subtraction, k - X (src/tron.cu:516).  The centre kernel took the distance to a block's second column from the first, (k - X0) - 1:
+    the r = 1 sample of a spoke 5e-4 rad off an axis (k = 0.99999988: spokes 305, 2817, 3122, 3427 ... of a golden-angle run, one slice
+    of 402 spokes in four has one) then lay outside where the reference has it inside, and on k-space whose energy sits at the centre --
+    every scan -- a slice came out at 1.1e-5 to 1.9e-5 of the oracle (flat random data hides it: 4e-7).  Windows that hold those spokes,
+    every slice against the north_star's 1e-5 with room to spare."""
     nro, npe = 256, 160
-    data = synth.kspace(nc, nro, npe * 2, seed=9700 + nc)
-    r = np.abs(np.arange(nro) - nro // 2).astype(np.float32)
-    env = (1.0 / (1.0 + (r / 2.0) ** 2) + 1e-4).astype(np.float32)            # 1 at the centre, 1e-4 at the rim
-    data = np.asfortranarray((data * env[None, None, :, None, None]).astype(np.complex64))
-    for skip in (0, 160):                                                      # (spoke 305 is in the second window, then in the first)
+    data = synth.kspace_scan(nc, nro, npe * 2, seed=9700 + nc)
+    for skip in (0, 160, 2700, 3000, 3400):
         fl = dict(golden_angle=1, data_undersamp=(npe + 0.5) / nro, prof_slide=npe, skip_angles=skip)
         got, dims = lib.recon(data, adjoint=True, **fl)
         want, _ = oracle.recon(data, adjoint=1, golden=1, data_undersamp=(npe + 0.5) / nro, prof_slide=npe, skip_angles=skip)

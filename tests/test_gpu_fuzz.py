@@ -19,6 +19,18 @@ def test_random_shapes_fast_vs_exact_vs_oracle(oracle):
     assert worst <= 1e-5
 
 
+def test_random_shapes_on_scan_like_data(oracle):
+    """The same sweep on k-space under a scanner's envelope and on smooth images (synth.scan_envelope): the samples next to the origin carry
+    the result, which is how round 6 found the centre kernel's window edge (tests/test_gpu_arc.py); flat random fields average such a thing away."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("tron_fuzz", os.path.join(root, "tests", "fuzz_shapes.py"))
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    worst, failures = fuzz.run(40, 20261004, verbose=False, scan=True)
+    assert not failures, failures
+    assert worst <= 1e-5
+
+
 @pytest.mark.slow      # 112 s, nearly all of it the CPU oracle's CGNR; tests/test_gpu_cgnr.py, test_gpu_round2.py keep each feature's own parity tests
 def test_random_shapes_round2_features_vs_oracle(oracle):
     """CGNR, Walsh combination, nt > 1, chunked / pinned host pipeline on random shapes, against the oracle."""

@@ -53,6 +53,18 @@ def test_metric_shape_402_spokes_8_coils_64_slices(oracle, metric_stream, kb):
     _check_slices(oracle, metric_stream, got, (0, 31, 63), golden=1, data_undersamp=0.7852, prof_slide=402)
 
 
+def test_metric_shape_on_k_space_whose_energy_sits_at_the_centre(oracle):
+    """The metric's slice shape (512 x 402 golden-angle spokes x 8 coils) on k-space with a scanner's envelope (synth.scan_envelope): the
+    first slice holds spoke 305, which runs 5e-4 rad off the ky axis -- the case the centre kernel had wrong until round 6
+    (tests/test_gpu_arc.py) -- and the samples |r| < 14 carry the image."""
+    data = synth.kspace_scan(8, NRO, 402 * 2, seed=synth.SEED_BASE + 27)
+    flags = dict(golden_angle=1, data_undersamp=0.7852, prof_slide=402)
+    got, dims = lib.recon(data, adjoint=True, **flags)
+    assert (dims.nz, dims.npe1work) == (2, 402)
+    worst = _check_slices(oracle, data, got, (0, 1), golden=1, data_undersamp=0.7852, prof_slide=402)
+    assert worst <= 3e-6, worst
+
+
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("kb", [lib.KB_FAST, lib.KB_EXACT])
 def test_config4_shape_804_spokes_8_coils(oracle, kb):
