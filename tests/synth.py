@@ -1,5 +1,7 @@
 """Seeded synthetic inputs: complex64, re/im i.i.d. uniform [-1,1) from a
 splitmix64 counter generator, so every test, fixture script and the bench agree."""
+import os
+
 import numpy as np
 
 SEED_BASE = 0x54524F4E  # "TRON"
@@ -26,7 +28,10 @@ def uniform_c64(n, seed=SEED_BASE):
 def kspace(nc, nro, npe1, seed=SEED_BASE, nt=1, npe2=1):
     """Radial k-space shaped like the .ra file: (nc, nt, nro, npe1, npe2), first dim fastest."""
     flat = uniform_c64(nc * nt * nro * npe1 * npe2, seed)
-    return flat.reshape((nc, nt, nro, npe1, npe2), order="F")
+    d = flat.reshape((nc, nt, nro, npe1, npe2), order="F")
+    if os.environ.get("TRON_TEST_SCAN") == "1":      # exploratory: every test's k-space under scan_envelope() (thresholds are tuned for flat fields: read the failures, do not gate on them)
+        d = np.asfortranarray((d * scan_envelope(nro)[None, None, :, None, None]).astype(np.complex64))
+    return d
 
 
 def scan_envelope(nro):
