@@ -40,3 +40,17 @@ def test_fresh_processes_launch_immediately_without_faults(tmp_path):
             assert img.shape == (1, 1, 256, 256, 1) and np.isfinite(img).all() and np.abs(img).max() > 0
         else:
             assert out == first, f"process {i}: output bytes differ from the first run"
+
+
+def test_plans_created_used_retargeted_and_destroyed_in_random_order():
+    """tests/soak.py: plans of random shapes (adjoint and forward, fp32 and complex-half, flat and scan-like k-space, scaled by 2^-40 .. 2^40,
+    host arrays on the heap and in mappings of their own, pinned or pageable) created, run on slice sub-ranges, retargeted and destroyed in
+    random order in one process: whatever a plan returns is, bit for bit, what a plan created fresh for that job returns (linear-angle
+    slice groups: to fp32 rounding).  Round 6 ran 12 000 operations of it clean; the suite keeps 600."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("tron_soak", os.path.join(ROOT, "tests", "soak.py"))
+    soak = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(soak)
+    with np.errstate(over="ignore"):
+        failures = soak.run(600, 20261005)
+    assert not failures, failures
