@@ -37,6 +37,18 @@ class Job:
                 self.data = np.asfortranarray(self.data * np.float32(2.0 ** int(rng.integers(-40, 41))))
             self.flags = dict(golden_angle=self.golden, data_undersamp=(self.npe + 0.5) / self.nro, prof_slide=self.slide,
                               chunk_slices=int(rng.choice([0, 0, 1, 2])), pin_host=int(rng.integers(0, 2)))
+            # now and then: CGNR, the Walsh combination, the exact kernels, another oversampling ratio, another window width
+            pick = int(rng.integers(0, 12))
+            if pick == 0 and self.nc > 1:
+                self.flags.update(coil_combine=1, walsh_patch=int(rng.integers(0, 3)))
+            elif pick == 1 and not self.half:                       # (CGNR takes complex64 k-space)
+                self.flags.update(niter=int(rng.integers(1, 4)), cgnr_consistent=int(rng.integers(0, 2)))
+            elif pick == 2:
+                self.flags.update(kb_mode=lib.KB_EXACT)
+            elif pick == 3:
+                self.flags.update(gridos=float(rng.choice([1.25, 1.5, 3.0])))
+            elif pick == 4:
+                self.flags.update(kernwidth=float(rng.choice([1.5, 2.5, 3.0, 4.0])))
             if self.half:
                 self.src = np.stack([self.data.real, self.data.imag]).astype(np.float16)
                 self.flags["input_half"] = 1
@@ -48,9 +60,12 @@ class Job:
             self.data = synth.image(self.nc, self.nx, seed=8000 + k)
             self.src = self.data
             self.flags = dict(golden_angle=self.golden)
+            if rng.integers(0, 4) == 0:
+                self.flags.update(kernwidth=float(rng.choice([1.5, 2.5, 3.0])))
+        self.extra = {k: v for k, v in self.flags.items() if k in ("coil_combine", "walsh_patch", "niter", "cgnr_consistent", "kb_mode", "gridos", "kernwidth")}
         self.desc = (f"{'adj' if self.adjoint else 'fwd'} nc={self.nc} G={self.golden} " +
                      (f"nro={self.nro} npe={self.npe} nz={self.nz} slide={self.slide} half={int(self.half)} chunk={self.flags['chunk_slices']} pin={self.flags['pin_host']}"
-                      if self.adjoint else f"nx={self.nx}"))
+                      if self.adjoint else f"nx={self.nx}") + (f" {self.extra}" if self.extra else ""))
 
     def config(self, skip):
         return lib.default_config(adjoint=int(self.adjoint), skip_angles=skip, **self.flags)
