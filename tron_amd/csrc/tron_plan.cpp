@@ -297,7 +297,9 @@ int tron::plan_create_share(tron_plan **out, const tron_config *cfg, const tron_
     // The heaviest tile (the k-space centre, crossed by every spoke) is one wave's serial work, so a
     // launch needs enough slices in flight to cover that critical path: batch up to 1 GiB of grid.
     // ... or 64 slices when the coils are many (still at most 6 GiB of grid: 288 GB of HBM make that cheap)
-    size_t auto_chunk = std::max<size_t>(1, ((size_t)2 << 30) / per_unit);   // (2 GiB: 128 slices x 8 coils; +5 % over 64-slice launches with the arc kernel)
+    // (4 GiB: 256 slices x 8 coils in ONE chain of launches -- round 6, late: +1.7 % short, +2 % sustained over two chains of 128, same box,
+    //  alternating, twice; rounds 3-6 batched 2 GiB, which had been +5 % over 1 GiB)
+    size_t auto_chunk = std::max<size_t>(1, ((size_t)4 << 30) / per_unit);
     if (auto_chunk < 64) auto_chunk = std::max<size_t>(auto_chunk, std::min<size_t>(64, ((size_t)6 << 30) / per_unit));
     int chunk = cfg->chunk_slices > 0 ? cfg->chunk_slices : (int)std::max<size_t>(1, auto_chunk);
     p->chunk = std::max(1, std::min(chunk, std::max(units, 1)));
