@@ -83,7 +83,7 @@ struct ScatLds {
     uint4 run[kScatMaxSpokes];                                   // first sample | down << 31, ulo | len << 10 | (offset & 0x7fff) << 17, cos, sin
     uint32_t off[kScatMaxSpokes];                                // the entries' record offsets inside the run (whole: a 64-tile's run exceeds 15 bits)
     unsigned long long acc[NC][G::kPitch * G::kStride];          // (re << 32) + im, fixed point
-    float2 pmax[2][G::kWaves];                                   // every wave's largest and second-largest |d| dcf of a round, by round parity
+    unsigned dmax_bits[2];                                        // largest |d| dcf of the rounds so far, by round parity
     unsigned pad[2];
     float psum[2][G::kWaves];                                    // every wave's sum of |d| dcf over its records of a round, by round parity (round 6)
     // a wave's next round of the member table (arc_prep_kernel: 80 bytes per group of 64 records), copied by LDS-DMA a round ahead
@@ -234,6 +234,7 @@ grid_scatter_kernel(const GridParams p)
         uint4 *const a4 = reinterpret_cast<uint4 *>(&L.acc[0][0]);
         constexpr int N4 = NC * kScatPitch * kScatStride / 2;
         for (int i = tid; i < N4; i += kScatThreads) a4[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (tid < 2) L.dmax_bits[tid] = 0u;
     }
 
     for (int iz = 0; iz < zper; ++iz) {
@@ -298,7 +299,7 @@ grid_scatter_kernel(const GridParams p)
         const int iters = quota >> 6;                           // per wave, the same for all of them
         const int pbeg = wave * quota, pend = min(total, pbeg + quota);
         SPROF_MARK(2);                                          // first member of the wave's quarter
-        float run_max = 0.f, run_max2 = 0.f;                    // largest and second-largest weighted sample of the rounds so far (workgroup-uniform)
+        float run_max = 0.f;                                    // largest weighted sample of the rounds so far (workgroup-uniform)
         float run_sum = 0.f;                                    // ... and the sum of all of them
         int e2 = 0;
         bool have_scale = false;
@@ -346,7 +347,7 @@ grid_scatter_kernel(const GridParams p)
             }
             SPROF_MARK(9);                                      // entries, loads issued
             // ---- largest density-compensated |re|, |im| ----
-            float mxv = 0.f, mx2 = 0.f, msum = 0.f;
+            float mxv = 0.f, msum = 0.f;
 #pragma unroll
             for (int q = 0; q < R; ++q) {
                 if (meta[q] >> 31) {
@@ -357,40 +358,28 @@ grid_scatter_kernel(const GridParams p)
                     for (int c = 0; c < NC; ++c)
                         if (c < ncb) mq = fmaxf(mq, fmaxf(fabsf(dreg[q][c].x), fabsf(dreg[q][c].y)) * sdc);
                     if (!(mq < 3.0e38f)) mq = 3.0e38f;          // inf / NaN in the data: garbage either way; keep the scale finite
-                    mx2 = fmaxf(mx2, fminf(mxv, mq));            // (the two largest of the lane's records)
                     mxv = fmaxf(mxv, mq);
                     msum += mq;                                 // (in q order: the same sum every run)
                 }
             }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
-                const float a1 = __shfl_xor(mxv, o), a2 = __shfl_xor(mx2, o);      // (the other half's two largest: disjoint records at every level)
-                mx2 = fmaxf(fminf(mxv, a1), fmaxf(mx2, a2));
-                mxv = fmaxf(mxv, a1);
+                mxv = fmaxf(mxv, __shfl_xor(mxv, o));
                 msum += __shfl_xor(msum, o);                    // xor butterfly of a commutative operation: the same bits in every lane
             }
             const int slot = (r0 / R) & 1;                      // (two slots, never cleared inside a slice: a fast wave's next round cannot disturb this one)
             if (lane == 0) {
-                L.pmax[slot][wave] = make_float2(mxv, mx2);
+                atomicMax(&L.dmax_bits[slot], __float_as_uint(fmaxf(mxv, run_max)));
                 L.psum[slot][wave] = fminf(msum, 3.0e38f);
             }
             SPROF_MARK(4);                                      // front: walk, loads, maximum
             __syncthreads();
             SPROF_MARK(5);
-            float new_max = run_max, new_max2 = run_max2;           // the two largest of every record so far: the rounds before + this round's waves
-#pragma unroll
-            for (int ww = 0; ww < kWaves; ++ww) {
-                const float2 pm = L.pmax[slot][ww];
-                new_max2 = fmaxf(fminf(new_max, pm.x), fmaxf(new_max2, pm.y));
-                new_max = fmaxf(new_max, pm.x);
-            }
+            const float new_max = __uint_as_float(L.dmax_bits[slot]);
             // S = 2^e, the largest with  bound * S < 2^31,  bound = what the |re| or |im| sum of ONE point can reach, the smaller of
             //   (a) M x the tile's largest |d| dcf x 1.75 K(0)^2: M = the most spokes whose line can pass one of the tile's 2x2 blocks (arc_prep_kernel:
             //       the run header), and one spoke adds at most its largest sample times the window products along a line (<= 1.65 K(0)^2);
             //   (b) K(0)^2 x the SUM of |d| dcf over every record of the tile so far: a sample adds at most K(0)^2 of itself to a point.
-            //   (c) K(0)^2 x the LARGEST record + M x 1.75 K(0)^2 x the SECOND largest (round 6, late): whatever reaches a point is the largest record once, at most,
-            //       and records no larger than the second largest on at most M spokes -- one isolated spike then costs its own magnitude once, not M times (a)
-            //       and not the tile's whole sum (b): the 640-spoke case of tests/test_gpu_scatter.py, middle band, 5.0e-6 -> see there.
             // Until round 5 only (a) stood, and ONE large sample (a spike 300 x its neighbourhood in a 640-spoke window: 1.8e-5 relative L2 against
             // the oracle, tests/test_gpu_scatter.py) set the step of the whole tile; (b) charges a spike as one sample, and data that falls off
             // with the radius as the sum it is.  On flat data (a) is the smaller one, as before.  Deterministic: every wave's sum is taken in a
@@ -400,8 +389,7 @@ grid_scatter_kernel(const GridParams p)
             for (int ww = 0; ww < kWaves; ++ww) rsum += L.psum[slot][ww];
             run_sum = fminf(run_sum + rsum, 3.0e38f);
             {
-                const float mw = (float)max(mwin, 1) * p.scat_wsum;
-                const float bound = fminf(fminf(new_max * mw, fmaf(new_max2, mw, new_max * p.scat_wmax)), run_sum * p.scat_wmax);
+                const float bound = fminf(new_max * (float)max(mwin, 1) * p.scat_wsum, run_sum * p.scat_wmax);
                 int e_new = have_scale ? e2 : 0;
                 if (bound > 0.f) {
                     const int ex = (int)((__float_as_uint(bound) >> 23) & 255u) - 127;      // bound < 2^(ex + 1)
@@ -426,7 +414,6 @@ grid_scatter_kernel(const GridParams p)
                 if (!(have_scale && run_max > 0.f) || e_new < e2) e2 = e_new;
                 have_scale = true;
                 run_max = new_max;
-                run_max2 = new_max2;
                 S = __uint_as_float((unsigned)(e2 + 127) << 23);
                 invS = __uint_as_float((unsigned)(127 - e2) << 23);
             }
@@ -582,6 +569,7 @@ grid_scatter_kernel(const GridParams p)
                 }
                 for (int k = tid; k < kRing; k += kScatThreads) L.acc[c][halo_index(k)] = 0ull;
             }
+            if (tid < 2) L.dmax_bits[tid] = 0u;
             if (more) table_to_lds(hdr_next.x);                 // (every wave is past the scatter: the old table is done with)
         }
         SPROF_MARK(8);                                          // store, next slice's table
