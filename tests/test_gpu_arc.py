@@ -195,7 +195,7 @@ def test_k_space_whose_energy_sits_at_the_centre_and_a_spoke_next_to_an_axis(ora
     every slice against the north_star's 1e-5 with room to spare."""
     nro, npe = 256, 160
     data = synth.kspace_scan(nc, nro, npe * 2, seed=9700 + nc)
-    for skip in (0, 160, 2700, 3000, 3400):
+    for skip in (160, 2700, 3000):                                             # (spokes 305 | 2817 | 3122 in the first window)
         fl = dict(golden_angle=1, data_undersamp=(npe + 0.5) / nro, prof_slide=npe, skip_angles=skip)
         got, dims = lib.recon(data, adjoint=True, **fl)
         want, _ = oracle.recon(data, adjoint=1, golden=1, data_undersamp=(npe + 0.5) / nro, prof_slide=npe, skip_angles=skip)

@@ -26,7 +26,7 @@ def test_random_shapes_on_scan_like_data(oracle):
     spec = importlib.util.spec_from_file_location("tron_fuzz", os.path.join(root, "tests", "fuzz_shapes.py"))
     fuzz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fuzz)
-    worst, failures = fuzz.run(40, 20261004, verbose=False, scan=True)
+    worst, failures = fuzz.run(24, 20261004, verbose=False, scan=True)
     assert not failures, failures
     assert worst <= 1e-5
 
