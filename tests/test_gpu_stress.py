@@ -80,3 +80,19 @@ def test_the_same_from_three_threads_at_once():
     for t in threads:
         t.join()
     assert sorted(results) == [20261010, 20261011, 20261012] and not any(results.values()), results
+
+
+def test_a_plan_that_does_not_fit_the_device_is_refused_cleanly():
+    """A work grid of 1.2 TB, then one of 300 GiB (just over the device's 288 GB): tron_plan_create returns TRON_ERR_NOMEM with the size in
+    the message, leaves nothing allocated, and the next plan of the process works."""
+    from tron_amd import lib
+    for nc, chunk in ((64, 600), (8, 1200)):
+        cfg = lib.default_config(adjoint=1, golden_angle=1, data_undersamp=0.05, prof_slide=100, chunk_slices=chunk)
+        dims = lib.derive_dims(cfg, (nc, 1, 2048, 100 * chunk, 1))
+        with pytest.raises(lib.TronError, match="cannot allocate"):
+            lib.Plan(cfg, dims)
+    data = synth.kspace(8, 256, 200, seed=5)
+    fl = dict(golden_angle=1, data_undersamp=100.5 / 256, prof_slide=100)
+    a, dims = lib.recon(data, adjoint=True, **fl)
+    b, _ = lib.recon(data, adjoint=True, **fl)
+    assert dims.nz == 2 and np.isfinite(a).all() and np.array_equal(a, b)
