@@ -52,6 +52,38 @@ def test_registered_and_pageable_large_buffers_give_the_same_bytes():
         assert np.array_equal(got, pageable), chunk
 
 
+def test_inputs_in_file_backed_shared_and_read_only_mappings(tmp_path):
+    """What a caller may hand over as k-space: a read-only or copy-on-write mapping of a file (np.memmap), a shared one, /dev/shm, an
+    anonymous mapping -- 36 MB each, so the call tries to register them (HostPins); whatever the driver makes of that, the bytes are those of
+    a pageable copy of an ordinary array."""
+    import mmap
+    nc, nro, npe, nz = 8, 256, 201, 11
+    data = synth.kspace(nc, nro, npe * nz, seed=1266)
+    fl = dict(golden_angle=1, prof_slide=npe, data_undersamp=(npe + 0.5) / nro)
+    ref, dims = lib.recon(data, adjoint=True, pin_host=0, **fl)
+    ref = np.asfortranarray(ref).reshape(-1, order="F")
+    flat = np.asfortranarray(data).reshape(-1, order="F")
+    cfg = lib.default_config(adjoint=1, pin_host=1, **fl)
+    shm = "/dev/shm/tron_test_%d.bin" % os.getpid()
+    try:
+        for kind in ("r", "c", "r+", "shm", "anonymous"):
+            path = shm if kind == "shm" else str(tmp_path / "in.bin")
+            if kind != "anonymous":
+                flat.tofile(path)
+                arr = np.memmap(path, dtype=np.complex64, mode="r+" if kind == "shm" else kind)
+            else:
+                m = mmap.mmap(-1, flat.nbytes)
+                m.write(flat.tobytes())
+                arr = np.frombuffer(m, dtype=np.complex64)
+            with lib.Plan(cfg, dims) as plan:
+                out = plan.recon(np.asarray(arr))
+            assert np.array_equal(out, ref), kind
+            del arr
+    finally:
+        if os.path.exists(shm):
+            os.remove(shm)
+
+
 def test_heap_resident_buffers_survive_a_worked_heap():
     """Round 6's fault (a copy from a hipHostRegister'ed buffer on the brk heap dies in about every third process once the heap has
     been worked, rounds 2-5): the sequence that showed it, in fresh processes, under the library's rule for what may be registered."""
